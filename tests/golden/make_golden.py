@@ -1,0 +1,216 @@
+"""Generate golden fixtures by running the REFERENCE (imported from /root/reference) on CPU.
+
+Run in the build container only (the reference never travels to the GPU box):
+
+    python tests/golden/make_golden.py
+
+Recipe: inert ``sys.modules`` stubs for the non-arithmetic modules the
+reference imports (toml, h5py, wandb, torchvision, torchlibrosa) and a stand-in
+``torchaudio.transforms`` whose MelSpectrogram returns a preset log-mel tensor (so no golden
+ever depends on the stand-in: every fixture starts at the log-mel input), then the model is
+built through the reference's own ``init_model_from_config`` from its AudioCaps YAML, the
+procedural weights of ``audiocaption_amd.procedural`` are loaded with ``load_state_dict`` and
+the reference modules are run.  Each result is also compared with ``oracle/cpu_path.py`` here,
+which is what pins the oracle.  Only inputs/outputs are written (``tests/golden/*.npz``).
+"""
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+_PRESET = {"lms": None}
+
+
+def _install_stubs():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    mod("toml", loads=lambda s: {}, load=lambda f: {})
+    mod("h5py")
+    mod("wandb", run=None)
+    mod("torchvision")
+
+    class SpecAugmentation(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+
+        def forward(self, x):
+            return x
+
+    tl = mod("torchlibrosa")
+    tl.augmentation = mod("torchlibrosa.augmentation", SpecAugmentation=SpecAugmentation)
+
+    class MelSpectrogram(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+
+        def forward(self, wav):
+            return _PRESET["lms"]
+
+    class AmplitudeToDB(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+
+        def forward(self, x):
+            return x
+
+    ta = mod("torchaudio")
+    ta.transforms = mod("torchaudio.transforms", MelSpectrogram=MelSpectrogram, AmplitudeToDB=AmplitudeToDB)
+    ta.functional = mod("torchaudio.functional")
+
+
+def main():
+    _install_stubs()
+    torch.manual_seed(0)
+    from captioning.utils import train_util  # noqa: E402  (reference)
+    from audiocaption_amd import procedural as P
+    from oracle import cpu_path as O
+
+    out_dir = os.path.dirname(os.path.abspath(__file__))
+    cfg = train_util.load_config(os.path.join(REF, "eg_configs/audiocaps/waveform/cnn14rnn_trm.yaml"))
+    V = cfg["model"]["decoder"]["args"]["vocab_size"]
+    model = train_util.init_model_from_config(cfg["model"], print_fn=lambda s: None)
+    state_np = P.cnn14rnn_trm_state(vocab_size=V)
+    state = P.to_torch(state_np)
+    missing = set(model.state_dict().keys()) ^ set(state.keys())
+    assert not missing, missing
+    model.load_state_dict(state, strict=True)
+    model.eval()
+    torch.set_grad_enabled(False)
+
+    report = {}
+
+    def cmp(name, a, b):
+        d = float((a - b).abs().max())
+        report[name] = d
+        print(f"  oracle vs reference  {name:28s} max|diff| = {d:.3e}")
+        return d
+
+    # ---- G1: log-mel -> Cnn14 blocks -> attn_emb -------------------------------------------
+    lms = torch.from_numpy(P.synthetic_logmel(2, 1001))
+    _PRESET["lms"] = lms
+    cnn = model.encoder.cnn
+    x = lms.transpose(1, 2).unsqueeze(1)
+    x = cnn.bn0(x.transpose(1, 3)).transpose(1, 3)
+    ref_blocks = []
+    for b in range(1, 7):
+        x = getattr(cnn, f"conv_block{b}")(x, pool_size=(2, 2) if b < 6 else (1, 1), pool_type="avg")
+        ref_blocks.append(x)
+    ref_cnn = cnn({"wav": torch.zeros(2, 320000), "wav_len": [320000, 320000], "specaug": False})
+    o_attn, o_blocks = O.cnn14_from_logmel(state, lms, return_blocks=True)
+    for b in range(6):
+        cmp(f"G1 conv_block{b + 1}", o_blocks[b], ref_blocks[b])
+    cmp("G1 attn_emb", o_attn, ref_cnn["attn_emb"])
+    assert torch.equal(ref_cnn["attn_emb_len"], O.cnn14_feat_len([320000, 320000]))
+    g1 = {"attn_emb": ref_cnn["attn_emb"].numpy()}
+    for b in range(6):
+        blk = ref_blocks[b]
+        g1[f"block{b + 1}_sum"] = blk.double().sum(dim=(2, 3)).numpy()  # (B, C) checksums
+        g1[f"block{b + 1}_abs_sum"] = blk.double().abs().sum(dim=(2, 3)).numpy()
+        g1[f"block{b + 1}_corner"] = blk[:, :8, :4, :2].numpy()
+    np.savez_compressed(os.path.join(out_dir, "g1_cnn14.npz"), **g1)
+
+    # ---- G2: GRU on ragged lengths -----------------------------------------------------------
+    attn = ref_cnn["attn_emb"]
+    for tag, lens in (("full", [31, 31]), ("ragged", [31, 20]), ("short", [7, 25])):
+        ref_rnn = model.encoder.rnn({"attn": attn, "attn_len": torch.tensor(lens)})
+        o_rnn = O.gru_forward(state, attn, lens)
+        cmp(f"G2 {tag} attn_emb", o_rnn["attn_emb"], ref_rnn["attn_emb"])
+        cmp(f"G2 {tag} fc_emb", o_rnn["fc_emb"], ref_rnn["fc_emb"])
+        np.savez_compressed(os.path.join(out_dir, f"g2_gru_{tag}.npz"), lens=np.array(lens),
+                            attn_emb=ref_rnn["attn_emb"].numpy(), fc_emb=ref_rnn["fc_emb"].numpy())
+
+    # ---- G4 inputs: B=4 ragged wav_len (reference smoke shapes cnn_encoder.py:845-849) -------
+    wav_len = [320000, 280000, 160000, 300000]
+    lms4 = torch.from_numpy(P.synthetic_logmel(4, 1001))
+    _PRESET["lms"] = lms4
+    inp = {"mode": "inference", "wav": torch.zeros(4, 320000), "wav_len": wav_len, "specaug": False}
+    ref_g = model(dict(inp, sample_method="greedy", max_length=20))
+    enc_attn, enc_len = ref_g["attn_emb"], ref_g["attn_emb_len"]
+    o_enc = O.gru_forward(state, O.cnn14_from_logmel(state, lms4), O.cnn14_feat_len(wav_len))
+    cmp("G4 encoder attn_emb", o_enc["attn_emb"], enc_attn)
+    cmp("G4 encoder fc_emb", o_enc["fc_emb"], ref_g["fc_emb"])
+    assert torch.equal(enc_len, o_enc["attn_emb_len"]), (enc_len, o_enc["attn_emb_len"])
+
+    # ---- G3: decoder, full (teacher-forced) sequence incl. a pad token ------------------------
+    g = torch.Generator().manual_seed(7)
+    word = torch.randint(4, V, (4, 12), generator=g)
+    word[:, 0] = 1
+    word[1, 5] = 0   # a generated pad-id token is masked as a key (transformer_model.py:55)
+    word[2, 9:] = 0
+    dec_in = {"word": word, "attn_emb": enc_attn, "attn_emb_len": enc_len, "cap_padding_mask": word == 0}
+    ref_d = model.decoder(dec_in)
+    o_d = O.decoder_forward(state, word, enc_attn, enc_len, word == 0)
+    cmp("G3 decoder embed", o_d["embed"], ref_d["embed"])
+    cmp("G3 decoder logit", o_d["logit"], ref_d["logit"])
+    top_v, top_i = ref_d["logit"].topk(8, dim=-1)
+    np.savez_compressed(os.path.join(out_dir, "g3_decoder.npz"), word=word.numpy(),
+                        attn_emb=enc_attn.numpy(), attn_emb_len=enc_len.numpy(),
+                        embed=ref_d["embed"].numpy(), logit_top_val=top_v.numpy(), logit_top_idx=top_i.numpy(),
+                        logit_row0=ref_d["logit"][0].numpy())
+
+    # ---- G4: greedy ------------------------------------------------------------------------
+    o_g = O.greedy_decode(state, o_enc["attn_emb"], o_enc["attn_emb_len"], 20)
+    print("  reference greedy seq:\n", ref_g["seq"].numpy())
+    assert torch.equal(o_g["seq"], ref_g["seq"]), (o_g["seq"], ref_g["seq"])
+    steps = o_g["steps"]
+    cmp("G4 greedy logit", o_g["logit"][:, :steps], ref_g["logit"][:, :steps])
+    cmp("G4 greedy logprob", o_g["sampled_logprob"][:, :steps], ref_g["sampled_logprob"][:, :steps])
+    cmp("G4 greedy embed", o_g["embed"][:, :steps], ref_g["embed"][:, :steps])
+    top2 = ref_g["logit"][:, :steps].topk(2, dim=-1).values
+    gap = (top2[..., 0] - top2[..., 1])
+    print(f"  greedy steps executed {steps}; min top1-top2 logit gap {float(gap.min()):.3e}")
+    np.savez_compressed(
+        os.path.join(out_dir, "g4_greedy.npz"), wav_len=np.array(wav_len), steps=np.array(steps),
+        attn_emb=enc_attn.numpy(), fc_emb=ref_g["fc_emb"].numpy(), attn_emb_len=enc_len.numpy(),
+        seq=ref_g["seq"].numpy(), sampled_logprob=ref_g["sampled_logprob"][:, :steps].numpy(),
+        embed=ref_g["embed"][:, :steps].numpy(), top2_gap=gap.numpy(),
+        logit_top_val=ref_g["logit"][:, :steps].topk(8, dim=-1).values.numpy(),
+        logit_top_idx=ref_g["logit"][:, :steps].topk(8, dim=-1).indices.numpy())
+
+    # ---- G5: beam 3 and 4 ---------------------------------------------------------------------
+    g5 = {"attn_emb_len": enc_len.numpy()}
+    for k in (3, 4):
+        ref_b = model(dict(inp, sample_method="beam", beam_size=k, max_length=20))
+        o_b = O.beam_search(state, o_enc["attn_emb"], o_enc["attn_emb_len"], k, 20)
+        print(f"  reference beam-{k} seq:\n", ref_b["seq"].numpy())
+        assert torch.equal(o_b["seq"], ref_b["seq"]), (o_b["seq"], ref_b["seq"])
+        g5[f"seq_beam{k}"] = ref_b["seq"].numpy()
+        g5[f"score_beam{k}"] = o_b["score"].numpy()
+    np.savez_compressed(os.path.join(out_dir, "g5_beam.npz"), **g5)
+
+    # ---- G7: LabelSmoothingLoss known answers (loss.py:51-74) ---------------------------------
+    sys.modules["wandb"].run = None
+    from captioning.losses.loss import LabelSmoothingLoss
+    logit = ref_d["logit"][:, :11]
+    tgt = word[:, 1:]
+    tgt_len = torch.tensor([11, 9, 8, 11])
+    loss = LabelSmoothingLoss(smoothing=0.1)({"logit": logit, "tgt": tgt, "tgt_len": tgt_len})
+    np.savez_compressed(os.path.join(out_dir, "g7_loss.npz"), tgt=tgt.numpy(), tgt_len=tgt_len.numpy(),
+                        loss=np.array(float(loss)))
+    print(f"  G7 label-smoothing loss = {float(loss):.6f}")
+
+    with open(os.path.join(out_dir, "REPORT.txt"), "w") as f:
+        f.write("max |oracle - reference| per fixture (written by make_golden.py, torch %s)\n" % torch.__version__)
+        for k, v in report.items():
+            f.write(f"{k:32s} {v:.3e}\n")
+        f.write(f"greedy steps {steps}, min top1-top2 gap {float(gap.min()):.3e}\n")
+    worst = max(report.values())
+    print(f"worst oracle-vs-reference diff: {worst:.3e}")
+    assert worst < 2e-4, "oracle does not match the reference"
+
+
+if __name__ == "__main__":
+    main()
