@@ -1,0 +1,107 @@
+"""ctypes binding of libaudiocaption_hip.so (declared in include/audiocaption_hip.h).
+
+The product path has NO fallback: if the library is missing or a call fails, an exception is
+raised.  Tensors are passed as raw device pointers together with the caller's current HIP stream.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaudiocaption_hip.so")
+
+AC_MAX_LAYERS = 8
+
+c_float_p = ctypes.c_void_p
+c_int_p = ctypes.c_void_p
+
+
+class AcTrmLayer(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in (
+        "sa_in_w", "sa_in_b", "sa_out_w", "sa_out_b", "ca_in_w", "ca_in_b", "ca_out_w", "ca_out_b",
+        "l1_w", "l1_b", "l2_w", "l2_b", "n1_w", "n1_b", "n2_w", "n2_b", "n3_w", "n3_b")]
+
+
+class AcTrmWeights(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "d_model", "nhead", "nlayers", "dim_ff", "vocab", "max_pos", "attn_emb_dim", "reserved")] + [
+        (n, ctypes.c_void_p) for n in ("emb", "pe", "cls_w", "proj_w", "proj_b", "proj_ln_w", "proj_ln_b")] + [
+        ("layer", AcTrmLayer * AC_MAX_LAYERS)]
+
+
+_I, _L, _F, _P = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p
+_WP = ctypes.POINTER(AcTrmWeights)
+
+# name -> (restype, argtypes); must list every symbol of include/audiocaption_hip.h
+SIGNATURES = {
+    "ac_abi_version": (_I, []),
+    "ac_logmel": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _L, _P]),
+    "ac_conv3x3_bn_relu": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ac_conv3x3_first": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ac_linear": (_I, [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _P]),
+    "ac_gru_layer": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "ac_mean_with_lens": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "ac_add_layernorm": (_I, [_P, _P, _P, _P, _P, _I, _I, _L, _L, _L, _P]),
+    "ac_trm_memory": (_I, [_WP, _P, _I, _I, _P, _P, _P]),
+    "ac_trm_workspace_floats": (_L, [_WP, _I, _I]),
+    "ac_trm_greedy": (_I, [_WP, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "ac_trm_forward_tokens": (_I, [_WP, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
+    "ac_trm_beam_step": (_I, [_WP, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P]),
+    "ac_trm_beam_reorder": (_I, [_WP, _I, _I, _I, _P, _P, _P]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Raises HipLibraryError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -m audiocaption_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback on the product path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ac_abi_version() != 1:
+        raise HipLibraryError("libaudiocaption_hip.so ABI version mismatch; rebuild it")
+    _lib = lib
+    return lib
+
+
+_ERR = {-1: "AC_ERR_ARG (arguments rejected)", -2: "AC_ERR_LAUNCH (HIP launch failed)"}
+
+
+def check(rc, what):
+    if rc != 0:
+        raise HipLibraryError(f"{what} failed: {_ERR.get(rc, rc)}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HipLibraryError("the HIP path needs tensors on a ROCm device (got a CPU tensor); "
+                              "there is no CPU fallback")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def f32c(t):
+    """Contiguous fp32 view/copy."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()

@@ -1,0 +1,74 @@
+"""Build libaudiocaption_hip.so (gfx950) in-tree with hipcc.
+
+``python -m audiocaption_amd.build`` or ``audiocaption_amd.build.build()``.  hipcc cross-compiles for
+gfx950 without a GPU, so this also runs in the CPU-only build container.  The .so is git-ignored
+but travels to the GPU box with the repository snapshot.
+"""
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libaudiocaption_hip.so")
+STAMP = LIB + ".stamp"
+SOURCES = ["logmel.hip", "conv3x3.hip", "gemm.hip", "gru.hip", "decoder.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
+         "-Wno-unused-function", "-Wno-unused-result"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (expected /opt/rocm/bin/hipcc)")
+
+
+def _digest():
+    h = hashlib.sha256()
+    for root in (CSRC, os.path.join(os.path.dirname(HERE), "include")):
+        for name in sorted(os.listdir(root)):
+            with open(os.path.join(root, name), "rb") as f:
+                h.update(name.encode())
+                h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=False):
+    """Compile every .hip source for gfx950 and link the shared library.  Returns its path."""
+    digest = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(STAMP):
+        with open(STAMP) as f:
+            if f.read().strip() == digest:
+                return LIB
+    hipcc = _hipcc()
+    objs = []
+    procs = []
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    for src in SOURCES:
+        obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+        cmd = [hipcc, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj] + FLAGS
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(obj)
+    for src, pr in procs:
+        out = pr.communicate()[0].decode()
+        if pr.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+        if verbose and out.strip():
+            print(out)
+    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stdout.decode())
+    with open(STAMP, "w") as f:
+        f.write(digest)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,172 @@
+"""Cnn14 waveform encoder, MI355X path.  Plugin-compatible with the reference class
+``captioning.models.cnn_encoder.Cnn14Encoder`` (cnn_encoder.py:330-464): same constructor, same
+``forward(input_dict) -> {"fc_emb", "attn_emb", "attn_emb_len"}`` contract, same ``state_dict()`` keys
+(SURVEY.md §2.4), same ``load_pretrained`` hook.
+
+The torch.nn sub-modules below only OWN the parameters (so checkpoints, ``.to()``, optimizers and
+``named_parameters`` behave exactly like the reference); the forward pass never calls them: it runs
+log-mel -> bn0 -> 12 x (conv3x3 + BN + ReLU [+ pool]) -> mean over mel entirely in the HIP kernels of
+``csrc/logmel.hip`` and ``csrc/conv3x3.hip`` and fails loudly if they are unavailable.
+"""
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+from .mel import MelTables
+
+CHANNELS = [1, 64, 128, 256, 512, 1024, 2048]
+
+
+class ConvBlock(nn.Module):
+    """Parameter container for two bias-free 3x3 convs + BatchNorms (reference cnn_encoder.py:32-57)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_channels, out_channels, (3, 3), (1, 1), (1, 1), bias=False)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, (3, 3), (1, 1), (1, 1), bias=False)
+        self.bn1 = nn.BatchNorm2d(out_channels)
+        self.bn2 = nn.BatchNorm2d(out_channels)
+        for conv in (self.conv1, self.conv2):
+            nn.init.xavier_uniform_(conv.weight)
+
+
+def cnn14_feat_len(wav_len, hop, ratio=32):
+    """attn_emb_len = floor((floor(L / hop) + 1) / 32) as a CPU int64 tensor (cnn_encoder.py:446-450)."""
+    wav_len = torch.as_tensor(wav_len).cpu()
+    n = torch.div(wav_len, hop, rounding_mode="floor") + 1
+    return torch.div(n, ratio, rounding_mode="floor").long()
+
+
+class Cnn14Encoder(nn.Module):
+
+    def __init__(self, sample_rate=32000, freeze=False):
+        super().__init__()
+        sr_to_fmax = {32000: 14000, 16000: 8000}
+        self.sample_rate = sample_rate
+        self.n_fft = 32 * sample_rate // 1000
+        self.hop_length = 10 * sample_rate // 1000
+        self.f_min, self.f_max = 50.0, float(sr_to_fmax[sample_rate])
+        self.bn0 = nn.BatchNorm2d(64)
+        for b in range(6):
+            setattr(self, f"conv_block{b + 1}", ConvBlock(CHANNELS[b], CHANNELS[b + 1]))
+        self.downsample_ratio = 32
+        self.fc1 = nn.Linear(2048, 2048, bias=True)
+        nn.init.xavier_uniform_(self.fc1.weight)
+        nn.init.zeros_(self.fc1.bias)
+        self.fc_emb_size = 2048
+        self.freeze = freeze
+        self._tables = None
+        self._packed = None
+        self._packed_key = None
+        self._bufs = {}
+
+    # ---- checkpoint hook (reference cnn_encoder.py:376-412: PANNs / COLA / BLAT layouts) ----------
+    def load_pretrained(self, pretrained, output_fn=print):
+        checkpoint = torch.load(pretrained, map_location="cpu")
+        if "model" in checkpoint:
+            sd = checkpoint["model"]
+            if any(k.startswith("backbone.") for k in sd):  # COLA
+                sd = {k[len("backbone."):]: v for k, v in sd.items() if k.startswith("backbone.")}
+        elif "state_dict" in checkpoint:  # BLAT
+            sd = {k.replace("audio_encoder.", ""): v for k, v in checkpoint["state_dict"].items()
+                  if "audio_encoder" in k}
+        else:
+            raise Exception("Unkown checkpoint format")
+        own = self.state_dict()
+        loaded = {k: v for k, v in sd.items() if k in own and own[k].shape == v.shape}
+        output_fn(f"Loading pre-trained model, with mismatched keys {[k for k in sd if k not in loaded]}\n")
+        own.update(loaded)
+        self.load_state_dict(own, strict=True)
+        if self.freeze:
+            for name, param in self.named_parameters():
+                param.requires_grad = name not in loaded
+
+    # ---- weight packing for the kernels (cached; invalidated by in-place updates / .to()) ----------
+    def _pack(self, device):
+        tensors = [self.bn0.weight, self.bn0.bias, self.bn0.running_mean, self.bn0.running_var]
+        for b in range(6):
+            blk = getattr(self, f"conv_block{b + 1}")
+            for conv, bn in ((blk.conv1, blk.bn1), (blk.conv2, blk.bn2)):
+                tensors += [conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var]
+        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        if self._packed is not None and key == self._packed_key:
+            return self._packed
+        with torch.no_grad():
+            pk = {"bn0": K.fold_bn(self.bn0.weight.float(), self.bn0.bias.float(), self.bn0.running_mean.float(),
+                                   self.bn0.running_var.float(), self.bn0.eps), "convs": []}
+            for b in range(6):
+                blk = getattr(self, f"conv_block{b + 1}")
+                for j, (conv, bn) in enumerate(((blk.conv1, blk.bn1), (blk.conv2, blk.bn2))):
+                    w = conv.weight.detach().float()
+                    if b == 0 and j == 0:
+                        wp = w.reshape(64, 9).contiguous()
+                    else:
+                        wp = K.pack_conv_weight(w)
+                    sc, sh = K.fold_bn(bn.weight.float(), bn.bias.float(), bn.running_mean.float(),
+                                       bn.running_var.float(), bn.eps)
+                    pk["convs"].append((wp, sc, sh))
+        self._packed, self._packed_key = pk, key
+        return pk
+
+    def _buf(self, name, numel, device):
+        b = self._bufs.get(name)
+        if b is None or b.numel() < numel or b.device != device:
+            b = torch.empty(numel, device=device, dtype=torch.float32)
+            self._bufs[name] = b
+        return b
+
+    def geometry(self, n_samples):
+        """Valid (H) and physical (Hp) row counts of the 6 resolution levels for an L-sample batch."""
+        T = n_samples // self.hop_length + 1
+        H = [T >> k for k in range(6)]
+        if H[5] < 1:
+            raise ValueError(f"clips of {n_samples} samples are shorter than one Cnn14 output frame")
+        Hp = [(H[5] + 1) << (5 - k) for k in range(6)]
+        return T, H, Hp
+
+    def encode(self, wav):
+        """wav (B, L) on the ROCm device -> attn_emb (B, T // 32, 2048)."""
+        if wav.dim() != 2:
+            raise ValueError("wav must be (batch, samples)")
+        dev = wav.device
+        if self._tables is None or self._tables.window.device != dev:
+            self._tables = MelTables(self.sample_rate, self.n_fft, self.hop_length, self.f_min, self.f_max, 64,
+                                     "slaney", "slaney", dev)
+        pk = self._pack(dev)
+        B, L = wav.shape
+        T, H, Hp = self.geometry(L)
+        x0 = K.logmel(wav, self._tables, pk["bn0"][0], pk["bn0"][1], rows_per_clip=Hp[0], channels_last=True)
+        full = self._buf("full", B * Hp[0] * 64 * 64, dev)      # conv1 outputs (largest: level 1)
+        pooled = self._buf("pooled", B * Hp[1] * 32 * 64, dev)  # block outputs (largest: block 1)
+        W = 64
+        for b in range(6):
+            cin, cout = CHANNELS[b], CHANNELS[b + 1]
+            w1, s1, t1 = pk["convs"][2 * b]
+            w2, s2, t2 = pk["convs"][2 * b + 1]
+            if b == 0:
+                K.conv3x3_first(x0, w1, s1, t1, full, B, Hp[0], H[0], W)
+            else:
+                K.conv3x3_bn_relu(pooled, w1, s1, t1, full, B, Hp[b], H[b], W, cin, cout, 0)
+            if b < 5:
+                K.conv3x3_bn_relu(full, w2, s2, t2, pooled, B, Hp[b], H[b], W, cout, cout, 1)
+                W //= 2
+            else:
+                attn = torch.empty(B, H[5], cout, device=dev, dtype=torch.float32)
+                K.conv3x3_bn_relu(full, w2, s2, t2, attn, B, Hp[b], H[b], W, cout, cout, 2)
+        return attn
+
+    def forward(self, input_dict, skip_fc=False):
+        if self.training:
+            raise NotImplementedError(
+                "Cnn14Encoder (HIP path): only the eval-mode forward exists so far; the training forward "
+                "(dropout, SpecAugment, backward) is not built yet")
+        wav = input_dict["wav"]
+        attn_emb = self.encode(wav)
+        feat_length = cnn14_feat_len(input_dict["wav_len"], self.hop_length, self.downsample_ratio)
+        out = {"attn_emb": attn_emb, "attn_emb_len": feat_length}
+        if not skip_fc:
+            # Cnn14's own clip embedding (cnn_encoder.py:451-456); CrnnEncoder discards it.
+            lens = feat_length.to(device=wav.device, dtype=torch.int32)
+            pooled = K.mean_with_lens(attn_emb, lens, add_max=True)
+            out["fc_emb"] = K.linear(pooled, self.fc1.weight.float(), self.fc1.bias.float(), relu=True)
+        return out

@@ -1,0 +1,345 @@
+// Cnn14 conv stack on gfx950: 3x3 / stride 1 / pad 1 convolution + eval-mode BatchNorm + ReLU
+// (+ 2x2 average pooling, or the final mean over the 2 mel columns) as ONE implicit-GEMM kernel
+// on the exact-f32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Replaces reference ConvBlock.forward (cnn_encoder.py:59-75) and the pooling / mean / transpose
+// glue of Cnn14Encoder.forward (cnn_encoder.py:431-444).
+//
+// Data layout (chosen for the GEMM, not inherited from NCHW):
+//   activations  [B * Hp][W][C]  fp32, channels-last.  H = time, W = mel.  Every clip owns Hp >= H+1
+//                physical rows; rows h >= H are ZERO.  They are the conv's vertical zero padding
+//                (one shared pad row separates consecutive clips) and make Hp_k = 2 * Hp_{k+1}, so a
+//                2x2 pooling window never straddles two clips and M-tiles may span clips freely.
+//   weights      [Cin/32][9 taps][Cout][32]  (packed once on the host side from OIHW)
+//   BN           folded to per-channel scale/shift applied to the f32 accumulator in the epilogue.
+//
+// GEMM view: M = B*Hp*W output pixels, N = Cout, K = 9*Cin.  A 256-thread block owns a 128-pixel
+// (TR rows x TC cols, TC = min(W,16)) by BN-channel tile; per 32-channel K-chunk it stages the
+// (TR+2)x(TC+2) input halo patch in LDS once and re-uses it for all 9 taps, streaming the 9 weight
+// slabs through a double-buffered LDS ring (global -> VGPR issued before the MFMAs of the current
+// tap, VGPR -> LDS after them).  The row index i of every 32x32 MFMA tile is laid out as
+// i = 4*window + 2*dy + dx, so the four pixels of a pooling window sit in four consecutive
+// accumulator registers of one lane and pooling costs three adds in the epilogue.
+#include "ac_common.h"
+
+namespace {
+
+constexpr int LDS_STRIDE = 36;       // 32 channels + 4 pad floats: 144-byte rows keep b128 reads aligned
+constexpr int MAX_NPIX = 66 * 4;     // largest halo patch: W = 2 -> (64+2) x (2+2)
+
+struct ConvParams {
+  const float* in;
+  const float* wpk;
+  const float* scale;
+  const float* shift;
+  float* out;
+  int rows_total, Hp, H, W, Cin, Cout;
+  int tc_log2, mt_cols, MT, NT;
+  int Hp_out, H_out, W_out;
+  int map_mode;
+};
+
+enum { MODE_FULL = 0, MODE_POOL = 1, MODE_MEANW = 2 };
+
+template <int BN, int MODE>
+__global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(ConvParams p) {
+  constexpr int NTW = BN / 64;  // 32-wide MFMA column tiles per wave
+  __shared__ __attribute__((aligned(16))) float sA[MAX_NPIX * LDS_STRIDE];
+  __shared__ __attribute__((aligned(16))) float sB[2][BN * LDS_STRIDE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int half = lane >> 5;
+
+  // ---- block -> (m_tile, n_tile); block b runs on XCD b % 8 (speed only, never correctness) ----
+  int m_tile, n_tile;
+  {
+    const int bid = blockIdx.x;
+    if (p.map_mode == 1) {         // weight-heavy layers: one XCD streams one weight column slab
+      const int xcd = bid & 7, seq = bid >> 3;
+      n_tile = xcd + 8 * (seq / p.MT);
+      m_tile = seq % p.MT;
+    } else if (p.map_mode == 2) {  // activation-heavy layers: blocks sharing a halo patch share an L2
+      const int xcd = bid & 7, seq = bid >> 3;
+      n_tile = seq % p.NT;
+      m_tile = (seq / p.NT) * 8 + xcd;
+      if (m_tile >= p.MT) return;
+    } else {
+      n_tile = bid % p.NT;
+      m_tile = bid / p.NT;
+    }
+  }
+  const int TC = 1 << p.tc_log2;
+  const int TR = 128 >> p.tc_log2;
+  const int PW = TC + 2, PH = TR + 2;
+  const int NPIX = PW * PH;
+  const int row0 = (m_tile / p.mt_cols) * TR;
+  const int col0 = (m_tile % p.mt_cols) * TC;
+
+  // ---- lane geometry: pixel of MFMA row i = 4*q + 2*dy + dx ----
+  const int QR2 = 32 >> p.tc_log2;  // rows covered by one 32-pixel MFMA tile
+  int ty0[2], tx0;                  // top-left pixel (inside the tile) of this lane's A row, dy = dx = 0
+  int pbase[2];
+  {
+    const int i = lane & 31;
+    const int q = i >> 2, dy = (i >> 1) & 1, dx = i & 1;
+    const int qc = q & ((TC >> 1) - 1);
+    const int qr = q >> (p.tc_log2 - 1);
+    tx0 = 2 * qc;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      ty0[m] = (2 * wm + m) * QR2 + 2 * qr;
+      pbase[m] = ((ty0[m] + dy) * PW + tx0 + dx) * LDS_STRIDE + half * 4;
+    }
+  }
+  int nbase[NTW];
+#pragma unroll
+  for (int n = 0; n < NTW; ++n) nbase[n] = ((wn * NTW + n) * 32 + (lane & 31)) * LDS_STRIDE + half * 4;
+
+  f32x16 acc[2][NTW];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < NTW; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  // tiles lying entirely in one clip's zero rows only have to write zeros
+  const int rc0 = row0 % p.Hp;
+  const bool all_pad = (rc0 >= p.H && rc0 + TR <= p.Hp) || row0 >= p.rows_total;
+
+  const int nchunk = p.Cin >> 5;
+  constexpr int BLD = BN * 8 / 256;  // float4 weight loads per thread per tap
+  if (!all_pad) {
+    // weight slab of flattened step it = chunk*9 + tap: [BN][32] floats, contiguous
+    const float* wsrc = p.wpk + (size_t)n_tile * BN * 32 + (size_t)tid * 4;
+    const size_t slab_stride = (size_t)p.Cout * 32;
+    const int total = nchunk * 9;
+    auto stage_patch = [&](int c) {
+      for (int idx = tid; idx < NPIX * 8; idx += 256) {
+        const int pix = idx >> 3, c4 = idx & 7;
+        const int pr = pix / PW, pc = pix - pr * PW;
+        const int gr = row0 - 1 + pr, gc = col0 - 1 + pc;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gr >= 0 && gr < p.rows_total && gc >= 0 && gc < p.W)
+          v = *(const float4*)(p.in + ((size_t)gr * p.W + gc) * p.Cin + c * 32 + c4 * 4);
+        *(float4*)(sA + pix * LDS_STRIDE + c4 * 4) = v;
+      }
+    };
+    stage_patch(0);
+#pragma unroll
+    for (int u = 0; u < BLD; ++u) {
+      const int idx = tid + u * 256;
+      *(float4*)(&sB[0][(idx >> 3) * LDS_STRIDE + (idx & 7) * 4]) = *(const float4*)(wsrc + (size_t)u * 1024);
+    }
+    __syncthreads();
+    int tap = 0, c = 0;
+#pragma unroll 1
+    for (int it = 0; it < total; ++it) {
+      // global -> VGPR for the next slab is issued before this slab's MFMAs and lands in LDS after them
+      const int nxt = it + 1 < total ? it + 1 : it;
+      f32x4 breg[BLD];
+#pragma unroll
+      for (int u = 0; u < BLD; ++u) breg[u] = *(const f32x4*)(wsrc + (size_t)nxt * slab_stride + (size_t)u * 1024);
+      __builtin_amdgcn_sched_barrier(0);  // keep the loads ahead of the MFMA block (hipcc sinks them otherwise)
+      const int ky = tap / 3, kx = tap - 3 * ky;
+      const float* a_tap = sA + (ky * PW + kx) * LDS_STRIDE;
+      const float* b_cur = sB[it & 1];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 a[2], b[NTW];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) a[m] = *(const f32x4*)(a_tap + pbase[m] + g * 8);
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) b[n] = *(const f32x4*)(b_cur + nbase[n] + g * 8);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) acc[m][n] = mfma32(a[m][s], b[n][s], acc[m][n]);
+      }
+      float* b_nxt = sB[(it + 1) & 1];
+#pragma unroll
+      for (int u = 0; u < BLD; ++u) {
+        const int idx = tid + u * 256;
+        *(f32x4*)(b_nxt + (idx >> 3) * LDS_STRIDE + (idx & 7) * 4) = breg[u];
+      }
+      __syncthreads();
+      if (++tap == 9) {
+        tap = 0;
+        if (++c < nchunk) {
+          stage_patch(c);
+          __syncthreads();
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: BN scale/shift, ReLU, pooling, zero rows; lanes 0..31 store 32 consecutive channels ----
+#pragma unroll
+  for (int n = 0; n < NTW; ++n) {
+    const int ch = n_tile * BN + (wn * NTW + n) * 32 + (lane & 31);
+    const float sc = p.scale[ch], sh = p.shift[ch];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        // window q = 2*rq + half of this MFMA tile; registers 4*rq + (2*dy + dx)
+        const int q = 2 * rq + half;
+        const int qc = q & ((TC >> 1) - 1);
+        const int qr = q >> (p.tc_log2 - 1);
+        const int wy = row0 + (2 * wm + m) * QR2 + 2 * qr;  // physical row of the window's dy = 0
+        const int wx = col0 + 2 * qc;
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = fmaxf(fmaf(acc[m][n][4 * rq + e], sc, sh), 0.f);
+        if (MODE == MODE_FULL) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int gr = wy + (e >> 1), gc = wx + (e & 1);
+            if (gr < p.rows_total) {
+              const bool valid = (gr % p.Hp) < p.H;
+              p.out[((size_t)gr * p.W + gc) * p.Cout + ch] = valid ? y[e] : 0.f;
+            }
+          }
+        } else if (MODE == MODE_POOL) {
+          const int orow = wy >> 1, ocol = wx >> 1;
+          if (wy < p.rows_total) {
+            const bool valid = (orow % p.Hp_out) < p.H_out;
+            const float o = 0.25f * ((y[0] + y[1]) + (y[2] + y[3]));
+            p.out[((size_t)orow * p.W_out + ocol) * p.Cout + ch] = valid ? o : 0.f;
+          }
+        } else {  // MODE_MEANW: W == 2, mean over the two mel columns, dense (B, H, Cout) output
+#pragma unroll
+          for (int dy = 0; dy < 2; ++dy) {
+            const int gr = wy + dy;
+            if (gr < p.rows_total) {
+              const int b = gr / p.Hp, h = gr - b * p.Hp;
+              if (h < p.H) p.out[((size_t)b * p.H + h) * p.Cout + ch] = 0.5f * (y[2 * dy] + y[2 * dy + 1]);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// First conv of block 1: Cin = 1, K = 9 - not a GEMM.  HBM-write bound (64 channels out per pixel).
+// 16 lanes cover the 64 output channels of one pixel (float4 each), so a wave stores 1 KiB contiguous.
+// ------------------------------------------------------------------------------------------------
+struct ConvFirstParams {
+  const float* in;    // [rows_total][W]
+  const float* w;     // [64][9]  (OIHW with I = 1)
+  const float* scale;
+  const float* shift;
+  float* out;         // [rows_total][W][64]
+  int rows_total, Hp, H, W;
+};
+
+__global__ __launch_bounds__(256) void conv_first_kernel(ConvFirstParams p) {
+  constexpr int RT = 4;  // rows per block
+  __shared__ float patch[RT + 2][64 + 2];
+  const int tid = threadIdx.x;
+  const int row0 = blockIdx.x * RT;
+  for (int idx = tid; idx < (RT + 2) * 66; idx += 256) {
+    const int pr = idx / 66, pc = idx - pr * 66;
+    const int gr = row0 - 1 + pr, gc = pc - 1;
+    float v = 0.f;
+    if (gr >= 0 && gr < p.rows_total && gc >= 0 && gc < p.W) v = p.in[(size_t)gr * p.W + gc];
+    patch[pr][pc] = v;
+  }
+  const int cg = tid & 15, ps = tid >> 4;
+  float w[4][9], sc[4], sh[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    sc[j] = p.scale[cg * 4 + j];
+    sh[j] = p.shift[cg * 4 + j];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) w[j][t] = p.w[(cg * 4 + j) * 9 + t];
+  }
+  __syncthreads();
+  for (int px = ps; px < RT * p.W; px += 16) {
+    const int r = px / p.W, c = px - r * p.W;
+    const int gr = row0 + r;
+    if (gr >= p.rows_total) break;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((gr % p.Hp) < p.H) {
+      float x[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) x[t] = patch[r + t / 3][c + t % 3];
+      float a[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) s = fmaf(x[t], w[j][t], s);
+        a[j] = fmaxf(fmaf(s, sc[j], sh[j]), 0.f);
+      }
+      o = make_float4(a[0], a[1], a[2], a[3]);
+    }
+    *(float4*)(p.out + ((size_t)gr * p.W + c) * 64 + cg * 4) = o;
+  }
+}
+
+template <int BN, int MODE>
+int launch_conv(const ConvParams& p, hipStream_t s) {
+  unsigned grid;
+  if (p.map_mode == 2) grid = (unsigned)(((p.MT + 7) / 8) * 8 * p.NT);
+  else grid = (unsigned)(p.MT * p.NT);
+  hipLaunchKernelGGL((conv3x3_mfma_kernel<BN, MODE>), dim3(grid), dim3(256), 0, s, p);
+  return ac_check_launch();
+}
+
+}  // namespace
+
+// C ABI: see include/audiocaption_hip.h
+extern "C" int ac_conv3x3_bn_relu(const float* in, const float* wpk, const float* scale, const float* shift,
+                                  float* out, int B, int Hp, int H, int W, int Cin, int Cout, int mode,
+                                  int map_mode, void* stream) {
+  if (!in || !wpk || !scale || !shift || !out) return AC_ERR_ARG;
+  if (B <= 0 || Hp <= H || W < 2 || (W & (W - 1)) || Cin % 32 || Cout % 64) return AC_ERR_ARG;
+  if (mode < 0 || mode > 2) return AC_ERR_ARG;
+  if (mode == MODE_POOL && (Hp & 1)) return AC_ERR_ARG;
+  if (mode == MODE_MEANW && W != 2) return AC_ERR_ARG;
+  ConvParams p;
+  p.in = in; p.wpk = wpk; p.scale = scale; p.shift = shift; p.out = out;
+  p.rows_total = B * Hp; p.Hp = Hp; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+  const int TC = W < 16 ? W : 16;
+  int l2 = 0;
+  while ((1 << l2) < TC) ++l2;
+  p.tc_log2 = l2;
+  const int TR = 128 / TC;
+  p.mt_cols = W / TC;
+  p.MT = ((p.rows_total + TR - 1) / TR) * p.mt_cols;
+  const int BN = (Cout % 128 == 0) ? 128 : 64;
+  p.NT = Cout / BN;
+  p.Hp_out = Hp / 2; p.H_out = H / 2; p.W_out = W / 2;
+  if (map_mode < 0) map_mode = (p.NT % 8 == 0) ? 1 : 2;  // default: see the kernel's mapping comment
+  if (map_mode == 1 && p.NT % 8 != 0) return AC_ERR_ARG;
+  p.map_mode = map_mode;
+  hipStream_t s = (hipStream_t)stream;
+  if (BN == 128) {
+    if (mode == MODE_FULL) return launch_conv<128, MODE_FULL>(p, s);
+    if (mode == MODE_POOL) return launch_conv<128, MODE_POOL>(p, s);
+    return launch_conv<128, MODE_MEANW>(p, s);
+  } else {
+    if (mode == MODE_FULL) return launch_conv<64, MODE_FULL>(p, s);
+    if (mode == MODE_POOL) return launch_conv<64, MODE_POOL>(p, s);
+    return launch_conv<64, MODE_MEANW>(p, s);
+  }
+}
+
+extern "C" int ac_conv3x3_first(const float* in, const float* w, const float* scale, const float* shift,
+                                float* out, int B, int Hp, int H, int W, void* stream) {
+  if (!in || !w || !scale || !shift || !out || B <= 0 || Hp <= H || W != 64) return AC_ERR_ARG;
+  ConvFirstParams p;
+  p.in = in; p.w = w; p.scale = scale; p.shift = shift; p.out = out;
+  p.rows_total = B * Hp; p.Hp = Hp; p.H = H; p.W = W;
+  const unsigned grid = (unsigned)((p.rows_total + 3) / 4);
+  hipLaunchKernelGGL(conv_first_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  return ac_check_launch();
+}

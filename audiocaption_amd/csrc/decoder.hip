@@ -1,0 +1,508 @@
+// Autoregressive Transformer decoder on gfx950: memory preparation, the per-position decoder step with
+// a self-attention KV cache, on-device greedy search and the device half of beam search.
+//
+// Replaces reference TransformerDecoder.forward (transformer_decoder.py:80-103), the decode loops
+// CaptionModel.stepwise_forward / sample_next_word / beam_search (base.py:152-325) and
+// TransformerModel.prepare_decoder_input (transformer_model.py:34-86).
+//
+// What is different from the reference's schedule (results are the same function of the inputs):
+//  * the reference re-runs the decoder on the WHOLE prefix every step and recomputes attn_proj and
+//    the cross-attention K/V projections of the audio memory on every call; here the memory side is
+//    computed once per batch (ac_trm_memory) and each step processes only the new position against
+//    cached self-attention K/V (the causal mask makes position t independent of later tokens);
+//  * the greedy loop never returns to the host: argmax, log-prob, <end> bookkeeping and the
+//    "every clip finished" test live in one kernel per step, so a whole decode is a fixed launch
+//    sequence on one stream.
+// Projections run on the f32 matrix cores through ac_linear; softmax / LayerNorm reductions are
+// 64-lane wavefront shuffles.
+#include "ac_common.h"
+#include "../../include/audiocaption_hip.h"
+
+extern "C" int ac_linear(const float* X, const float* W, const float* bias, float* Y, int M, int N, int K,
+                         long ldx, long ldw, long ldy, int relu, void* stream);
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// x[r][:] = E[tok[r][t]] * sqrt(d) + pe[t]                     (transformer_decoder.py:89-91)
+// ---------------------------------------------------------------------------------------------
+__global__ void embed_pe_kernel(const int* tok, long tok_stride, int t, const float* emb, const float* pe,
+                                float scale, float* x, int d) {
+  const int r = blockIdx.x;
+  const int w = tok[(size_t)r * tok_stride + t];
+  for (int c = threadIdx.x; c < d; c += blockDim.x)
+    x[(size_t)r * d + c] = emb[(size_t)w * d + c] * scale + pe[(size_t)t * d + c];
+}
+
+// ---------------------------------------------------------------------------------------------
+// out = LayerNorm(x + y) * w + b, one wave per row
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void add_layernorm_kernel(const float* x, const float* y, const float* w,
+                                                            const float* b, float* out, int rows, int d,
+                                                            long ldx, long ldy, long ldo) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * ldx;
+  const float* yr = y ? y + (size_t)row * ldy : nullptr;
+  float v[16];  // d <= 1024
+  float s = 0.f;
+  int n = 0;
+  for (int c = lane; c < d; c += 64, ++n) {
+    v[n] = xr[c] + (yr ? yr[c] : 0.f);
+    s += v[n];
+  }
+  const float mean = wave_sum(s) / (float)d;
+  float q = 0.f;
+  for (int i = 0; i < n; ++i) {
+    const float dlt = v[i] - mean;
+    q = fmaf(dlt, dlt, q);
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)d + 1e-5f);
+  n = 0;
+  for (int c = lane; c < d; c += 64, ++n) out[(size_t)row * ldo + c] = (v[n] - mean) * rstd * w[c] + b[c];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Single-query multi-head attention for one decode position.  grid (rows, heads), one wave each.
+//   self  : keys 0..t from the KV cache (the new k/v row is appended here), key j masked when
+//           key_mask[r][j] != 0                      (tgt_key_padding_mask, transformer_model.py:55)
+//   cross : keys 0..Tm-1 of the projected audio memory, key j masked when j >= key_len[r / row_div]
+//           (memory_key_padding_mask, transformer_decoder.py:94)
+// ---------------------------------------------------------------------------------------------
+constexpr int MAX_KEYS = 1024;
+
+struct AttnParams {
+  const float* q; long ldq;
+  const float* K; const float* V;        // key j of kv-row R at K + R*row_stride + j*key_stride
+  long row_stride, key_stride;
+  int row_div, nkeys;
+  const int* key_len;                     // per kv-row valid length or null
+  const unsigned char* key_mask; long mask_stride;  // per row or null
+  const float* new_k; const float* new_v; long ld_new;  // appended at key index nkeys-1 when non-null
+  float* Kw; float* Vw;                   // writable cache base (same geometry as K/V) for the append
+  float* out; long ldo;
+  int hd; float scale;
+};
+
+__global__ __launch_bounds__(64) void attn_step_kernel(AttnParams p) {
+  __shared__ float sc[MAX_KEYS];
+  const int r = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+  const int kr = r / p.row_div;
+  const bool act = lane < p.hd;
+  const size_t hoff = (size_t)h * p.hd + lane;
+  if (p.new_k && act) {
+    const size_t dst = (size_t)kr * p.row_stride + (size_t)(p.nkeys - 1) * p.key_stride + hoff;
+    p.Kw[dst] = p.new_k[(size_t)r * p.ld_new + hoff];
+    p.Vw[dst] = p.new_v[(size_t)r * p.ld_new + hoff];
+  }
+  __syncthreads();
+  const float qv = act ? p.q[(size_t)r * p.ldq + hoff] * p.scale : 0.f;
+  const float* Kb = p.K + (size_t)kr * p.row_stride + hoff;
+  const float* Vb = p.V + (size_t)kr * p.row_stride + hoff;
+  const int klen = p.key_len ? p.key_len[kr] : p.nkeys;
+  for (int j = 0; j < p.nkeys; ++j) {
+    const float s = wave_sum(act ? qv * Kb[(size_t)j * p.key_stride] : 0.f);
+    const bool masked = (j >= klen) || (p.key_mask && p.key_mask[(size_t)r * p.mask_stride + j]);
+    if (lane == 0) sc[j] = masked ? -INFINITY : s;
+  }
+  __syncthreads();
+  float m = -INFINITY;
+  for (int j = lane; j < p.nkeys; j += 64) m = fmaxf(m, sc[j]);
+  m = wave_max(m);
+  float den = 0.f;
+  for (int j = lane; j < p.nkeys; j += 64) {
+    const float e = expf(sc[j] - m);
+    sc[j] = e;
+    den += e;
+  }
+  den = wave_sum(den);
+  __syncthreads();
+  if (act) {
+    float o = 0.f;
+    for (int j = 0; j < p.nkeys; ++j) o = fmaf(sc[j], Vb[(size_t)j * p.key_stride], o);
+    p.out[(size_t)r * p.ldo + hoff] = o / den;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// greedy pick for step t (base.py:214-218 log_softmax + max, :161-167, :202-208)
+// ---------------------------------------------------------------------------------------------
+struct PickParams {
+  const float* logit; long ldl;  // row b at logit + b*ldl (already offset to step t)
+  int V, t, max_len, end_idx, pad_idx;
+  int64_t* seq; float* logprob;
+  int* tok; unsigned char* mask;  // [B][max_len+1]
+  int* unfinished;                // [B]
+  int* cnt;                       // [max_len]
+};
+
+__device__ __forceinline__ void argmax_merge(float& v, int& i, float ov, int oi) {
+  if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+
+__global__ __launch_bounds__(256) void greedy_pick_kernel(PickParams p) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  __shared__ float ssum[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (p.t > 0 && p.cnt[p.t - 1] == 0) return;  // the reference loop has already stopped (base.py:167)
+  const float* row = p.logit + (size_t)b * p.ldl;
+  float v = -INFINITY;
+  int idx = 0x7fffffff;
+  for (int c = tid; c < p.V; c += 256) argmax_merge(v, idx, row[c], c);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(v, o, 64);
+    const int oi = __shfl_xor(idx, o, 64);
+    argmax_merge(v, idx, ov, oi);
+  }
+  if (lane == 0) { sv[wave] = v; si[wave] = idx; }
+  __syncthreads();
+  v = sv[0]; idx = si[0];
+#pragma unroll
+  for (int k = 1; k < 4; ++k) argmax_merge(v, idx, sv[k], si[k]);
+  float s = 0.f;
+  for (int c = tid; c < p.V; c += 256) s += expf(row[c] - v);
+  s = wave_sum(s);
+  if (lane == 0) ssum[wave] = s;
+  __syncthreads();
+  if (tid == 0) {
+    const float tot = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);
+    const int prev = p.t == 0 ? 1 : p.unfinished[b];
+    const int unf = prev && (idx != p.end_idx);
+    const int w = unf ? idx : p.end_idx;
+    p.unfinished[b] = unf;
+    p.seq[(size_t)b * p.max_len + p.t] = w;
+    p.logprob[(size_t)b * p.max_len + p.t] = -logf(tot);
+    p.tok[(size_t)b * (p.max_len + 1) + p.t + 1] = w;
+    p.mask[(size_t)b * (p.max_len + 1) + p.t + 1] = (w == p.pad_idx) ? 1 : 0;
+    if (unf) atomicAdd(&p.cnt[p.t], 1);
+  }
+}
+
+__global__ void greedy_init_kernel(int64_t* seq, float* logprob, int* tok, unsigned char* mask, int* unfinished,
+                                   int* cnt, int B, int max_len, int start_idx, int end_idx, int pad_idx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B * max_len) { seq[i] = end_idx; logprob[i] = 0.f; }
+  if (i < B * (max_len + 1)) {
+    const int c = i % (max_len + 1);
+    tok[i] = c == 0 ? start_idx : end_idx;
+    mask[i] = c == 0 ? (start_idx == pad_idx) : 0;
+  }
+  if (i < B) unfinished[i] = 1;
+  if (i < max_len) cnt[i] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// beam search, device half (base.py:282-289)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_max256(float v, float* sh) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+__device__ __forceinline__ float block_sum256(float v, float* sh) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// lp[r][:] = log_softmax(log_softmax(logit[r]) / temp) + cum[r]
+__global__ __launch_bounds__(256) void beam_logprob_kernel(const float* logit, const float* cum, float temp,
+                                                           float* lp, int V) {
+  __shared__ float sh[4];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const float* row = logit + (size_t)r * V;
+  float m = -INFINITY;
+  for (int c = tid; c < V; c += 256) m = fmaxf(m, row[c]);
+  m = block_max256(m, sh);
+  float s = 0.f;
+  for (int c = tid; c < V; c += 256) s += expf(row[c] - m);
+  s = block_sum256(s, sh);
+  const float lse1 = m + logf(s);
+  const float inv_t = 1.0f / temp;
+  float m2 = -INFINITY;
+  for (int c = tid; c < V; c += 256) m2 = fmaxf(m2, (row[c] - lse1) * inv_t);
+  m2 = block_max256(m2, sh);
+  float s2 = 0.f;
+  for (int c = tid; c < V; c += 256) s2 += expf((row[c] - lse1) * inv_t - m2);
+  s2 = block_sum256(s2, sh);
+  const float lse2 = m2 + logf(s2);
+  const float cr = cum[r];
+  for (int c = tid; c < V; c += 256) lp[(size_t)r * V + c] = cr + ((row[c] - lse1) * inv_t - lse2);
+}
+
+// per clip: the `beam` largest entries of lp[clip*beam .. +nrows][V] flattened (lowest index wins ties)
+__global__ __launch_bounds__(256) void beam_topk_kernel(const float* lp, int beam, int nrows, int V,
+                                                        float* top_val, int* top_idx) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  __shared__ int chosen[64];
+  const int clip = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* base = lp + (size_t)clip * beam * V;
+  const int n = nrows * V;
+  for (int k = 0; k < beam; ++k) {
+    float v = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int c = tid; c < n; c += 256) {
+      bool skip = false;
+      for (int j = 0; j < k; ++j) skip |= (chosen[j] == c);
+      if (!skip) argmax_merge(v, idx, base[c], c);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(v, o, 64);
+      const int oi = __shfl_xor(idx, o, 64);
+      argmax_merge(v, idx, ov, oi);
+    }
+    __syncthreads();
+    if (lane == 0) { sv[wave] = v; si[wave] = idx; }
+    __syncthreads();
+    if (tid == 0) {
+      v = sv[0]; idx = si[0];
+      for (int w = 1; w < 4; ++w) argmax_merge(v, idx, sv[w], si[w]);
+      chosen[k] = idx;
+      top_val[clip * beam + k] = v;
+      top_idx[clip * beam + k] = idx;
+    }
+    __syncthreads();
+  }
+}
+
+// dst[l][r][0..t][:] = src[l][src_row[r]][0..t][:] for both K and V caches
+__global__ void cache_gather_kernel(const float* src, float* dst, const int* src_row, int R, int max_len, int t,
+                                    int d, size_t set_stride /* floats between K and V sets and layers */, int nsets) {
+  const int r = blockIdx.x, set = blockIdx.y;
+  const int sr = src_row[r];
+  const size_t n = (size_t)(t + 1) * d;
+  const float* s = src + set * set_stride + (size_t)sr * max_len * d;
+  float* o = dst + set * set_stride + (size_t)r * max_len * d;
+  for (size_t i = threadIdx.x; i < n; i += blockDim.x) o[i] = s[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// workspace carving
+// ---------------------------------------------------------------------------------------------
+struct Ws {
+  float *x, *qkv, *att, *tmp, *ff, *q2, *lg;
+  float* cache[2];  // [2 (K,V)][nlayers][R][max_len][d] each
+  int *tok, *unfinished;
+  unsigned char* mask;
+  size_t cache_set_stride;  // R*max_len*d
+  size_t total;
+};
+
+inline size_t align4(size_t n) { return (n + 3) & ~(size_t)3; }
+
+Ws carve(const ac_trm_weights* w, int R, int max_len, float* base) {
+  Ws s;
+  const size_t d = w->d_model;
+  size_t off = 0;
+  auto take = [&](size_t n) { float* p = base ? base + off : nullptr; off += align4(n); return p; };
+  s.x = take(R * d);
+  s.qkv = take(R * 3 * d);
+  s.att = take(R * d);
+  s.tmp = take(R * d);
+  s.ff = take((size_t)R * w->dim_ff);
+  s.q2 = take(R * d);
+  s.lg = take((size_t)R * w->vocab);
+  s.cache_set_stride = (size_t)R * max_len * d;
+  for (int i = 0; i < 2; ++i) s.cache[i] = take(2 * (size_t)w->nlayers * s.cache_set_stride);
+  s.tok = (int*)take((size_t)R * (max_len + 1));
+  s.unfinished = (int*)take(R);
+  s.mask = (unsigned char*)take(((size_t)R * (max_len + 1) + 3) / 4);
+  s.total = off;
+  return s;
+}
+
+#define AC_TRY(expr)            \
+  do {                          \
+    int _e = (expr);            \
+    if (_e != AC_OK) return _e; \
+  } while (0)
+
+int check_weights(const ac_trm_weights* w) {
+  if (!w || w->nlayers < 1 || w->nlayers > AC_MAX_LAYERS) return AC_ERR_ARG;
+  if (w->d_model % 32 || w->d_model > 1024 || w->dim_ff % 32 || w->attn_emb_dim % 32) return AC_ERR_ARG;
+  if (w->nhead < 1 || w->d_model % w->nhead || w->d_model / w->nhead > 64) return AC_ERR_ARG;
+  return AC_OK;
+}
+
+int launch_ln(const float* x, const float* y, const float* w, const float* b, float* out, int rows, int d,
+              long ldx, long ldy, long ldo, hipStream_t s) {
+  hipLaunchKernelGGL(add_layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, y, w, b, out, rows, d, ldx,
+                     ldy, ldo);
+  return ac_check_launch();
+}
+
+// One decoder position for R rows.  tokens/mask: [R][tok_stride]; the input token is column t.
+// cache: active KV cache set.  The last layer's output goes to xout (row stride ldxo).
+int decoder_step(const ac_trm_weights* w, const float* memkv, const int* mem_len, int R, int row_div, int Tm,
+                 int max_len, int t, const int* tok, const unsigned char* mask, long tok_stride, float* cache,
+                 const Ws& ws, float* xout, long ldxo, hipStream_t s) {
+  const int d = w->d_model, hd = d / w->nhead;
+  const float scale = 1.0f / sqrtf((float)hd);
+  void* st = (void*)s;
+  if (t >= w->max_pos) return AC_ERR_ARG;
+  hipLaunchKernelGGL(embed_pe_kernel, dim3(R), dim3(256), 0, s, tok, tok_stride, t, w->emb, w->pe,
+                     sqrtf((float)d), ws.x, d);
+  AC_TRY(ac_check_launch());
+  const size_t Rm = (size_t)(R / row_div) * Tm;  // memory rows
+  for (int l = 0; l < w->nlayers; ++l) {
+    const ac_trm_layer& L = w->layer[l];
+    const bool last = l == w->nlayers - 1;
+    // ---- self attention over the cached prefix ----
+    AC_TRY(ac_linear(ws.x, L.sa_in_w, L.sa_in_b, ws.qkv, R, 3 * d, d, d, d, 3 * d, 0, st));
+    AttnParams a;
+    float* Kc = cache + (size_t)(2 * l) * ws.cache_set_stride;
+    float* Vc = cache + (size_t)(2 * l + 1) * ws.cache_set_stride;
+    a.q = ws.qkv; a.ldq = 3 * d;
+    a.K = Kc; a.V = Vc; a.Kw = Kc; a.Vw = Vc;
+    a.row_stride = (long)max_len * d; a.key_stride = d; a.row_div = 1; a.nkeys = t + 1;
+    a.key_len = nullptr; a.key_mask = mask; a.mask_stride = tok_stride;
+    a.new_k = ws.qkv + d; a.new_v = ws.qkv + 2 * d; a.ld_new = 3 * d;
+    a.out = ws.att; a.ldo = d; a.hd = hd; a.scale = scale;
+    hipLaunchKernelGGL(attn_step_kernel, dim3(R, w->nhead), dim3(64), 0, s, a);
+    AC_TRY(ac_check_launch());
+    AC_TRY(ac_linear(ws.att, L.sa_out_w, L.sa_out_b, ws.tmp, R, d, d, d, d, d, 0, st));
+    AC_TRY(launch_ln(ws.x, ws.tmp, L.n1_w, L.n1_b, ws.x, R, d, d, d, d, s));
+    // ---- cross attention over the audio memory ----
+    AC_TRY(ac_linear(ws.x, L.ca_in_w, L.ca_in_b, ws.q2, R, d, d, d, d, d, 0, st));
+    const float* mk = memkv + (size_t)l * Rm * 2 * d;
+    a.q = ws.q2; a.ldq = d;
+    a.K = mk; a.V = mk + d; a.Kw = nullptr; a.Vw = nullptr;
+    a.row_stride = (long)Tm * 2 * d; a.key_stride = 2 * d; a.row_div = row_div; a.nkeys = Tm;
+    a.key_len = mem_len; a.key_mask = nullptr; a.mask_stride = 0;
+    a.new_k = nullptr; a.new_v = nullptr; a.ld_new = 0;
+    hipLaunchKernelGGL(attn_step_kernel, dim3(R, w->nhead), dim3(64), 0, s, a);
+    AC_TRY(ac_check_launch());
+    AC_TRY(ac_linear(ws.att, L.ca_out_w, L.ca_out_b, ws.tmp, R, d, d, d, d, d, 0, st));
+    AC_TRY(launch_ln(ws.x, ws.tmp, L.n2_w, L.n2_b, ws.x, R, d, d, d, d, s));
+    // ---- feed forward ----
+    AC_TRY(ac_linear(ws.x, L.l1_w, L.l1_b, ws.ff, R, w->dim_ff, d, d, d, w->dim_ff, 1, st));
+    AC_TRY(ac_linear(ws.ff, L.l2_w, L.l2_b, ws.tmp, R, d, w->dim_ff, w->dim_ff, w->dim_ff, d, 0, st));
+    if (last)
+      AC_TRY(launch_ln(ws.x, ws.tmp, L.n3_w, L.n3_b, xout, R, d, d, d, ldxo, s));
+    else
+      AC_TRY(launch_ln(ws.x, ws.tmp, L.n3_w, L.n3_b, ws.x, R, d, d, d, d, s));
+  }
+  return AC_OK;
+}
+
+}  // namespace
+
+extern "C" int ac_abi_version(void) { return AC_ABI_VERSION; }
+
+extern "C" int ac_add_layernorm(const float* x, const float* y, const float* w, const float* b, float* out,
+                                int rows, int d, long ldx, long ldy, long ldo, void* stream) {
+  if (!x || !w || !b || !out || rows <= 0 || d <= 0 || d > 1024) return AC_ERR_ARG;
+  return launch_ln(x, y, w, b, out, rows, d, ldx, ldy, ldo, (hipStream_t)stream);
+}
+
+extern "C" int ac_trm_memory(const ac_trm_weights* w, const float* attn_emb, int R, int Tm, float* memkv,
+                             float* tmp, void* stream) {
+  AC_TRY(check_weights(w));
+  if (!attn_emb || !memkv || !tmp || R <= 0 || Tm <= 0 || Tm > MAX_KEYS) return AC_ERR_ARG;
+  const int d = w->d_model, rows = R * Tm;
+  hipStream_t s = (hipStream_t)stream;
+  // attn_proj: Linear -> ReLU -> (Dropout: identity in eval) -> LayerNorm
+  AC_TRY(ac_linear(attn_emb, w->proj_w, w->proj_b, tmp, rows, d, w->attn_emb_dim, w->attn_emb_dim,
+                   w->attn_emb_dim, d, 1, stream));
+  AC_TRY(launch_ln(tmp, nullptr, w->proj_ln_w, w->proj_ln_b, tmp, rows, d, d, 0, d, s));
+  // cross-attention K and V of every layer: rows d..3d-1 of multihead_attn.in_proj
+  for (int l = 0; l < w->nlayers; ++l) {
+    const ac_trm_layer& L = w->layer[l];
+    AC_TRY(ac_linear(tmp, L.ca_in_w + (size_t)d * d, L.ca_in_b + d, memkv + (size_t)l * rows * 2 * d, rows,
+                     2 * d, d, d, d, 2 * d, 0, stream));
+  }
+  return AC_OK;
+}
+
+extern "C" long ac_trm_workspace_floats(const ac_trm_weights* w, int rows, int max_len) {
+  if (check_weights(w) != AC_OK || rows <= 0 || max_len <= 0) return -1;
+  return (long)carve(w, rows, max_len, nullptr).total;
+}
+
+extern "C" int ac_trm_greedy(const ac_trm_weights* w, const float* memkv, const int* mem_len, int B, int Tm,
+                             int max_len, int start_idx, int end_idx, int pad_idx, int64_t* seq, float* logit,
+                             float* logprob, float* embed, int* unfinished_cnt, float* ws_base, void* stream) {
+  AC_TRY(check_weights(w));
+  if (!memkv || !mem_len || !seq || !logit || !logprob || !embed || !unfinished_cnt || !ws_base) return AC_ERR_ARG;
+  if (B <= 0 || Tm <= 0 || Tm > MAX_KEYS || max_len <= 0 || max_len > w->max_pos) return AC_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const Ws ws = carve(w, B, max_len, ws_base);
+  const int d = w->d_model, V = w->vocab;
+  const int n_init = B * (max_len + 1);
+  hipLaunchKernelGGL(greedy_init_kernel, dim3((n_init + 255) / 256), dim3(256), 0, s, seq, logprob, ws.tok,
+                     ws.mask, ws.unfinished, unfinished_cnt, B, max_len, start_idx, end_idx, pad_idx);
+  AC_TRY(ac_check_launch());
+  for (int t = 0; t < max_len; ++t) {
+    float* xout = embed + (size_t)t * d;
+    AC_TRY(decoder_step(w, memkv, mem_len, B, 1, Tm, max_len, t, ws.tok, ws.mask, max_len + 1, ws.cache[0], ws,
+                        xout, (long)max_len * d, s));
+    AC_TRY(ac_linear(xout, w->cls_w, nullptr, logit + (size_t)t * V, B, V, d, (long)max_len * d, d,
+                     (long)max_len * V, 0, stream));
+    PickParams p;
+    p.logit = logit + (size_t)t * V; p.ldl = (long)max_len * V;
+    p.V = V; p.t = t; p.max_len = max_len; p.end_idx = end_idx; p.pad_idx = pad_idx;
+    p.seq = seq; p.logprob = logprob; p.tok = ws.tok; p.mask = ws.mask; p.unfinished = ws.unfinished;
+    p.cnt = unfinished_cnt;
+    hipLaunchKernelGGL(greedy_pick_kernel, dim3(B), dim3(256), 0, s, p);
+    AC_TRY(ac_check_launch());
+  }
+  return AC_OK;
+}
+
+extern "C" int ac_trm_forward_tokens(const ac_trm_weights* w, const float* memkv, const int* mem_len, int N,
+                                     int Tm, const int* tokens, const unsigned char* key_mask, int T,
+                                     float* embed, float* logit, float* ws_base, void* stream) {
+  AC_TRY(check_weights(w));
+  if (!memkv || !mem_len || !tokens || !embed || !logit || !ws_base) return AC_ERR_ARG;
+  if (N <= 0 || Tm <= 0 || Tm > MAX_KEYS || T <= 0 || T > w->max_pos) return AC_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const Ws ws = carve(w, N, T, ws_base);
+  const int d = w->d_model, V = w->vocab;
+  for (int t = 0; t < T; ++t)
+    AC_TRY(decoder_step(w, memkv, mem_len, N, 1, Tm, T, t, tokens, key_mask, T, ws.cache[0], ws,
+                        embed + (size_t)t * d, (long)T * d, s));
+  return ac_linear(embed, w->cls_w, nullptr, logit, N * T, V, d, d, d, V, 0, stream);
+}
+
+extern "C" int ac_trm_beam_step(const ac_trm_weights* w, const float* memkv, const int* mem_len, int B, int beam,
+                                int Tm, int max_len, int t, float temp, const int* tokens,
+                                const unsigned char* key_mask, const float* cum_logprob, float* top_val,
+                                int* top_idx, float* ws_base, void* stream) {
+  AC_TRY(check_weights(w));
+  if (!memkv || !mem_len || !tokens || !cum_logprob || !top_val || !top_idx || !ws_base) return AC_ERR_ARG;
+  if (B <= 0 || beam <= 0 || beam > 64 || Tm <= 0 || Tm > MAX_KEYS || t < 0 || t >= max_len) return AC_ERR_ARG;
+  if (max_len > w->max_pos || !(temp > 0.f)) return AC_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int R = B * beam, d = w->d_model, V = w->vocab;
+  const Ws ws = carve(w, R, max_len, ws_base);
+  AC_TRY(decoder_step(w, memkv, mem_len, R, beam, Tm, max_len, t, tokens, key_mask, max_len + 1,
+                      ws.cache[t & 1], ws, ws.x, d, s));
+  AC_TRY(ac_linear(ws.x, w->cls_w, nullptr, ws.lg, R, V, d, d, d, V, 0, stream));
+  // lp is written over the qkv/ff scratch?  No: it needs R*V floats, reuse a second logits-sized area.
+  float* lp = ws.lg;  // in place: every element is read before it is written by the same thread
+  hipLaunchKernelGGL(beam_logprob_kernel, dim3(R), dim3(256), 0, s, ws.lg, cum_logprob, temp, lp, V);
+  AC_TRY(ac_check_launch());
+  hipLaunchKernelGGL(beam_topk_kernel, dim3(B), dim3(256), 0, s, lp, beam, t == 0 ? 1 : beam, V, top_val,
+                     top_idx);
+  return ac_check_launch();
+}
+
+extern "C" int ac_trm_beam_reorder(const ac_trm_weights* w, int R, int max_len, int t, const int* src_row,
+                                   float* ws_base, void* stream) {
+  AC_TRY(check_weights(w));
+  if (!src_row || !ws_base || R <= 0 || t < 0 || t >= max_len) return AC_ERR_ARG;
+  const Ws ws = carve(w, R, max_len, ws_base);
+  hipLaunchKernelGGL(cache_gather_kernel, dim3(R, 2 * w->nlayers), dim3(256), 0, (hipStream_t)stream,
+                     ws.cache[t & 1], ws.cache[(t + 1) & 1], src_row, R, max_len, t, w->d_model,
+                     ws.cache_set_stride, 2 * w->nlayers);
+  return ac_check_launch();
+}

@@ -1,0 +1,115 @@
+// Length-aware bidirectional GRU layer + masked mean pooling on gfx950.
+//
+// Replaces, per layer, what the reference gets from pack_padded_sequence -> nn.GRU ->
+// pad_packed_sequence (rnn_encoder.py:34-49, model_util.py:10-27): the input projections of all time
+// steps are one MFMA GEMM (ac_linear, N = 2 directions x 3 gates x H); this file is the recurrence.
+//
+// Clips never interact inside the recurrence, so each (clip, direction) pair is ONE persistent
+// workgroup that walks its own valid steps (forward: 0..len-1, reverse: len-1..0 - i.e. the reverse
+// direction starts at the clip's own last valid frame, exactly what packing does) with the hidden
+// state in LDS; no inter-workgroup synchronisation exists anywhere.  The 768x256 recurrent matrix is
+// streamed from L2 every step in a k-major transposed copy so that the 768 threads read it fully
+// coalesced.  Steps t >= len are written as zeros (pad_packed_sequence semantics).
+#include "ac_common.h"
+
+namespace {
+
+struct GruParams {
+  const float* gx;     // [B][T][2][3H]  x W_ih^T + b_ih, gate order r, z, n
+  const float* whhT;   // [2][H][3H]     W_hh transposed (k-major)
+  const float* bhh;    // [2][3H]
+  const int* lens;     // [B]
+  float* out;          // [B][T][2H]
+  int B, T;
+};
+
+constexpr int H = 256;
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(768) void gru_layer_kernel(GruParams p) {
+  __shared__ __attribute__((aligned(16))) float sh[H];
+  __shared__ float sg[3 * H];
+  const int n = threadIdx.x;
+  const int b = blockIdx.x >> 1, dir = blockIdx.x & 1;
+  int len = p.lens[b];
+  len = len < 0 ? 0 : (len > p.T ? p.T : len);
+  const float* W = p.whhT + (size_t)dir * H * 3 * H + n;
+  const float bias = p.bhh[dir * 3 * H + n];
+  if (n < H) sh[n] = 0.f;
+  __syncthreads();
+  for (int step = 0; step < len; ++step) {
+    const int t = dir ? (len - 1 - step) : step;
+    float acc = bias;
+#pragma unroll 8
+    for (int k = 0; k < H; k += 4) {
+      const float4 hv = *(const float4*)(sh + k);
+      acc = fmaf(W[(size_t)(k + 0) * 3 * H], hv.x, acc);
+      acc = fmaf(W[(size_t)(k + 1) * 3 * H], hv.y, acc);
+      acc = fmaf(W[(size_t)(k + 2) * 3 * H], hv.z, acc);
+      acc = fmaf(W[(size_t)(k + 3) * 3 * H], hv.w, acc);
+    }
+    sg[n] = acc;
+    __syncthreads();
+    if (n < H) {
+      const float* gxp = p.gx + (((size_t)b * p.T + t) * 2 + dir) * 3 * H;
+      const float r = sigmoidf_(gxp[n] + sg[n]);
+      const float z = sigmoidf_(gxp[H + n] + sg[H + n]);
+      const float c = tanhf(gxp[2 * H + n] + r * sg[2 * H + n]);
+      const float hn = (1.0f - z) * c + z * sh[n];
+      sh[n] = hn;
+      p.out[((size_t)b * p.T + t) * 2 * H + dir * H + n] = hn;
+    }
+    __syncthreads();
+  }
+  if (n < H)
+    for (int t = len; t < p.T; ++t) p.out[((size_t)b * p.T + t) * 2 * H + dir * H + n] = 0.f;
+}
+
+// fc_emb[b][c] = sum_{t < len[b]} x[b][t][c] / len[b]   (model_util.py:41-63 mean_with_lens)
+__global__ void mean_lens_kernel(const float* x, const int* lens, float* out, int T, int C) {
+  const int b = blockIdx.x;
+  const int len = lens[b];
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int t = 0; t < len && t < T; ++t) s += x[((size_t)b * T + t) * C + c];
+    out[(size_t)b * C + c] = s / (float)len;
+  }
+}
+
+// max over valid steps (model_util.py:65-81 max_with_lens) + mean, Cnn14's own fc_emb input
+__global__ void maxmean_lens_kernel(const float* x, const int* lens, float* out, int T, int C) {
+  const int b = blockIdx.x;
+  const int len = lens[b];
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f, m = -INFINITY;
+    for (int t = 0; t < len && t < T; ++t) {
+      const float v = x[((size_t)b * T + t) * C + c];
+      s += v;
+      m = fmaxf(m, v);
+    }
+    out[(size_t)b * C + c] = m + s / (float)len;
+  }
+}
+
+}  // namespace
+
+// C ABI: see include/audiocaption_hip.h
+extern "C" int ac_gru_layer(const float* gx, const float* whhT, const float* bhh, const int* lens, float* out,
+                            int B, int T, int hidden, void* stream) {
+  if (!gx || !whhT || !bhh || !lens || !out || B <= 0 || T <= 0 || hidden != H) return AC_ERR_ARG;
+  GruParams p;
+  p.gx = gx; p.whhT = whhT; p.bhh = bhh; p.lens = lens; p.out = out; p.B = B; p.T = T;
+  hipLaunchKernelGGL(gru_layer_kernel, dim3(2 * B), dim3(768), 0, (hipStream_t)stream, p);
+  return ac_check_launch();
+}
+
+extern "C" int ac_mean_with_lens(const float* x, const int* lens, float* out, int B, int T, int C, int add_max,
+                                 void* stream) {
+  if (!x || !lens || !out || B <= 0 || T <= 0 || C <= 0) return AC_ERR_ARG;
+  if (add_max)
+    hipLaunchKernelGGL(maxmean_lens_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, lens, out, T, C);
+  else
+    hipLaunchKernelGGL(mean_lens_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, lens, out, T, C);
+  return ac_check_launch();
+}

@@ -1,0 +1,101 @@
+"""Thin Python entry points over the C ABI (include/audiocaption_hip.h).
+
+Each function takes/returns torch tensors that live on the ROCm device, passes raw pointers and the
+current stream to libaudiocaption_hip.so and raises on any failure.  No function here computes
+anything on the host and none has a fallback.
+"""
+import torch
+
+from . import _lib
+from ._lib import check, f32c, ptr, stream
+
+
+def _dev(t):
+    if not t.is_cuda:
+        raise _lib.HipLibraryError("the HIP path needs tensors on a ROCm device; there is no CPU fallback")
+    return t
+
+
+def logmel(wav, tables, scale=None, shift=None, rows_per_clip=None, channels_last=True):
+    """wav (B, L) -> log-mel.  channels_last: (B*rows_per_clip, 64) rows layout for the conv stack
+    (frames >= T zero); else (B, 64, T) like the reference's MelSpectrogram+AmplitudeToDB output."""
+    lib = _lib.load()
+    wav = f32c(_dev(wav))
+    B, L = wav.shape
+    T = L // tables.hop + 1
+    if channels_last:
+        Hp = rows_per_clip if rows_per_clip is not None else T
+        out = torch.empty(B * Hp, 64, device=wav.device, dtype=torch.float32)
+        sb, st, sm = Hp * 64, 64, 1
+    else:
+        Hp = T
+        out = torch.empty(B, 64, T, device=wav.device, dtype=torch.float32)
+        sb, st, sm = 64 * T, 1, T
+    check(lib.ac_logmel(ptr(wav), B, L, tables.n_fft, tables.hop, ptr(tables.window), ptr(tables.twiddle),
+                        ptr(tables.melfb), ptr(tables.mel_lo), ptr(tables.mel_hi), ptr(scale), ptr(shift),
+                        ptr(out), Hp, sb, st, sm, stream()), "ac_logmel")
+    return out
+
+
+def conv3x3_first(x, w, scale, shift, out, B, Hp, H, W=64):
+    lib = _lib.load()
+    check(lib.ac_conv3x3_first(ptr(x), ptr(w), ptr(scale), ptr(shift), ptr(out), B, Hp, H, W, stream()),
+          "ac_conv3x3_first")
+    return out
+
+
+def conv3x3_bn_relu(x, wpk, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode=-1):
+    lib = _lib.load()
+    check(lib.ac_conv3x3_bn_relu(ptr(x), ptr(wpk), ptr(scale), ptr(shift), ptr(out), B, Hp, H, W, Cin, Cout,
+                                 mode, map_mode, stream()), "ac_conv3x3_bn_relu")
+    return out
+
+
+def pack_conv_weight(w):
+    """OIHW (Cout, Cin, 3, 3) -> [Cin/32][9][Cout][32] (see csrc/conv3x3.hip)."""
+    cout, cin = w.shape[0], w.shape[1]
+    return (w.permute(1, 2, 3, 0).reshape(cin // 32, 32, 9, cout).permute(0, 2, 3, 1).contiguous())
+
+
+def fold_bn(bn_weight, bn_bias, mean, var, eps):
+    scale = bn_weight / torch.sqrt(var + eps)
+    return scale.contiguous(), (bn_bias - mean * scale).contiguous()
+
+
+def linear(x, w, b=None, relu=False, out=None):
+    """y = act(x @ w.T + b); x (M, K) row-major (stride(0) may exceed K), w (N, K)."""
+    lib = _lib.load()
+    M, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    check(lib.ac_linear(ptr(x), ptr(w), ptr(b), ptr(out), M, N, K, x.stride(0), w.stride(0), out.stride(0),
+                        1 if relu else 0, stream()), "ac_linear")
+    return out
+
+
+def gru_layer(gx, whhT, bhh, lens_i32, B, T, hidden):
+    lib = _lib.load()
+    out = torch.empty(B, T, 2 * hidden, device=gx.device, dtype=torch.float32)
+    check(lib.ac_gru_layer(ptr(gx), ptr(whhT), ptr(bhh), ptr(lens_i32), ptr(out), B, T, hidden, stream()),
+          "ac_gru_layer")
+    return out
+
+
+def mean_with_lens(x, lens_i32, add_max=False):
+    lib = _lib.load()
+    B, T, C = x.shape
+    out = torch.empty(B, C, device=x.device, dtype=torch.float32)
+    check(lib.ac_mean_with_lens(ptr(x), ptr(lens_i32), ptr(out), B, T, C, 1 if add_max else 0, stream()),
+          "ac_mean_with_lens")
+    return out
+
+
+def add_layernorm(x, y, w, b, out=None):
+    lib = _lib.load()
+    rows, d = x.shape
+    if out is None:
+        out = torch.empty(rows, d, device=x.device, dtype=torch.float32)
+    check(lib.ac_add_layernorm(ptr(x), ptr(y), ptr(w), ptr(b), ptr(out), rows, d, x.stride(0),
+                               y.stride(0) if y is not None else 0, out.stride(0), stream()), "ac_add_layernorm")
+    return out

@@ -1,0 +1,203 @@
+"""Transformer caption decoder, MI355X path.  Plugin-compatible with the reference class
+``captioning.models.transformer_decoder.TransformerDecoder`` (transformer_decoder.py:11-103) and its
+base ``captioning.models.BaseDecoder`` (models/__init__.py:64-92): same constructor, attributes
+(``vocab_size``, ``d_model``, ``emb_dim``, ``fc_emb_dim``, ``attn_emb_dim``), ``state_dict()`` keys and
+``forward({"word", "attn_emb", "attn_emb_len", "cap_padding_mask"}) -> {"embed", "logit"}``.
+
+The nn modules own the parameters only.  All arithmetic runs in csrc/decoder.hip + csrc/gemm.hip:
+``memory()`` projects the audio features once, ``forward`` / ``greedy`` / ``beam_*`` run the per-position
+decoder step against a self-attention KV cache.
+"""
+import ctypes
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import check, f32c, ptr, stream
+
+
+class PositionalEncoding(nn.Module):
+    """Sinusoid table kept as a frozen Parameter named ``pe`` so that it appears in checkpoints exactly
+    like the reference's (model_util.py:167-186)."""
+
+    def __init__(self, d_model, dropout=0.1, max_len=100):
+        super().__init__()
+        self.dropout = nn.Dropout(p=dropout)
+        pe = torch.zeros(max_len, d_model)
+        position = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+        pe[:, 0::2] = torch.sin(position * div_term)
+        pe[:, 1::2] = torch.cos(position * div_term)
+        self.register_parameter("pe", nn.Parameter(pe.unsqueeze(1), requires_grad=False))
+
+
+class BaseDecoder(nn.Module):
+
+    def __init__(self, emb_dim, vocab_size, fc_emb_dim, attn_emb_dim, dropout=0.2, tie_weights=False):
+        super().__init__()
+        self.emb_dim = emb_dim
+        self.vocab_size = vocab_size
+        self.fc_emb_dim = fc_emb_dim
+        self.attn_emb_dim = attn_emb_dim
+        self.tie_weights = tie_weights
+        self.word_embedding = nn.Embedding(vocab_size, emb_dim)
+        self.in_dropout = nn.Dropout(dropout)
+
+
+class TransformerDecoder(BaseDecoder):
+
+    def __init__(self, emb_dim, vocab_size, fc_emb_dim, attn_emb_dim, dropout, freeze=False,
+                 tie_weights=False, **kwargs):
+        super().__init__(emb_dim, vocab_size, fc_emb_dim, attn_emb_dim, dropout=dropout, tie_weights=tie_weights)
+        self.d_model = emb_dim
+        self.nhead = kwargs.get("nhead", self.d_model // 64)
+        self.nlayers = kwargs.get("nlayers", 2)
+        self.dim_feedforward = kwargs.get("dim_feedforward", self.d_model * 4)
+        self.pos_encoder = PositionalEncoding(self.d_model, dropout)
+        layer = nn.TransformerDecoderLayer(d_model=self.d_model, nhead=self.nhead,
+                                           dim_feedforward=self.dim_feedforward, dropout=dropout)
+        self.model = nn.TransformerDecoder(layer, self.nlayers)
+        self.classifier = nn.Linear(self.d_model, vocab_size, bias=False)
+        if tie_weights:
+            self.classifier.weight = self.word_embedding.weight
+        self.attn_proj = nn.Sequential(nn.Linear(self.attn_emb_dim, self.d_model), nn.ReLU(),
+                                       nn.Dropout(dropout), nn.LayerNorm(self.d_model))
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        self.freeze = freeze
+        if freeze:
+            for p in self.parameters():
+                p.requires_grad = False
+        self._w = None
+        self._w_key = None
+        self._w_keep = None
+        self._ws = {}
+
+    def load_pretrained(self, pretrained, output_fn=print):
+        """Reference transformer_decoder.py:56-72: take the ``decoder.*`` entries of a model checkpoint."""
+        checkpoint = torch.load(pretrained, map_location="cpu")
+        if "model" in checkpoint:
+            checkpoint = checkpoint["model"]
+        sd = {k[8:]: v for k, v in checkpoint.items() if k.startswith("decoder.")} or checkpoint
+        own = self.state_dict()
+        loaded = {k: v for k, v in sd.items() if k in own and own[k].shape == v.shape}
+        own.update(loaded)
+        self.load_state_dict(own, strict=True)
+        if self.freeze:
+            for name, param in self.named_parameters():
+                param.requires_grad = name not in loaded
+
+    # ------------------------------------------------------------------------------------------
+    def weights(self):
+        """ac_trm_weights struct of device pointers (rebuilt when a parameter changes)."""
+        params = list(self.parameters())
+        key = tuple((t.data_ptr(), t._version, t.dtype) for t in params)
+        if self._w is not None and key == self._w_key:
+            return self._w
+        keep = []
+
+        def P(t):
+            t = f32c(t.detach())
+            keep.append(t)
+            return ctypes.c_void_p(ptr(t).value)
+
+        if self.nlayers > _lib.AC_MAX_LAYERS:
+            raise ValueError("too many decoder layers for the HIP path")
+        w = _lib.AcTrmWeights()
+        w.d_model, w.nhead, w.nlayers, w.dim_ff = self.d_model, self.nhead, self.nlayers, self.dim_feedforward
+        w.vocab, w.max_pos, w.attn_emb_dim = self.vocab_size, self.pos_encoder.pe.shape[0], self.attn_emb_dim
+        w.emb, w.pe, w.cls_w = P(self.word_embedding.weight), P(self.pos_encoder.pe), P(self.classifier.weight)
+        w.proj_w, w.proj_b = P(self.attn_proj[0].weight), P(self.attn_proj[0].bias)
+        w.proj_ln_w, w.proj_ln_b = P(self.attn_proj[3].weight), P(self.attn_proj[3].bias)
+        for i, L in enumerate(self.model.layers):
+            wl = w.layer[i]
+            wl.sa_in_w, wl.sa_in_b = P(L.self_attn.in_proj_weight), P(L.self_attn.in_proj_bias)
+            wl.sa_out_w, wl.sa_out_b = P(L.self_attn.out_proj.weight), P(L.self_attn.out_proj.bias)
+            wl.ca_in_w, wl.ca_in_b = P(L.multihead_attn.in_proj_weight), P(L.multihead_attn.in_proj_bias)
+            wl.ca_out_w, wl.ca_out_b = P(L.multihead_attn.out_proj.weight), P(L.multihead_attn.out_proj.bias)
+            wl.l1_w, wl.l1_b, wl.l2_w, wl.l2_b = P(L.linear1.weight), P(L.linear1.bias), P(L.linear2.weight), P(L.linear2.bias)
+            wl.n1_w, wl.n1_b = P(L.norm1.weight), P(L.norm1.bias)
+            wl.n2_w, wl.n2_b = P(L.norm2.weight), P(L.norm2.bias)
+            wl.n3_w, wl.n3_b = P(L.norm3.weight), P(L.norm3.bias)
+        self._w, self._w_key, self._w_keep = w, key, keep
+        return w
+
+    def workspace(self, rows, max_len, device):
+        lib = _lib.load()
+        n = lib.ac_trm_workspace_floats(ctypes.byref(self.weights()), rows, max_len)
+        if n <= 0:
+            raise _lib.HipLibraryError("ac_trm_workspace_floats rejected the decoder configuration")
+        ws = self._ws.get(device)
+        if ws is None or ws.numel() < n:
+            ws = torch.empty(n, device=device, dtype=torch.float32)
+            self._ws[device] = ws
+        return ws
+
+    def memory(self, attn_emb):
+        """attn_emb (R, Tm, attn_emb_dim) -> memkv (nlayers, R*Tm, 2*d): attn_proj + cross-attn K/V."""
+        lib = _lib.load()
+        attn_emb = f32c(attn_emb)
+        R, Tm, _ = attn_emb.shape
+        memkv = torch.empty(self.nlayers, R * Tm, 2 * self.d_model, device=attn_emb.device, dtype=torch.float32)
+        tmp = torch.empty(R * Tm, self.d_model, device=attn_emb.device, dtype=torch.float32)
+        check(lib.ac_trm_memory(ctypes.byref(self.weights()), ptr(attn_emb), R, Tm, ptr(memkv), ptr(tmp), stream()),
+              "ac_trm_memory")
+        return memkv
+
+    def forward(self, input_dict):
+        if self.training:
+            raise NotImplementedError("TransformerDecoder (HIP path): the training forward/backward is not built yet")
+        lib = _lib.load()
+        attn_emb = input_dict["attn_emb"]
+        dev = attn_emb.device
+        word = input_dict["word"].to(dev)
+        N, T = word.shape
+        Tm = attn_emb.shape[1]
+        mem_len = torch.as_tensor(input_dict["attn_emb_len"]).to(device=dev, dtype=torch.int32)
+        mask = input_dict.get("cap_padding_mask")
+        mask_u8 = None if mask is None else mask.to(dev).to(torch.uint8).contiguous()
+        memkv = self.memory(attn_emb)
+        tokens = word.to(torch.int32).contiguous()
+        embed = torch.empty(N, T, self.d_model, device=dev, dtype=torch.float32)
+        logit = torch.empty(N, T, self.vocab_size, device=dev, dtype=torch.float32)
+        ws = self.workspace(N, T, dev)
+        check(lib.ac_trm_forward_tokens(ctypes.byref(self.weights()), ptr(memkv), ptr(mem_len), N, Tm, ptr(tokens),
+                                        ptr(mask_u8), T, ptr(embed), ptr(logit), ptr(ws), stream()),
+              "ac_trm_forward_tokens")
+        return {"embed": embed, "logit": logit}
+
+    def greedy(self, attn_emb, attn_emb_len, max_length, start_idx, end_idx, pad_idx):
+        """On-device greedy search.  Returns device tensors seq (int64), logit, logprob, embed, cnt."""
+        lib = _lib.load()
+        dev = attn_emb.device
+        B, Tm, _ = attn_emb.shape
+        mem_len = torch.as_tensor(attn_emb_len).to(device=dev, dtype=torch.int32)
+        memkv = self.memory(attn_emb)
+        seq = torch.empty(B, max_length, device=dev, dtype=torch.int64)
+        logit = torch.empty(B, max_length, self.vocab_size, device=dev, dtype=torch.float32)
+        logprob = torch.empty(B, max_length, device=dev, dtype=torch.float32)
+        embed = torch.empty(B, max_length, self.d_model, device=dev, dtype=torch.float32)
+        cnt = torch.empty(max_length, device=dev, dtype=torch.int32)
+        ws = self.workspace(B, max_length, dev)
+        check(lib.ac_trm_greedy(ctypes.byref(self.weights()), ptr(memkv), ptr(mem_len), B, Tm, max_length,
+                                start_idx, end_idx, pad_idx, ptr(seq), ptr(logit), ptr(logprob), ptr(embed),
+                                ptr(cnt), ptr(ws), stream()), "ac_trm_greedy")
+        return {"seq": seq, "logit": logit, "sampled_logprob": logprob, "embed": embed, "unfinished_cnt": cnt}
+
+    def beam_step(self, memkv, mem_len, B, beam, Tm, max_length, t, temp, tokens, mask, cum, ws):
+        lib = _lib.load()
+        dev = memkv.device
+        top_val = torch.empty(B, beam, device=dev, dtype=torch.float32)
+        top_idx = torch.empty(B, beam, device=dev, dtype=torch.int32)
+        check(lib.ac_trm_beam_step(ctypes.byref(self.weights()), ptr(memkv), ptr(mem_len), B, beam, Tm, max_length,
+                                   t, float(temp), ptr(tokens), ptr(mask), ptr(cum), ptr(top_val), ptr(top_idx),
+                                   ptr(ws), stream()), "ac_trm_beam_step")
+        return top_val, top_idx
+
+    def beam_reorder(self, R, max_length, t, src_row, ws):
+        lib = _lib.load()
+        check(lib.ac_trm_beam_reorder(ctypes.byref(self.weights()), R, max_length, t, ptr(src_row), ptr(ws),
+                                      stream()), "ac_trm_beam_reorder")

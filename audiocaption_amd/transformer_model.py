@@ -1,0 +1,188 @@
+"""Encoder-decoder captioning model, MI355X path.  Plugin-compatible with the reference classes
+``captioning.models.base.CaptionModel`` (base.py:24-361) and
+``captioning.models.transformer_model.TransformerModel`` (transformer_model.py:11-86):
+
+* ``model(input_dict) -> dict`` with ``seq`` (int64, CPU, (B, max_len)), ``logit``, ``sampled_logprob``,
+  ``embed`` plus the encoder outputs; ``input_dict`` keys as ``Runner._forward`` builds them (run.py:29-51);
+* class-level ``set_index(start_idx, end_idx, pad_idx)`` and the defaults pad 0 / start 1 / end 2 /
+  max_length 20 (base.py:10-21);
+* the decoder must be a ``TransformerDecoder`` (base.py:42-46).
+
+Differences in schedule, not in results: greedy search runs entirely on the device (one C call, no
+per-step host synchronisation, KV cache); beam search batches ALL clips and beams into one decoder
+call per step (the reference loops over clips, base.py:266) with the reference's per-clip bookkeeping
+(done beams, -1000 trick, length-normalised score, early exit) done on the host from one small
+device->host copy per step.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .transformer_decoder import TransformerDecoder
+
+
+class CaptionMetaMixin:
+    pad_idx = 0
+    start_idx = 1
+    end_idx = 2
+    max_length = 20
+
+    @classmethod
+    def set_index(cls, start_idx, end_idx, pad_idx):
+        cls.start_idx = start_idx
+        cls.end_idx = end_idx
+        cls.pad_idx = pad_idx
+
+
+class CaptionModel(nn.Module, CaptionMetaMixin):
+
+    compatible_decoders = (TransformerDecoder,)
+
+    def __init__(self, encoder, decoder, **kwargs):
+        super().__init__()
+        self.encoder = encoder
+        self.decoder = decoder
+        self.vocab_size = decoder.vocab_size
+        self.train_forward_keys = ["cap", "cap_len", "ss_ratio"]
+        self.inference_forward_keys = ["sample_method", "max_length", "temp"]
+        if kwargs.get("freeze_encoder", False):
+            for param in self.encoder.parameters():
+                param.requires_grad = False
+        names = [c.__name__ for c in self.compatible_decoders]
+        assert isinstance(self.decoder, self.compatible_decoders), \
+            f"{self.decoder.__class__.__name__} is incompatible with {self.__class__.__name__}, " \
+            f"please use decoder in {names} "
+
+    def forward(self, input_dict):
+        encoder_output_dict = self.encoder(input_dict)
+        output = self.forward_decoder(input_dict, encoder_output_dict)
+        return output
+
+    def forward_decoder(self, input_dict, encoder_output_dict):
+        if input_dict["mode"] == "train":
+            raise NotImplementedError(
+                "CaptionModel (HIP path): mode='train' (teacher forcing / scheduled sampling with backward) "
+                "is not built yet; only mode='inference' exists")
+        elif input_dict["mode"] == "inference":
+            forward_dict = {"mode": "inference"}
+            default_args = {"sample_method": "greedy", "max_length": self.max_length, "temp": 1.0}
+            for key in self.inference_forward_keys:
+                forward_dict[key] = input_dict.get(key, default_args[key])
+            if forward_dict["sample_method"] == "beam":
+                forward_dict["beam_size"] = input_dict.get("beam_size", 3)
+                forward_dict["n_best"] = input_dict.get("n_best", False)
+                forward_dict["n_best_size"] = input_dict.get("n_best_size", forward_dict["beam_size"])
+            forward_dict.update(encoder_output_dict)
+            output = self.inference_forward(forward_dict)
+        else:
+            raise Exception("mode should be either 'train' or 'inference'")
+        output.update(encoder_output_dict)
+        return output
+
+    def inference_forward(self, input_dict):
+        method = input_dict["sample_method"]
+        if method == "beam":
+            return self.beam_search(input_dict)
+        if method == "greedy":
+            return self.greedy_search(input_dict)
+        raise NotImplementedError(
+            f"sample_method={method!r}: only 'greedy' and 'beam' are on the accelerated path "
+            "(dbs / gumbel / top-k / top-p sampling are out of scope, SURVEY.md §2.1 row 7)")
+
+
+class TransformerModel(CaptionModel):
+
+    def __init__(self, encoder, decoder, **kwargs):
+        super().__init__(encoder, decoder, **kwargs)
+
+    # ---- greedy (base.py:152-218) -----------------------------------------------------------------
+    def greedy_search(self, input_dict):
+        if input_dict.get("temp", 1.0) != 1.0:
+            pass  # greedy argmax does not depend on temp (base.py:216-218 ignores it for "greedy")
+        res = self.decoder.greedy(input_dict["attn_emb"], input_dict["attn_emb_len"],
+                                  int(input_dict["max_length"]), self.start_idx, self.end_idx, self.pad_idx)
+        return {
+            "seq": res["seq"].cpu(),                          # the reference keeps seq on the CPU (base.py:122)
+            "logit": res["logit"],
+            "sampled_logprob": res["sampled_logprob"].cpu(),  # CPU as in base.py:126
+            "embed": res["embed"],
+            "unfinished_cnt": res["unfinished_cnt"],
+        }
+
+    # ---- beam search (base.py:254-361), all clips batched ---------------------------------------------
+    def beam_search(self, input_dict):
+        dec = self.decoder
+        attn_emb = input_dict["attn_emb"]
+        dev = attn_emb.device
+        B, Tm, _ = attn_emb.shape
+        beam = int(input_dict["beam_size"])
+        max_length = int(input_dict["max_length"])
+        temp = float(input_dict["temp"])
+        n_best = bool(input_dict.get("n_best", False))
+        n_best_size = int(input_dict.get("n_best_size", beam))
+        V = self.vocab_size
+        R = B * beam
+        mem_len = torch.as_tensor(input_dict["attn_emb_len"]).to(device=dev, dtype=torch.int32)
+        memkv = dec.memory(attn_emb)
+        ws = dec.workspace(R, max_length, dev)
+
+        tokens = np.full((R, max_length + 1), self.end_idx, dtype=np.int32)
+        tokens[:, 0] = self.start_idx
+        cum = np.zeros((B, beam), dtype=np.float32)
+        done = [[] for _ in range(B)]
+        active = [True] * B
+        src_row = np.arange(R, dtype=np.int32)
+        for t in range(max_length):
+            tok_dev = torch.from_numpy(tokens).to(dev)
+            mask_dev = torch.from_numpy((tokens == self.pad_idx).astype(np.uint8)).to(dev)
+            cum_dev = torch.from_numpy(cum.reshape(-1)).to(dev)
+            top_val, top_idx = dec.beam_step(memkv, mem_len, B, beam, Tm, max_length, t, temp, tok_dev, mask_dev,
+                                             cum_dev, ws)
+            top_val = top_val.cpu().numpy()
+            top_idx = top_idx.cpu().numpy()
+            new_tokens = tokens.copy()
+            for i in range(B):
+                if not active[i]:
+                    src_row[i * beam:(i + 1) * beam] = np.arange(i * beam, (i + 1) * beam)
+                    continue
+                prev_beam = top_idx[i] // V
+                word = top_idx[i] % V
+                rows = i * beam + prev_beam
+                new_tokens[i * beam:(i + 1) * beam, :t + 1] = tokens[rows, :t + 1]
+                new_tokens[i * beam:(i + 1) * beam, t + 1] = word
+                src_row[i * beam:(i + 1) * beam] = rows
+                is_end = word == self.end_idx
+                if t == max_length - 1:
+                    is_end[:] = True
+                for k in range(beam):
+                    if is_end[k]:
+                        done[i].append({"seq": new_tokens[i * beam + k, 1:t + 2].copy(),
+                                        "score": float(top_val[i, k]) / (t + 1)})
+                cum[i] = top_val[i] - np.where(is_end, np.float32(1000.0), np.float32(0.0))
+                if len(done[i]) == beam:  # '==' as in base.py:321
+                    active[i] = False
+            tokens = new_tokens
+            if not any(active):
+                break
+            dec.beam_reorder(R, max_length, t, torch.from_numpy(src_row.copy()).to(dev), ws)
+
+        if n_best:
+            seq = torch.full((B, n_best_size, max_length), self.end_idx, dtype=torch.long)
+        else:
+            seq = torch.full((B, max_length), self.end_idx, dtype=torch.long)
+        for i in range(B):
+            beams = sorted(done[i], key=lambda x: -x["score"])
+            if n_best:
+                for j, bm in enumerate(beams[:n_best_size]):
+                    seq[i, j, :len(bm["seq"])] = torch.from_numpy(bm["seq"].astype(np.int64))
+            else:
+                s = beams[0]["seq"]
+                seq[i, :len(s)] = torch.from_numpy(s.astype(np.int64))
+        # logit / embed / sampled_logprob are not filled by the reference's beam search either
+        # (base.py:124-127 leaves them at torch.empty / zeros)
+        return {
+            "seq": seq,
+            "logit": torch.empty(B, max_length, V, device=dev),
+            "sampled_logprob": torch.zeros(B, max_length),
+            "embed": torch.empty(B, max_length, dec.d_model, device=dev),
+        }

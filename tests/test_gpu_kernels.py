@@ -1,0 +1,199 @@
+"""GPU parity tests, kernel by kernel: the HIP path (through the C ABI) against the CPU oracle on the
+same seeded inputs.  Tolerances are absolute, fp32, stated per test."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _report(name, got, want):
+    got, want = got.detach().float().cpu(), want.detach().float().cpu()
+    d = (got - want).abs()
+    i = int(d.argmax())
+    print(f"[{name}] shape {tuple(want.shape)} max|diff| {float(d.max()):.3e} mean|diff| {float(d.mean()):.3e} "
+          f"at flat {i}: got {float(got.flatten()[i]):.6f} want {float(want.flatten()[i]):.6f}; "
+          f"|want| max {float(want.abs().max()):.3e}")
+    return float(d.max())
+
+
+@pytest.fixture(scope="module")
+def K():
+    from audiocaption_amd import build
+    build.build()
+    from audiocaption_amd import kernels
+    return kernels
+
+
+def test_library_loaded_is_in_tree():
+    from audiocaption_amd import _lib, build
+    build.build()
+    _lib.load()
+    assert os.path.exists(_lib.LIB_PATH)
+    with open("/proc/self/maps") as f:
+        assert "libaudiocaption_hip.so" in f.read()
+
+
+@pytest.mark.parametrize("M,N,K_", [(64, 256, 256), (64, 768, 256), (64, 4981, 256), (64, 256, 1024),
+                                    (4, 768, 256), (192, 4981, 256), (1984, 1536, 2048), (837, 512, 256),
+                                    (130, 70, 96)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_linear(K, M, N, K_, relu):
+    g = torch.Generator().manual_seed(M * 131 + N)
+    x = torch.randn(M, K_, generator=g)
+    w = torch.randn(N, K_, generator=g) / math.sqrt(K_)
+    b = torch.randn(N, generator=g)
+    want = torch.nn.functional.linear(x, w, b)
+    if relu:
+        want = want.relu()
+    got = K.linear(x.cuda(), w.cuda(), b.cuda(), relu=relu)
+    assert _report(f"linear {M}x{N}x{K_}", got, want) < 2e-5 * max(1.0, math.sqrt(K_ / 256))
+
+
+def test_linear_asymmetric_identity(K):
+    """transpose-detecting check: X = I gives Y = W^T rows, with an asymmetric W."""
+    n = 64
+    w = torch.arange(n * n, dtype=torch.float32).reshape(n, n) / 100.0
+    got = K.linear(torch.eye(n).cuda(), w.cuda(), None)
+    assert torch.equal(got.cpu(), w.t().contiguous())
+
+
+def test_linear_strided_rows(K):
+    g = torch.Generator().manual_seed(5)
+    big = torch.randn(64, 20 * 256, generator=g)
+    w = torch.randn(300, 256, generator=g)
+    x = big[:, 3 * 256:4 * 256]  # row stride 5120, like embed[b, t]
+    got = K.linear(x.cuda() if False else big.cuda()[:, 3 * 256:4 * 256], w.cuda(), None)
+    assert _report("linear strided", got, x @ w.t()) < 5e-5
+
+
+def test_add_layernorm(K):
+    g = torch.Generator().manual_seed(1)
+    x, y = torch.randn(70, 256, generator=g), torch.randn(70, 256, generator=g)
+    w, b = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g)
+    want = torch.nn.functional.layer_norm(x + y, (256,), w, b)
+    got = K.add_layernorm(x.cuda(), y.cuda(), w.cuda(), b.cuda())
+    assert _report("add_layernorm", got, want) < 5e-6
+    got = K.add_layernorm(x.cuda(), None, w.cuda(), b.cuda())
+    assert _report("layernorm", got, torch.nn.functional.layer_norm(x, (256,), w, b)) < 5e-6
+
+
+@pytest.mark.parametrize("L,B", [(320000, 2), (64000, 3), (35231, 2)])
+def test_logmel_matches_oracle(K, L, B):
+    """fp32 log-mel in dB vs the oracle (torch.stft path).  Tolerance 2e-3 dB absolute: both are fp32
+    transforms of 1024 points followed by 10*log10; the noise inputs have no near-empty bins."""
+    from audiocaption_amd import procedural as P
+    from audiocaption_amd.mel import MelTables
+    from oracle import cpu_path as O
+    wav = torch.from_numpy(P.synthetic_wav(B, L, varied=True))
+    want = O.logmel(wav, 32000)
+    tables = MelTables(32000, 1024, 320, 50.0, 14000.0, 64, "slaney", "slaney", "cuda:0")
+    got = K.logmel(wav.cuda(), tables, channels_last=False)
+    assert got.shape == want.shape
+    assert _report(f"logmel L={L}", got, want) < 2e-3
+    # rows layout + folded affine + zero pad rows
+    T = L // 320 + 1
+    Hp = T + 5
+    sc, sh = torch.rand(64) + 0.5, torch.randn(64)
+    rows = K.logmel(wav.cuda(), tables, sc.cuda(), sh.cuda(), rows_per_clip=Hp).cpu().reshape(B, Hp, 64)
+    want_rows = want.transpose(1, 2) * sc + sh
+    assert _report("logmel rows", rows[:, :T], want_rows) < 4e-3
+    assert float(rows[:, T:].abs().max()) == 0.0
+
+
+def test_logmel_known_answers(K):
+    """zeros -> -100 dB everywhere (clamp at 1e-10); a bin-centred sinusoid peaks in the right mel band."""
+    from audiocaption_amd.mel import MelTables
+    tables = MelTables(32000, 1024, 320, 50.0, 14000.0, 64, "slaney", "slaney", "cuda:0")
+    z = K.logmel(torch.zeros(1, 32000).cuda(), tables, channels_last=False).cpu()
+    assert torch.equal(z, torch.full_like(z, -100.0))
+    t = torch.arange(32000) / 32000.0
+    f0 = 32000.0 / 1024 * 100  # bin 100 = 3125 Hz
+    s = K.logmel(torch.sin(2 * math.pi * f0 * t)[None].cuda(), tables, channels_last=False).cpu()[0]
+    fb = tables.melfb.cpu()
+    assert int(s[:, 50].argmax()) == int(fb[100].argmax())
+
+
+def _ref_conv_block_input(B, H, W, C, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(B, C, H, W, generator=g)
+
+
+def _to_rows(x_nchw, Hp):
+    """(B, C, H, W) -> [B*Hp][W][C] with zero pad rows."""
+    B, C, H, W = x_nchw.shape
+    out = torch.zeros(B, Hp, W, C)
+    out[:, :H] = x_nchw.permute(0, 2, 3, 1)
+    return out.reshape(B * Hp, W, C).contiguous()
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,mode", [
+    (2, 13, 64, 64, 64, 0), (2, 13, 64, 64, 64, 1), (3, 21, 32, 64, 128, 0), (2, 20, 32, 128, 128, 1),
+    (2, 11, 16, 128, 256, 0), (2, 9, 8, 256, 512, 1), (3, 7, 4, 512, 1024, 0), (3, 6, 4, 1024, 1024, 1),
+    (5, 3, 2, 1024, 2048, 0), (5, 3, 2, 2048, 2048, 2), (1, 31, 2, 64, 128, 2), (2, 30, 16, 32, 64, 1)])
+@pytest.mark.parametrize("map_mode", [-1, 0])
+def test_conv3x3_bn_relu(K, B, H, W, Cin, Cout, mode, map_mode):
+    """conv3x3+BN+ReLU(+pool / +mean over W) vs F.conv2d on the CPU.  Tolerance 1e-4 * sqrt(K/576) abs on
+    O(1) activations (fp32 accumulation-order differences only)."""
+    import torch.nn.functional as F
+    if map_mode == 0 and Cin > 512:
+        pytest.skip("linear mapping only exercised on the small shapes")
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + W + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * math.sqrt(2.0 / (9 * Cin))
+    sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    y = F.relu(F.conv2d(x, w, padding=1) * sc[None, :, None, None] + sh[None, :, None, None])
+    Hp = H + 1 + ((H + 1) % 2)  # even, >= H+1
+    if mode == 1:
+        want = F.avg_pool2d(y, 2)
+        Ho, Wo, Hpo = H // 2, W // 2, Hp // 2
+        want_rows = _to_rows(want, Hpo)
+        out = torch.full((B * Hpo, Wo, Cout), 7.0).cuda()
+    elif mode == 0:
+        want_rows = _to_rows(y, Hp)
+        out = torch.full((B * Hp, W, Cout), 7.0).cuda()
+    else:
+        want_rows = y.mean(dim=3).transpose(1, 2).contiguous()  # (B, H, Cout)
+        out = torch.full((B, H, Cout), 7.0).cuda()
+    K.conv3x3_bn_relu(_to_rows(x, Hp).cuda(), K.pack_conv_weight(w.cuda()), sc.cuda(), sh.cuda(), out, B, Hp, H, W,
+                      Cin, Cout, mode, map_mode)
+    tol = 1e-4 * max(1.0, math.sqrt(9 * Cin / 576))
+    assert _report(f"conv {B}x{H}x{W} {Cin}->{Cout} mode{mode}", out.reshape(want_rows.shape), want_rows) < tol
+
+
+def test_conv3x3_first(K):
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(3)
+    B, H, W = 3, 37, 64
+    x = torch.randn(B, 1, H, W, generator=g)
+    w = torch.randn(64, 1, 3, 3, generator=g) * 0.5
+    sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    y = F.relu(F.conv2d(x, w, padding=1) * sc[None, :, None, None] + sh[None, :, None, None])
+    Hp = 40
+    out = torch.full((B * Hp, W, 64), 7.0).cuda()
+    K.conv3x3_first(_to_rows(x, Hp).reshape(B * Hp, W).cuda(), w.reshape(64, 9).cuda(), sc.cuda(), sh.cuda(), out,
+                    B, Hp, H, W)
+    assert _report("conv_first", out, _to_rows(y, Hp)) < 1e-5
+
+
+def test_gru_layer_and_pooling_vs_oracle(K, state4981):
+    from oracle import cpu_path as O
+    import audiocaption_amd as A
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(5, 31, 2048, generator=g)
+    lens = [31, 20, 7, 1, 25]
+    want = O.gru_forward(state4981, x, lens)
+    rnn = A.RnnEncoder(-1, 2048, 2048, bidirectional=True, hidden_size=256, dropout=0.5, num_layers=3)
+    rnn.load_state_dict({k[len("encoder.rnn."):]: v for k, v in state4981.items() if k.startswith("encoder.rnn.")})
+    rnn = rnn.eval().cuda()
+    got = rnn({"attn": x.cuda(), "attn_len": torch.tensor(lens)})
+    assert _report("gru attn_emb", got["attn_emb"], want["attn_emb"]) < 2e-5
+    assert _report("gru fc_emb", got["fc_emb"], want["fc_emb"]) < 2e-5
+    assert torch.equal(got["attn_emb_len"], torch.tensor(lens))
+    # truncation to max(len) (pad_packed_sequence) and zeros at padded steps
+    got2 = rnn({"attn": x.cuda(), "attn_len": torch.tensor([9, 20, 7, 1, 12])})
+    assert got2["attn_emb"].shape == (5, 20, 512)
+    assert float(got2["attn_emb"][0, 9:].abs().max()) == 0.0
