@@ -44,10 +44,21 @@ def conv3x3_first(x, w, scale, shift, out, B, Hp, H, W=64):
     return out
 
 
+# Optional per-launch observer used by bench.py to time the dominant kernel with HIP events on the
+# launch stream: called as hook(phase, info) with phase "pre"/"post" around every MFMA conv launch.
+CONV_LAUNCH_HOOK = None
+
+
 def conv3x3_bn_relu(x, wpk, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode=-1):
     lib = _lib.load()
+    hook = CONV_LAUNCH_HOOK
+    if hook is not None:
+        info = {"B": B, "H": H, "Hp": Hp, "W": W, "Cin": Cin, "Cout": Cout, "mode": mode}
+        hook("pre", info)
     check(lib.ac_conv3x3_bn_relu(ptr(x), ptr(wpk), ptr(scale), ptr(shift), ptr(out), B, Hp, H, W, Cin, Cout,
                                  mode, map_mode, stream()), "ac_conv3x3_bn_relu")
+    if hook is not None:
+        hook("post", info)
     return out
 
 

@@ -1,0 +1,167 @@
+#!/usr/bin/env python
+"""Headline benchmark: clips/s for encode + greedy decode of the Cnn14Rnn-Trm captioner on synthetic
+10 s @ 32 kHz clips (BASELINE.json metric, configs[1]: batch 64 per GPU, max_length 20).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (torch.distributed / RCCL when N > 1); clips are independent, so the batch is
+sharded across ranks with no data-path collective ("scaling": "weak").  A step is one pass of the hot
+path (log-mel -> Cnn14 -> bi-GRU -> greedy Transformer decoding, token ids back on the host) over one
+resident batch.  Rank 0 prints ONE JSON line with the throughput, the roofline of the dominant kernel
+(the pooled 128-channel-tile instance of the f32-MFMA conv, timed live with HIP events on its launch
+stream) and a CPU baseline (the oracle, timed on the host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import torch
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step")
+    ap.add_argument("--seconds", type=float, default=10.0, help="clip duration")
+    ap.add_argument("--max-length", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-clips", type=int, default=4, help="clips per CPU-baseline pass")
+    ap.add_argument("--cpu-reps", type=int, default=3)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    import audiocaption_amd as A
+    from audiocaption_amd import build, kernels as K, procedural as P
+    build.build()
+
+    vocab = 4368  # Clotho v2 (eg_configs/clotho_v2/waveform/cnn14rnn_trm.yaml:31)
+    state = P.to_torch(P.cnn14rnn_trm_state(vocab))
+    model = A.init_model_from_config(A.cnn14rnn_trm_config(vocab), print_fn=lambda s: None)
+    model.load_state_dict(state, strict=True)
+    model = model.eval().to(dev)
+
+    L = int(args.seconds * 32000)
+    B = args.batch
+    wav = torch.from_numpy(P.synthetic_wav(B, L, seed=P.BASE_SEED + rank)).to(dev)  # resident in HBM
+    wav_len = [L] * B
+    inp = {"mode": "inference", "wav": wav, "wav_len": wav_len, "specaug": False, "sample_method": "greedy",
+           "max_length": args.max_length}
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    out = None
+    for _ in range(args.warmup):
+        out = model(dict(inp))
+    # ---- timed region: exactly K steps, HIP events around every launch of the dominant kernel ----
+    events = []
+
+    def hook(phase, info):
+        if info["mode"] == 1 and info["Cout"] % 128 == 0:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()  # on torch's current stream == the kernel's launch stream
+            if phase == "pre":
+                events.append([e, None, dict(info)])
+            else:
+                events[-1][1] = e
+
+    K.CONV_LAUNCH_HOOK = hook
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = model(dict(inp))
+    sync_all()
+    t1 = time.perf_counter()
+    K.CONV_LAUNCH_HOOK = None
+    elapsed = t1 - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    steps_exec = int((out["unfinished_cnt"].cpu() > 0).sum().item()) + 1
+    steps_exec = min(steps_exec, args.max_length)
+
+    # dominant kernel: conv3x3_mfma_kernel<128, POOL> (conv2 of blocks 2-5)
+    flops = sum(2.0 * 9 * i["Cin"] * i["Cout"] * i["H"] * i["W"] * i["B"] for _, _, i in events)
+    ms = sum(s.elapsed_time(e) for s, e, _ in events)
+    n_launch = len(events)
+    achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+
+    result = None
+    if rank == 0:
+        clips = world * B * args.steps
+        result = {
+            "metric": "clips/sec (10 s @ 32 kHz) encode+greedy-decode, Cnn14_Rnn-Trm",
+            "value": clips / elapsed,
+            "unit": "clips/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"Cnn14Rnn-Trm greedy decode, batch {B} per GPU, {args.seconds:g} s @ 32 kHz "
+                                   f"synthetic clips, max_length {args.max_length}, vocab {vocab} (BASELINE configs[1])",
+                       "global_batch": world * B, "decode_steps_executed": steps_exec,
+                       "sharding": f"clips sharded over {world} rank(s), no data-path collective"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "conv3x3_mfma_kernel<128, POOL> (f32 MFMA implicit GEMM, conv2 of blocks 2-5)",
+                         "launches_timed": n_launch,
+                         "avg_launch_ms": ms / n_launch if n_launch else None,
+                         "algorithmic_gflop_per_launch": flops / n_launch / 1e9 if n_launch else None},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import cpu_path as O  # the CPU restatement, timed as a reported baseline only
+            nc = args.cpu_clips
+            cwav = torch.from_numpy(P.synthetic_wav(B, L)[:nc])
+            O.caption_forward(state, cwav[:1], [L], "greedy", max_length=args.max_length, force_steps=True)
+            times = []
+            for _ in range(args.cpu_reps):
+                c0 = time.perf_counter()
+                O.caption_forward(state, cwav, [L] * nc, "greedy", max_length=args.max_length, force_steps=True)
+                times.append(time.perf_counter() - c0)
+            times.sort()
+            result["cpu_baseline"] = {
+                "value": nc / times[len(times) // 2], "unit": "clips/s", "cores": torch.get_num_threads(),
+                "kind": "port",
+                "sample": f"oracle/cpu_path.py caption_forward (fp32 torch CPU ops), {nc} clips x {args.seconds:g} s, "
+                          f"greedy {args.max_length} steps, median of {args.cpu_reps} passes after 1 warm-up"}
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

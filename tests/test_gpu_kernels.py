@@ -109,7 +109,7 @@ def test_logmel_known_answers(K):
     from audiocaption_amd.mel import MelTables
     tables = MelTables(32000, 1024, 320, 50.0, 14000.0, 64, "slaney", "slaney", "cuda:0")
     z = K.logmel(torch.zeros(1, 32000).cuda(), tables, channels_last=False).cpu()
-    assert torch.equal(z, torch.full_like(z, -100.0))
+    assert float((z + 100.0).abs().max()) < 1e-4  # 10*log10f(1e-10f) is -100 to within an ulp
     t = torch.arange(32000) / 32000.0
     f0 = 32000.0 / 1024 * 100  # bin 100 = 3125 Hz
     s = K.logmel(torch.sin(2 * math.pi * f0 * t)[None].cuda(), tables, channels_last=False).cpu()[0]
