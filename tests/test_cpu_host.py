@@ -1,0 +1,156 @@
+"""CPU tests of the host side: the C-ABI library builds, loads and exports every declared symbol (no
+compute calls), plugin construction mirrors the reference protocol, and the product path refuses to
+run without the GPU instead of falling back."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import audiocaption_amd as A
+from audiocaption_amd import _lib, build, config, procedural as P
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    return build.build()
+
+
+def test_library_exports_every_declared_symbol(lib_path):
+    header = open(os.path.join(REPO, "include", "audiocaption_hip.h")).read()
+    declared = set(re.findall(r"\b(ac_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    lib = ctypes.CDLL(lib_path)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/audiocaption_hip.h but not exported"
+    assert declared == set(_lib.SIGNATURES), "ctypes signature table out of sync with the header"
+    assert lib.ac_abi_version() == 1
+
+
+def test_argument_validation_without_gpu(lib_path):
+    lib = _lib.load()
+    # rejected before any HIP call: null pointers / bad sizes -> AC_ERR_ARG
+    assert lib.ac_linear(None, None, None, None, 4, 4, 32, 32, 32, 4, 0, None) == -1
+    assert lib.ac_conv3x3_bn_relu(None, None, None, None, None, 1, 8, 4, 16, 32, 64, 0, -1, None) == -1
+    assert lib.ac_gru_layer(None, None, None, None, None, 1, 1, 256, None) == -1
+    w = _lib.AcTrmWeights()
+    assert lib.ac_trm_workspace_floats(ctypes.byref(w), 4, 20) == -1  # zeroed config is invalid
+
+
+def test_workspace_size_formula(lib_path):
+    lib = _lib.load()
+    w = _lib.AcTrmWeights()
+    w.d_model, w.nhead, w.nlayers, w.dim_ff, w.vocab, w.max_pos, w.attn_emb_dim = 256, 4, 2, 1024, 4368, 100, 512
+    n = lib.ac_trm_workspace_floats(ctypes.byref(w), 64, 20)
+    cache = 2 * 2 * 2 * 64 * 20 * 256  # 2 sets x (K,V) x layers x rows x len x d
+    assert n > cache + 64 * 4368
+
+
+def test_state_dict_keys_and_param_count_match_reference_layout():
+    model = A.init_model_from_config(A.cnn14rnn_trm_config(4981), print_fn=lambda s: None)
+    sd = model.state_dict()
+    want = P.cnn14rnn_trm_state(4981)
+    assert set(sd) == set(want)
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(want[k].shape), k
+    assert sum(p.numel() for p in model.parameters()) == 90_395_840  # SURVEY.md §2.4 (AudioCaps vocab)
+    trainable = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    assert trainable == 10_696_448  # GRU + decoder minus the frozen pe table: the DDP gradient payload
+    assert not any(p.requires_grad for p in model.encoder.cnn.parameters())  # freeze_cnn
+
+
+def test_stale_clotho_encoder_name_is_accepted():
+    cfg = A.cnn14rnn_trm_config(4368, encoder_name="Cnn14RnnEncoder")
+    model = A.init_model_from_config(cfg, print_fn=lambda s: None)
+    assert isinstance(model.encoder, A.CrnnEncoder)
+
+
+def test_decoder_compatibility_assertion():
+    enc = torch.nn.Identity()
+
+    class NotADecoder(torch.nn.Module):
+        vocab_size = 10
+
+    with pytest.raises(AssertionError):
+        A.TransformerModel(enc, NotADecoder())
+
+
+def test_set_index_is_class_level():
+    try:
+        A.TransformerModel.set_index(5, 6, 7)
+        assert (A.TransformerModel.start_idx, A.TransformerModel.end_idx, A.TransformerModel.pad_idx) == (5, 6, 7)
+    finally:
+        A.TransformerModel.set_index(1, 2, 0)
+
+
+def test_no_cpu_fallback():
+    model = A.init_model_from_config(A.cnn14rnn_trm_config(64), print_fn=lambda s: None).eval()
+    with pytest.raises(_lib.HipLibraryError):
+        model({"mode": "inference", "wav": torch.zeros(1, 32000), "wav_len": [32000], "specaug": False})
+    with pytest.raises(Exception):
+        model({"mode": "bogus", "wav": torch.zeros(1, 32000), "wav_len": [32000], "specaug": False})
+    model.train()
+    with pytest.raises(NotImplementedError):
+        model({"mode": "train", "wav": torch.zeros(1, 32000), "wav_len": [32000], "specaug": False})
+
+
+def test_feat_len_and_geometry():
+    from audiocaption_amd.cnn_encoder import cnn14_feat_len
+    lens = cnn14_feat_len([320000, 280000, 160000, 300000], 320)
+    assert lens.tolist() == [31, 27, 15, 29] and lens.dtype == torch.int64 and lens.device.type == "cpu"
+    cnn = A.Cnn14Encoder(32000)
+    T, H, Hp = cnn.geometry(320000)
+    assert T == 1001 and H == [1001, 500, 250, 125, 62, 31] and Hp == [1024, 512, 256, 128, 64, 32]
+    T, H, Hp = cnn.geometry(960000)
+    assert H[5] == 93 and Hp[5] == 94 and all(Hp[k] == 2 * Hp[k + 1] and Hp[k] > H[k] for k in range(5))
+    with pytest.raises(ValueError):
+        cnn.geometry(3000)
+
+
+def test_pack_conv_weight_layout():
+    from audiocaption_amd.kernels import pack_conv_weight
+    w = torch.arange(128 * 64 * 9, dtype=torch.float32).reshape(128, 64, 3, 3)
+    p = pack_conv_weight(w)
+    assert p.shape == (2, 9, 128, 32)
+    assert p[1, 5, 77, 3] == w[77, 35, 1, 2]  # chunk 1, tap ky=1,kx=2, cout 77, cin 32+3
+
+
+def test_compat_install_resolves_reference_dotted_paths():
+    import importlib
+    import sys
+    from audiocaption_amd import compat
+    saved = {k: v for k, v in sys.modules.items() if k.startswith("captioning")}
+    try:
+        compat.install()
+        mod = importlib.import_module("captioning.models.crnn_trm_encoder")
+        assert mod.CrnnEncoder is A.CrnnEncoder
+        assert importlib.import_module("captioning.models.transformer_model").TransformerModel is A.TransformerModel
+    finally:
+        for k in [k for k in sys.modules if k.startswith("captioning")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+
+
+def test_procedural_weights_are_deterministic():
+    a = P.decoder_state("decoder.", 100)
+    b = P.decoder_state("decoder.", 100)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    w = P.synthetic_wav(2, 1000)
+    assert w.dtype == np.float32 and np.abs(w).max() <= 1.0 and np.array_equal(w, P.synthetic_wav(2, 1000))
+
+
+def test_mel_filterbank_properties():
+    from audiocaption_amd.mel import melscale_fbanks
+    fb = melscale_fbanks(513, 50.0, 14000.0, 64, 32000, "slaney", "slaney")
+    assert fb.shape == (513, 64) and float(fb.min()) >= 0
+    nz = (fb > 0)
+    assert nz.any(0).all()                      # every filter has support
+    first = nz.float().argmax(0)
+    assert (first[1:] >= first[:-1]).all()      # supports move up monotonically
+    assert int(nz.sum(1).max()) <= 2            # triangular: a bin feeds at most 2 filters
+    freqs = torch.linspace(0, 16000, 513)
+    assert float(fb[freqs < 50.0].abs().max()) == 0 and float(fb[freqs > 14000.0].abs().max()) == 0

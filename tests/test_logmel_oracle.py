@@ -1,0 +1,45 @@
+"""CPU: the (parity-unpinned) log-mel oracle cross-checked independently - float64 numpy DFT of the
+reflect-padded, Hann-windowed frames, closed-form answers, and agreement of the product-side filterbank
+(audiocaption_amd/mel.py) with the oracle's."""
+import math
+
+import numpy as np
+import torch
+
+from audiocaption_amd import procedural as P
+from audiocaption_amd.mel import melscale_fbanks
+from oracle import cpu_path as O
+
+
+def _logmel_f64(wav, n_fft=1024, hop=320):
+    x = np.asarray(wav, dtype=np.float64)
+    xp = np.pad(x, (n_fft // 2, n_fft // 2), mode="reflect")
+    T = len(x) // hop + 1
+    n = np.arange(n_fft)
+    win = 0.5 - 0.5 * np.cos(2 * np.pi * n / n_fft)
+    frames = np.stack([xp[t * hop:t * hop + n_fft] * win for t in range(T)])
+    power = np.abs(np.fft.rfft(frames, axis=1)) ** 2
+    fb = O.mel_filterbank().double().numpy()
+    return 10 * np.log10(np.maximum(power @ fb, 1e-10)).T
+
+
+def test_logmel_matches_float64_dft():
+    wav = P.synthetic_wav(1, 16000, varied=True)[0]
+    got = O.logmel(torch.from_numpy(wav)[None], 32000)[0].numpy()
+    want = _logmel_f64(wav)
+    assert got.shape == want.shape == (64, 51)
+    assert np.abs(got - want).max() < 2e-3
+
+
+def test_logmel_known_answers():
+    z = O.logmel(torch.zeros(1, 8000), 32000)
+    assert torch.equal(z, torch.full_like(z, -100.0))
+    t = torch.arange(32000) / 32000.0
+    f0 = 32000.0 / 1024 * 100
+    s = O.logmel(torch.sin(2 * math.pi * f0 * t)[None], 32000)[0]
+    assert int(s[:, 50].argmax()) == int(O.mel_filterbank()[100].argmax())
+    assert O.logmel(torch.zeros(2, 320000)).shape == (2, 64, 1001)
+
+
+def test_product_filterbank_equals_oracle_filterbank():
+    assert torch.equal(melscale_fbanks(513, 50.0, 14000.0, 64, 32000, "slaney", "slaney"), O.mel_filterbank())
