@@ -38,6 +38,7 @@ SIGNATURES = {
     "ac_abi_version": (_I, []),
     "ac_logmel": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _L, _P]),
     "ac_conv3x3_bn_relu": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ac_conv3x3_bn_relu_winograd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ac_conv3x3_first": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ac_linear": (_I, [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _P]),
     "ac_gru_layer": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),

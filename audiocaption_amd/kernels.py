@@ -53,12 +53,40 @@ def conv3x3_bn_relu(x, wpk, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map
     lib = _lib.load()
     hook = CONV_LAUNCH_HOOK
     if hook is not None:
-        info = {"B": B, "H": H, "Hp": Hp, "W": W, "Cin": Cin, "Cout": Cout, "mode": mode}
+        info = {"B": B, "H": H, "Hp": Hp, "W": W, "Cin": Cin, "Cout": Cout, "mode": mode, "algo": "direct"}
         hook("pre", info)
     check(lib.ac_conv3x3_bn_relu(ptr(x), ptr(wpk), ptr(scale), ptr(shift), ptr(out), B, Hp, H, W, Cin, Cout,
                                  mode, map_mode, stream()), "ac_conv3x3_bn_relu")
     if hook is not None:
         hook("post", info)
+    return out
+
+
+def conv3x3_bn_relu_winograd(x, upk, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode=-1):
+    lib = _lib.load()
+    hook = CONV_LAUNCH_HOOK
+    if hook is not None:
+        info = {"B": B, "H": H, "Hp": Hp, "W": W, "Cin": Cin, "Cout": Cout, "mode": mode, "algo": "winograd"}
+        hook("pre", info)
+    check(lib.ac_conv3x3_bn_relu_winograd(ptr(x), ptr(upk), ptr(scale), ptr(shift), ptr(out), B, Hp, H, W, Cin,
+                                          Cout, mode, map_mode, stream()), "ac_conv3x3_bn_relu_winograd")
+    if hook is not None:
+        hook("post", info)
+    return out
+
+
+def pack_conv_weight_winograd(w):
+    """OIHW (Cout, Cin, 3, 3) -> U = G g G^T as [Cin/32][4 j][4 i][Cout][32] (csrc/conv3x3_winograd.hip).
+    The transform is evaluated in float64 and rounded once to fp32."""
+    cout, cin = w.shape[0], w.shape[1]
+    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]],
+                     dtype=torch.float64, device=w.device)
+    out = torch.empty(cin // 32, 4, 4, cout, 32, device=w.device, dtype=torch.float32)
+    step = max(1, (1 << 22) // (cin * 16))  # bound the float64 temporary
+    for o0 in range(0, cout, step):
+        u = torch.einsum("ia,ocab,jb->ocij", G, w[o0:o0 + step].double(), G)  # (o, c, i, j)
+        u = u.permute(1, 3, 2, 0).reshape(cin // 32, 32, 4, 4, -1).permute(0, 2, 3, 4, 1)  # [c/32][j][i][o][32]
+        out[:, :, :, o0:o0 + step] = u.float()
     return out
 
 

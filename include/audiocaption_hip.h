@@ -54,6 +54,12 @@ int ac_logmel(const float* wav, int B, int L, int n_fft, int hop, const float* w
  * map_mode: -1 auto, 0 linear, 1 weight-slab-per-XCD, 2 halo-patch-per-XCD block mapping. */
 int ac_conv3x3_bn_relu(const float* in, const float* wpk, const float* scale, const float* shift, float* out,
                        int B, int Hp, int H, int W, int Cin, int Cout, int mode, int map_mode, void* stream);
+/* Same operation in Winograd F(2x2,3x3) form (2.25x fewer multiplications, fp32): identical arguments
+ * except the weights, upk = U = G g G^T packed as [Cin/32][4 j][4 i][Cout][32] (transform column j, row i);
+ * Hp must be even. */
+int ac_conv3x3_bn_relu_winograd(const float* in, const float* upk, const float* scale, const float* shift,
+                                float* out, int B, int Hp, int H, int W, int Cin, int Cout, int mode,
+                                int map_mode, void* stream);
 /* First conv (Cin = 1): in [B*Hp][64], w [64][9] (OIHW), out [B*Hp][64][64]. */
 int ac_conv3x3_first(const float* in, const float* w, const float* scale, const float* shift, float* out,
                      int B, int Hp, int H, int W, void* stream);

@@ -35,6 +35,7 @@ def _cnn_from_logmel(cnn, lms):
     pooled = torch.empty(B * Hp[1] * 32 * 64, device=lms.device)
     W = 64
     from audiocaption_amd.cnn_encoder import CHANNELS
+    conv = K.conv3x3_bn_relu_winograd if cnn.conv_algo == "winograd" else K.conv3x3_bn_relu
     blocks = []
     for b in range(6):
         cin, cout = CHANNELS[b], CHANNELS[b + 1]
@@ -43,15 +44,15 @@ def _cnn_from_logmel(cnn, lms):
         if b == 0:
             K.conv3x3_first(x0, w1, s1, t1, full, B, Hp[0], H[0], W)
         else:
-            K.conv3x3_bn_relu(pooled, w1, s1, t1, full, B, Hp[b], H[b], W, cin, cout, 0)
+            conv(pooled, w1, s1, t1, full, B, Hp[b], H[b], W, cin, cout, 0)
         if b < 5:
-            K.conv3x3_bn_relu(full, w2, s2, t2, pooled, B, Hp[b], H[b], W, cout, cout, 1)
+            conv(full, w2, s2, t2, pooled, B, Hp[b], H[b], W, cout, cout, 1)
             W //= 2
             blk = pooled[:B * Hp[b + 1] * W * cout].reshape(B, Hp[b + 1], W, cout)[:, :H[b + 1]]
             blocks.append(blk.permute(0, 3, 1, 2).clone())  # (B, C, H, W) like the reference
         else:
             attn = torch.empty(B, H[5], cout, device=lms.device)
-            K.conv3x3_bn_relu(full, w2, s2, t2, attn, B, Hp[b], H[b], W, cout, cout, 2)
+            conv(full, w2, s2, t2, attn, B, Hp[b], H[b], W, cout, cout, 2)
     return attn, blocks
 
 
