@@ -129,7 +129,8 @@ class Cnn14Encoder(nn.Module):
         H = [T >> k for k in range(6)]
         if H[5] < 1:
             raise ValueError(f"clips of {n_samples} samples are shorter than one Cnn14 output frame")
-        Hp = [(H[5] + 1) << (5 - k) for k in range(6)]
+        hp6 = (H[5] + 2) & ~1  # >= H6 + 1 and even (a 2-row Winograd tile / pooling pair never straddles clips)
+        Hp = [hp6 << (5 - k) for k in range(6)]
         return T, H, Hp
 
     def encode(self, wav):

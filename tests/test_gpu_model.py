@@ -27,7 +27,7 @@ def _cnn_from_logmel(cnn, lms):
     pk = cnn._pack(lms.device)
     B, _, T = lms.shape
     H = [T >> k for k in range(6)]
-    Hp = [(H[5] + 1) << (5 - k) for k in range(6)]
+    Hp = cnn.geometry((T - 1) * cnn.hop_length)[2]
     x0 = torch.zeros(B, Hp[0], 64, device=lms.device)
     x0[:, :T] = lms.transpose(1, 2) * pk["bn0"][0] + pk["bn0"][1]
     x0 = x0.reshape(B * Hp[0], 64).contiguous()

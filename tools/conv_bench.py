@@ -1,0 +1,69 @@
+#!/usr/bin/env python
+"""Per-layer timing of the Cnn14 conv kernels (HIP events on the launch stream), direct vs Winograd.
+Development tool: `python tools/conv_bench.py [--batch 64] [--iters 5]`."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from audiocaption_amd import build, kernels as K
+
+LAYERS = [  # (name, H, Hp, W, Cin, Cout, mode)
+    ("b1c2", 1001, 1024, 64, 64, 64, 1), ("b2c1", 500, 512, 32, 64, 128, 0), ("b2c2", 500, 512, 32, 128, 128, 1),
+    ("b3c1", 250, 256, 16, 128, 256, 0), ("b3c2", 250, 256, 16, 256, 256, 1), ("b4c1", 125, 128, 8, 256, 512, 0),
+    ("b4c2", 125, 128, 8, 512, 512, 1), ("b5c1", 62, 64, 4, 512, 1024, 0), ("b5c2", 62, 64, 4, 1024, 1024, 1),
+    ("b6c1", 31, 32, 2, 1024, 2048, 0), ("b6c2", 31, 32, 2, 2048, 2048, 2)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--algos", default="direct,winograd")
+    ap.add_argument("--layers", default="")
+    args = ap.parse_args()
+    build.build()
+    B = args.batch
+    dev = "cuda:0"
+    tot = {a: 0.0 for a in args.algos.split(",")}
+    for name, H, Hp, W, Cin, Cout, mode in LAYERS:
+        if args.layers and name not in args.layers.split(","):
+            continue
+        x = torch.randn(B * Hp, W, Cin, device=dev)
+        x.view(B, Hp, W, Cin)[:, H:] = 0
+        w = torch.randn(Cout, Cin, 3, 3, device=dev) * (2.0 / (9 * Cin)) ** 0.5
+        sc, sh = torch.rand(Cout, device=dev) + 0.5, torch.randn(Cout, device=dev) * 0.1
+        if mode == 0:
+            out = torch.empty(B * Hp, W, Cout, device=dev)
+        elif mode == 1:
+            out = torch.empty(B * Hp // 2, W // 2, Cout, device=dev)
+        else:
+            out = torch.empty(B, H, Cout, device=dev)
+        gflop = 2.0 * 9 * Cin * Cout * H * W * B / 1e9
+        line = f"{name} {Cin:4d}->{Cout:4d} {H}x{W} mode{mode} {gflop:7.1f} GF"
+        for algo in args.algos.split(","):
+            if algo == "direct":
+                wp = K.pack_conv_weight(w)
+                fn = lambda: K.conv3x3_bn_relu(x, wp, sc, sh, out, B, Hp, H, W, Cin, Cout, mode)
+            else:
+                wp = K.pack_conv_weight_winograd(w)
+                fn = lambda: K.conv3x3_bn_relu_winograd(x, wp, sc, sh, out, B, Hp, H, W, Cin, Cout, mode)
+            fn()
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(args.iters):
+                fn()
+            e.record()
+            torch.cuda.synchronize()
+            ms = s.elapsed_time(e) / args.iters
+            tot[algo] += ms
+            line += f" | {algo} {ms * 1000:8.1f} us {gflop / ms:7.1f} TF"
+        print(line, flush=True)
+    print("total ms:", {a: round(v, 3) for a, v in tot.items()})
+
+
+if __name__ == "__main__":
+    main()
