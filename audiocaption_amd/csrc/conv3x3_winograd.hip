@@ -79,7 +79,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(WinoParams p) {
   const int TCT = 1 << p.tct_log2;       // tile columns
   const int TRT = 64 >> p.tct_log2;      // tile rows
   const int PW = 2 * TCT + 2, PH = 2 * TRT + 2;
-  const int NPIX = PW * PH;
   const int row0 = (m_tile / p.mt_cols) * (2 * TRT);
   const int col0 = (m_tile % p.mt_cols) * (2 * TCT);
 

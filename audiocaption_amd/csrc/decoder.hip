@@ -90,21 +90,42 @@ __global__ __launch_bounds__(64) void attn_step_kernel(AttnParams p) {
   const int r = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
   const int kr = r / p.row_div;
   const bool act = lane < p.hd;
-  const size_t hoff = (size_t)h * p.hd + lane;
+  const size_t hoff = (size_t)h * p.hd;
   if (p.new_k && act) {
-    const size_t dst = (size_t)kr * p.row_stride + (size_t)(p.nkeys - 1) * p.key_stride + hoff;
-    p.Kw[dst] = p.new_k[(size_t)r * p.ld_new + hoff];
-    p.Vw[dst] = p.new_v[(size_t)r * p.ld_new + hoff];
+    const size_t dst = (size_t)kr * p.row_stride + (size_t)(p.nkeys - 1) * p.key_stride + hoff + lane;
+    p.Kw[dst] = p.new_k[(size_t)r * p.ld_new + hoff + lane];
+    p.Vw[dst] = p.new_v[(size_t)r * p.ld_new + hoff + lane];
   }
   __syncthreads();
-  const float qv = act ? p.q[(size_t)r * p.ldq + hoff] * p.scale : 0.f;
+  const float* qp = p.q + (size_t)r * p.ldq + hoff;
   const float* Kb = p.K + (size_t)kr * p.row_stride + hoff;
   const float* Vb = p.V + (size_t)kr * p.row_stride + hoff;
   const int klen = p.key_len ? p.key_len[kr] : p.nkeys;
-  for (int j = 0; j < p.nkeys; ++j) {
-    const float s = wave_sum(act ? qv * Kb[(size_t)j * p.key_stride] : 0.f);
-    const bool masked = (j >= klen) || (p.key_mask && p.key_mask[(size_t)r * p.mask_stride + j]);
-    if (lane == 0) sc[j] = masked ? -INFINITY : s;
+  // scores: lane j owns key j (independent 16-byte loads of its whole K row: no serial latency chain)
+  if (p.hd == 64) {
+    f32x4 q[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) q[i] = *(const f32x4*)(qp + 4 * i);
+    for (int j = lane; j < p.nkeys; j += 64) {
+      const float* kp = Kb + (size_t)j * p.key_stride;
+      f32x4 kv[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) kv[i] = *(const f32x4*)(kp + 4 * i);
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        s += (q[i][0] * kv[i][0] + q[i][1] * kv[i][1]) + (q[i][2] * kv[i][2] + q[i][3] * kv[i][3]);
+      const bool masked = (j >= klen) || (p.key_mask && p.key_mask[(size_t)r * p.mask_stride + j]);
+      sc[j] = masked ? -INFINITY : s * p.scale;
+    }
+  } else {
+    for (int j = lane; j < p.nkeys; j += 64) {
+      const float* kp = Kb + (size_t)j * p.key_stride;
+      float s = 0.f;
+      for (int c = 0; c < p.hd; ++c) s = fmaf(qp[c], kp[c], s);
+      const bool masked = (j >= klen) || (p.key_mask && p.key_mask[(size_t)r * p.mask_stride + j]);
+      sc[j] = masked ? -INFINITY : s * p.scale;
+    }
   }
   __syncthreads();
   float m = -INFINITY;
@@ -119,10 +140,158 @@ __global__ __launch_bounds__(64) void attn_step_kernel(AttnParams p) {
   den = wave_sum(den);
   __syncthreads();
   if (act) {
-    float o = 0.f;
-    for (int j = 0; j < p.nkeys; ++j) o = fmaf(sc[j], Vb[(size_t)j * p.key_stride], o);
-    p.out[(size_t)r * p.ldo + hoff] = o / den;
+    // lane d owns output channel d; the value rows are coalesced and independent of each other
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+    int j = 0;
+    for (; j + 4 <= p.nkeys; j += 4) {
+      const float v0 = Vb[(size_t)(j + 0) * p.key_stride + lane], v1 = Vb[(size_t)(j + 1) * p.key_stride + lane];
+      const float v2 = Vb[(size_t)(j + 2) * p.key_stride + lane], v3 = Vb[(size_t)(j + 3) * p.key_stride + lane];
+      o0 = fmaf(sc[j], v0, o0);
+      o1 = fmaf(sc[j + 1], v1, o1);
+      o2 = fmaf(sc[j + 2], v2, o2);
+      o3 = fmaf(sc[j + 3], v3, o3);
+    }
+    for (; j < p.nkeys; ++j) o0 = fmaf(sc[j], Vb[(size_t)j * p.key_stride + lane], o0);
+    p.out[(size_t)r * p.ldo + hoff + lane] = ((o0 + o1) + (o2 + o3)) / den;
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Decode-step projection  Y[R, N] = act(A[R, K] W[N, K]^T + bias)  with the producer of A fused in:
+//   PRO_PLAIN : A = X                                   (rows of a previous kernel's output)
+//   PRO_EMBED : A = E[tok[r][t]] * sqrt(d) + pe[t]       (transformer_decoder.py:89-91)
+//   PRO_ADDLN : A = LayerNorm(X + Y2) * g + b            (the post-LN residual join of the previous sub-layer)
+// For the fused producers the 32-row A tile is built once per block in LDS (K = d_model) and the blocks of
+// column tile 0 also write it out (xout): it is the residual stream for the next join / the `embed` output.
+// Tile 32 x 32, the four waves split K and reduce through LDS: the step is latency-, not throughput-bound.
+// ---------------------------------------------------------------------------------------------
+enum { PRO_PLAIN = 0, PRO_EMBED = 1, PRO_ADDLN = 2 };
+constexpr int DEC_MAX_D = 512;
+
+struct DecGemmParams {
+  const float* X; long ldx;          // PLAIN: A rows; ADDLN: residual input
+  const float* Y2; long ldy2;        // ADDLN: sub-layer output to add
+  const float* ln_w; const float* ln_b;
+  const int* tok; long tok_stride; int t;  // EMBED
+  const float* emb; const float* pe; float emb_scale;
+  float* xout; long ldxo;            // where column-tile-0 blocks store the produced A rows (may be null)
+  const float* W; long ldw; const float* bias;
+  float* Y; long ldy;
+  int M, N, K, relu;
+};
+
+template <int PRO>
+__global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) float dsm[];
+  float* red = dsm;                    // [4][32*33]
+  float* sX = dsm + 4 * 32 * 33;       // [32][K + 4] (fused producers only)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5;
+  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  const int ldsx = p.K + 4;
+  if (PRO != PRO_PLAIN) {
+    // 8 rows per wave; a row is K = d_model <= 512 floats = up to 8 per lane
+    for (int rr = 0; rr < 8; ++rr) {
+      const int row = wave * 8 + rr, r = m0 + row;
+      float v[DEC_MAX_D / 64];
+      const int nv = p.K >> 6;
+      if (r < p.M) {
+        if (PRO == PRO_EMBED) {
+          const int w = p.tok[(size_t)r * p.tok_stride + p.t];
+#pragma unroll
+          for (int i = 0; i < DEC_MAX_D / 64; ++i)
+            if (i < nv) v[i] = p.emb[(size_t)w * p.K + lane + 64 * i] * p.emb_scale + p.pe[(size_t)p.t * p.K + lane + 64 * i];
+        } else {
+          float s = 0.f;
+#pragma unroll
+          for (int i = 0; i < DEC_MAX_D / 64; ++i)
+            if (i < nv) {
+              v[i] = p.X[(size_t)r * p.ldx + lane + 64 * i] + p.Y2[(size_t)r * p.ldy2 + lane + 64 * i];
+              s += v[i];
+            }
+          const float mean = wave_sum(s) / (float)p.K;
+          float q = 0.f;
+#pragma unroll
+          for (int i = 0; i < DEC_MAX_D / 64; ++i)
+            if (i < nv) { const float dl = v[i] - mean; q = fmaf(dl, dl, q); }
+          const float rstd = rsqrtf(wave_sum(q) / (float)p.K + 1e-5f);
+#pragma unroll
+          for (int i = 0; i < DEC_MAX_D / 64; ++i)
+            if (i < nv) v[i] = (v[i] - mean) * rstd * p.ln_w[lane + 64 * i] + p.ln_b[lane + 64 * i];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < DEC_MAX_D / 64; ++i) v[i] = 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < DEC_MAX_D / 64; ++i)
+        if (i < nv) {
+          sX[row * ldsx + lane + 64 * i] = v[i];
+          if (blockIdx.x == 0 && p.xout && r < p.M) p.xout[(size_t)r * p.ldxo + lane + 64 * i] = v[i];
+        }
+    }
+    __syncthreads();
+  }
+  const int kw = p.K >> 2;
+  const int gm_l = m0 + (lane & 31), gn_l = n0 + (lane & 31);
+  const bool mv = gm_l < p.M, nv_ = gn_l < p.N;
+  const float* xa = (PRO == PRO_PLAIN) ? p.X + (size_t)(mv ? gm_l : 0) * p.ldx + wave * kw + half * 4
+                                       : sX + (lane & 31) * ldsx + wave * kw + half * 4;
+  const float* wb = p.W + (size_t)(nv_ ? gn_l : 0) * p.ldw + wave * kw + half * 4;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int k0 = 0; k0 < kw; k0 += 64) {  // up to 8 steps of 8: all loads of the batch issued before the MFMAs
+    f32x4 a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = k0 + 8 * u;
+      if (k < kw) {
+        a[u] = *(const f32x4*)(xa + k);
+        b[u] = *(const f32x4*)(wb + k);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = k0 + 8 * u;
+      if (k < kw) {
+        f32x4 av = a[u], bv = b[u];
+        if (PRO == PRO_PLAIN && !mv) av = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (!nv_) bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = mfma32(av[s], bv[s], acc);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave * (32 * 33) + ((r & 3) + 8 * (r >> 2) + 4 * half) * 33 + (lane & 31)] = acc[r];
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = tid + u * 256, i = e >> 5, jn = e & 31;
+    const int gm = m0 + i, gn = n0 + jn;
+    if (gm < p.M && gn < p.N) {
+      const int o = i * 33 + jn;
+      float y = (red[o] + red[32 * 33 + o]) + (red[2 * 32 * 33 + o] + red[3 * 32 * 33 + o]);
+      if (p.bias) y += p.bias[gn];
+      if (p.relu) y = fmaxf(y, 0.f);
+      p.Y[(size_t)gm * p.ldy + gn] = y;
+    }
+  }
+}
+
+template <int PRO>
+int launch_dec_gemm(const DecGemmParams& p, hipStream_t s) {
+  if (p.K % 32 || (PRO != PRO_PLAIN && (p.K > DEC_MAX_D || p.K % 64))) return AC_ERR_ARG;
+  const size_t lds = (4 * 32 * 33 + (PRO != PRO_PLAIN ? 32 * (p.K + 4) : 0)) * sizeof(float);
+  dim3 grid((p.N + 31) / 32, (p.M + 31) / 32);
+  if (lds > 64 * 1024) {  // d_model 512: opt in to a larger dynamic LDS window
+    if (hipFuncSetAttribute((const void*)dec_gemm_kernel<PRO>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return AC_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL((dec_gemm_kernel<PRO>), grid, dim3(256), lds, s, p);
+  return ac_check_launch();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -289,7 +458,7 @@ __global__ void cache_gather_kernel(const float* src, float* dst, const int* src
 // workspace carving
 // ---------------------------------------------------------------------------------------------
 struct Ws {
-  float *x, *qkv, *att, *tmp, *ff, *q2, *lg;
+  float *x, *x2, *qkv, *att, *tmp, *ff, *q2, *lg;
   float* cache[2];  // [2 (K,V)][nlayers][R][max_len][d] each
   int *tok, *unfinished;
   unsigned char* mask;
@@ -305,6 +474,7 @@ Ws carve(const ac_trm_weights* w, int R, int max_len, float* base) {
   size_t off = 0;
   auto take = [&](size_t n) { float* p = base ? base + off : nullptr; off += align4(n); return p; };
   s.x = take(R * d);
+  s.x2 = take(R * d);
   s.qkv = take(R * 3 * d);
   s.att = take(R * d);
   s.tmp = take(R * d);
@@ -341,23 +511,41 @@ int launch_ln(const float* x, const float* y, const float* w, const float* b, fl
 }
 
 // One decoder position for R rows.  tokens/mask: [R][tok_stride]; the input token is column t.
-// cache: active KV cache set.  The last layer's output goes to xout (row stride ldxo).
+// cache: active KV cache set.  Returns through `fin` the operands of the LAST residual join
+// (embed = LayerNorm(fin.x + fin.y) with the last layer's norm3), which the caller fuses into the
+// classifier projection; 8 launches per layer: the residual joins and the embedding never run alone.
+struct StepOut {
+  const float* x;
+  const float* y;
+  const float* ln_w;
+  const float* ln_b;
+};
+
 int decoder_step(const ac_trm_weights* w, const float* memkv, const int* mem_len, int R, int row_div, int Tm,
                  int max_len, int t, const int* tok, const unsigned char* mask, long tok_stride, float* cache,
-                 const Ws& ws, float* xout, long ldxo, hipStream_t s) {
+                 const Ws& ws, StepOut* fin, hipStream_t s) {
   const int d = w->d_model, hd = d / w->nhead;
   const float scale = 1.0f / sqrtf((float)hd);
-  void* st = (void*)s;
-  if (t >= w->max_pos) return AC_ERR_ARG;
-  hipLaunchKernelGGL(embed_pe_kernel, dim3(R), dim3(256), 0, s, tok, tok_stride, t, w->emb, w->pe,
-                     sqrtf((float)d), ws.x, d);
-  AC_TRY(ac_check_launch());
+  if (t >= w->max_pos || d > DEC_MAX_D || d % 64) return AC_ERR_ARG;
   const size_t Rm = (size_t)(R / row_div) * Tm;  // memory rows
+  float* xa = ws.x;    // residual stream, ping-pong: a join reads one and writes the other
+  float* xb = ws.x2;
+  DecGemmParams g;
+  g.tok = tok; g.tok_stride = tok_stride; g.t = t; g.emb = w->emb; g.pe = w->pe; g.emb_scale = sqrtf((float)d);
+  g.M = R;
+  // pending join carried into the next projection: x_next = LayerNorm(jx + jy) * jw + jb
+  const float *jx = nullptr, *jy = nullptr, *jw = nullptr, *jb = nullptr;
   for (int l = 0; l < w->nlayers; ++l) {
     const ac_trm_layer& L = w->layer[l];
-    const bool last = l == w->nlayers - 1;
-    // ---- self attention over the cached prefix ----
-    AC_TRY(ac_linear(ws.x, L.sa_in_w, L.sa_in_b, ws.qkv, R, 3 * d, d, d, d, 3 * d, 0, st));
+    // ---- self attention: QKV projection with the layer input produced in its prologue ----
+    g.W = L.sa_in_w; g.ldw = d; g.bias = L.sa_in_b; g.Y = ws.qkv; g.ldy = 3 * d; g.N = 3 * d; g.K = d; g.relu = 0;
+    g.xout = xa; g.ldxo = d;
+    if (l == 0) {
+      AC_TRY(launch_dec_gemm<PRO_EMBED>(g, s));
+    } else {
+      g.X = jx; g.ldx = d; g.Y2 = jy; g.ldy2 = d; g.ln_w = jw; g.ln_b = jb;
+      AC_TRY(launch_dec_gemm<PRO_ADDLN>(g, s));
+    }
     AttnParams a;
     float* Kc = cache + (size_t)(2 * l) * ws.cache_set_stride;
     float* Vc = cache + (size_t)(2 * l + 1) * ws.cache_set_stride;
@@ -369,10 +557,14 @@ int decoder_step(const ac_trm_weights* w, const float* memkv, const int* mem_len
     a.out = ws.att; a.ldo = d; a.hd = hd; a.scale = scale;
     hipLaunchKernelGGL(attn_step_kernel, dim3(R, w->nhead), dim3(64), 0, s, a);
     AC_TRY(ac_check_launch());
-    AC_TRY(ac_linear(ws.att, L.sa_out_w, L.sa_out_b, ws.tmp, R, d, d, d, d, d, 0, st));
-    AC_TRY(launch_ln(ws.x, ws.tmp, L.n1_w, L.n1_b, ws.x, R, d, d, d, d, s));
-    // ---- cross attention over the audio memory ----
-    AC_TRY(ac_linear(ws.x, L.ca_in_w, L.ca_in_b, ws.q2, R, d, d, d, d, d, 0, st));
+    g.X = ws.att; g.ldx = d; g.W = L.sa_out_w; g.ldw = d; g.bias = L.sa_out_b; g.Y = ws.tmp; g.ldy = d;
+    g.N = d; g.K = d; g.relu = 0; g.xout = nullptr;
+    AC_TRY(launch_dec_gemm<PRO_PLAIN>(g, s));
+    // ---- cross attention: query projection of x1 = LN1(x + self_attn) ----
+    g.X = xa; g.ldx = d; g.Y2 = ws.tmp; g.ldy2 = d; g.ln_w = L.n1_w; g.ln_b = L.n1_b;
+    g.W = L.ca_in_w; g.ldw = d; g.bias = L.ca_in_b; g.Y = ws.q2; g.ldy = d; g.N = d; g.K = d; g.relu = 0;
+    g.xout = xb; g.ldxo = d;
+    AC_TRY(launch_dec_gemm<PRO_ADDLN>(g, s));
     const float* mk = memkv + (size_t)l * Rm * 2 * d;
     a.q = ws.q2; a.ldq = d;
     a.K = mk; a.V = mk + d; a.Kw = nullptr; a.Vw = nullptr;
@@ -381,17 +573,34 @@ int decoder_step(const ac_trm_weights* w, const float* memkv, const int* mem_len
     a.new_k = nullptr; a.new_v = nullptr; a.ld_new = 0;
     hipLaunchKernelGGL(attn_step_kernel, dim3(R, w->nhead), dim3(64), 0, s, a);
     AC_TRY(ac_check_launch());
-    AC_TRY(ac_linear(ws.att, L.ca_out_w, L.ca_out_b, ws.tmp, R, d, d, d, d, d, 0, st));
-    AC_TRY(launch_ln(ws.x, ws.tmp, L.n2_w, L.n2_b, ws.x, R, d, d, d, d, s));
-    // ---- feed forward ----
-    AC_TRY(ac_linear(ws.x, L.l1_w, L.l1_b, ws.ff, R, w->dim_ff, d, d, d, w->dim_ff, 1, st));
-    AC_TRY(ac_linear(ws.ff, L.l2_w, L.l2_b, ws.tmp, R, d, w->dim_ff, w->dim_ff, w->dim_ff, d, 0, st));
-    if (last)
-      AC_TRY(launch_ln(ws.x, ws.tmp, L.n3_w, L.n3_b, xout, R, d, d, d, ldxo, s));
-    else
-      AC_TRY(launch_ln(ws.x, ws.tmp, L.n3_w, L.n3_b, ws.x, R, d, d, d, d, s));
+    g.X = ws.att; g.ldx = d; g.W = L.ca_out_w; g.ldw = d; g.bias = L.ca_out_b; g.Y = ws.tmp; g.ldy = d;
+    g.N = d; g.K = d; g.relu = 0; g.xout = nullptr;
+    AC_TRY(launch_dec_gemm<PRO_PLAIN>(g, s));
+    // ---- feed forward on x2 = LN2(x1 + cross_attn) ----
+    g.X = xb; g.ldx = d; g.Y2 = ws.tmp; g.ldy2 = d; g.ln_w = L.n2_w; g.ln_b = L.n2_b;
+    g.W = L.l1_w; g.ldw = d; g.bias = L.l1_b; g.Y = ws.ff; g.ldy = w->dim_ff; g.N = w->dim_ff; g.K = d; g.relu = 1;
+    g.xout = xa; g.ldxo = d;
+    AC_TRY(launch_dec_gemm<PRO_ADDLN>(g, s));
+    g.X = ws.ff; g.ldx = w->dim_ff; g.W = L.l2_w; g.ldw = w->dim_ff; g.bias = L.l2_b; g.Y = ws.tmp; g.ldy = d;
+    g.N = d; g.K = w->dim_ff; g.relu = 0; g.xout = nullptr;
+    AC_TRY(launch_dec_gemm<PRO_PLAIN>(g, s));
+    // x3 = LN3(x2 + ff) is produced by the next consumer (next layer's QKV or the caller's projection)
+    jx = xa; jy = ws.tmp; jw = L.n3_w; jb = L.n3_b;
+    float* tswap = xa; xa = xb; xb = tswap;  // next layer writes its input into the other buffer
   }
+  fin->x = jx; fin->y = jy; fin->ln_w = jw; fin->ln_b = jb;
   return AC_OK;
+}
+
+// logits[R, V] = LayerNorm(fin.x + fin.y) W_cls^T, the normalised rows also stored to xout (= `embed`)
+int classifier_step(const ac_trm_weights* w, const StepOut& fin, int R, float* xout, long ldxo, float* logit,
+                    long ldl, hipStream_t s) {
+  DecGemmParams g;
+  g.tok = nullptr; g.tok_stride = 0; g.t = 0; g.emb = nullptr; g.pe = nullptr; g.emb_scale = 0.f;
+  g.M = R; g.N = w->vocab; g.K = w->d_model; g.relu = 0;
+  g.X = fin.x; g.ldx = w->d_model; g.Y2 = fin.y; g.ldy2 = w->d_model; g.ln_w = fin.ln_w; g.ln_b = fin.ln_b;
+  g.W = w->cls_w; g.ldw = w->d_model; g.bias = nullptr; g.Y = logit; g.ldy = ldl; g.xout = xout; g.ldxo = ldxo;
+  return launch_dec_gemm<PRO_ADDLN>(g, s);
 }
 
 }  // namespace
@@ -442,11 +651,11 @@ extern "C" int ac_trm_greedy(const ac_trm_weights* w, const float* memkv, const 
                      ws.mask, ws.unfinished, unfinished_cnt, B, max_len, start_idx, end_idx, pad_idx);
   AC_TRY(ac_check_launch());
   for (int t = 0; t < max_len; ++t) {
-    float* xout = embed + (size_t)t * d;
+    StepOut fin;
     AC_TRY(decoder_step(w, memkv, mem_len, B, 1, Tm, max_len, t, ws.tok, ws.mask, max_len + 1, ws.cache[0], ws,
-                        xout, (long)max_len * d, s));
-    AC_TRY(ac_linear(xout, w->cls_w, nullptr, logit + (size_t)t * V, B, V, d, (long)max_len * d, d,
-                     (long)max_len * V, 0, stream));
+                        &fin, s));
+    AC_TRY(classifier_step(w, fin, B, embed + (size_t)t * d, (long)max_len * d, logit + (size_t)t * V,
+                           (long)max_len * V, s));
     PickParams p;
     p.logit = logit + (size_t)t * V; p.ldl = (long)max_len * V;
     p.V = V; p.t = t; p.max_len = max_len; p.end_idx = end_idx; p.pad_idx = pad_idx;
@@ -467,10 +676,12 @@ extern "C" int ac_trm_forward_tokens(const ac_trm_weights* w, const float* memkv
   hipStream_t s = (hipStream_t)stream;
   const Ws ws = carve(w, N, T, ws_base);
   const int d = w->d_model, V = w->vocab;
-  for (int t = 0; t < T; ++t)
-    AC_TRY(decoder_step(w, memkv, mem_len, N, 1, Tm, T, t, tokens, key_mask, T, ws.cache[0], ws,
-                        embed + (size_t)t * d, (long)T * d, s));
-  return ac_linear(embed, w->cls_w, nullptr, logit, N * T, V, d, d, d, V, 0, stream);
+  for (int t = 0; t < T; ++t) {
+    StepOut fin;
+    AC_TRY(decoder_step(w, memkv, mem_len, N, 1, Tm, T, t, tokens, key_mask, T, ws.cache[0], ws, &fin, s));
+    AC_TRY(classifier_step(w, fin, N, embed + (size_t)t * d, (long)T * d, logit + (size_t)t * V, (long)T * V, s));
+  }
+  return AC_OK;
 }
 
 extern "C" int ac_trm_beam_step(const ac_trm_weights* w, const float* memkv, const int* mem_len, int B, int beam,
@@ -484,9 +695,10 @@ extern "C" int ac_trm_beam_step(const ac_trm_weights* w, const float* memkv, con
   hipStream_t s = (hipStream_t)stream;
   const int R = B * beam, d = w->d_model, V = w->vocab;
   const Ws ws = carve(w, R, max_len, ws_base);
+  StepOut fin;
   AC_TRY(decoder_step(w, memkv, mem_len, R, beam, Tm, max_len, t, tokens, key_mask, max_len + 1,
-                      ws.cache[t & 1], ws, ws.x, d, s));
-  AC_TRY(ac_linear(ws.x, w->cls_w, nullptr, ws.lg, R, V, d, d, d, V, 0, stream));
+                      ws.cache[t & 1], ws, &fin, s));
+  AC_TRY(classifier_step(w, fin, R, nullptr, 0, ws.lg, V, s));
   // lp is written over the qkv/ff scratch?  No: it needs R*V floats, reuse a second logits-sized area.
   float* lp = ws.lg;  // in place: every element is read before it is written by the same thread
   hipLaunchKernelGGL(beam_logprob_kernel, dim3(R), dim3(256), 0, s, ws.lg, cum_logprob, temp, lp, V);
