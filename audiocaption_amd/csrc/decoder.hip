@@ -180,99 +180,121 @@ struct DecGemmParams {
   int M, N, K, relu;
 };
 
+constexpr int DEC_WAVES = 8;  // waves per block: they split K (and the 32 producer rows)
+
 template <int PRO>
-__global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmParams p) {
+__global__ __launch_bounds__(64 * DEC_WAVES) void dec_gemm_kernel(DecGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];
-  float* red = dsm;                    // [4][32*33]
-  float* sX = dsm + 4 * 32 * 33;       // [32][K + 4] (fused producers only)
+  float* sX = dsm;   // [32][K + 4] A tile of the fused producers
+  float* red = dsm;  // [DEC_WAVES][32*33] split-K partials (re-uses the A tile after a barrier)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5;
   const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
   const int ldsx = p.K + 4;
+  const int kw = p.K / DEC_WAVES;  // K % 64 == 0 => kw % 8 == 0
+  const int gm_l = m0 + (lane & 31), gn_l = n0 + (lane & 31);
+  const bool mv = gm_l < p.M, nv_ = gn_l < p.N;
+  const float* wb = p.W + (size_t)(nv_ ? gn_l : 0) * p.ldw + wave * kw + half * 4;
+  // the weight fragments of the first K batch do not depend on the producer: request them first so their
+  // latency overlaps the residual/LayerNorm prologue
+  f32x4 b0[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) b0[u] = *(const f32x4*)(wb + (8 * u < kw ? 8 * u : 0));
   if (PRO != PRO_PLAIN) {
-    // 8 rows per wave; a row is K = d_model <= 512 floats = up to 8 per lane
-    for (int rr = 0; rr < 8; ++rr) {
-      const int row = wave * 8 + rr, r = m0 + row;
-      float v[DEC_MAX_D / 64];
-      const int nv = p.K >> 6;
-      if (r < p.M) {
-        if (PRO == PRO_EMBED) {
-          const int w = p.tok[(size_t)r * p.tok_stride + p.t];
+    constexpr int RPW = 32 / DEC_WAVES;   // rows per wave
+    constexpr int NV = DEC_MAX_D / 64;    // a row is K = d_model <= 512 floats = up to 8 per lane
+    const int nv = p.K >> 6;
+    float v[RPW][NV];
+    // every load of the wave's rows is issued before anything is reduced (no serial latency chain)
 #pragma unroll
-          for (int i = 0; i < DEC_MAX_D / 64; ++i)
-            if (i < nv) v[i] = p.emb[(size_t)w * p.K + lane + 64 * i] * p.emb_scale + p.pe[(size_t)p.t * p.K + lane + 64 * i];
-        } else {
-          float s = 0.f;
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int r = m0 + wave * RPW + rr;
+      const bool ok = r < p.M;
+      if (PRO == PRO_EMBED) {
+        const int w = ok ? p.tok[(size_t)r * p.tok_stride + p.t] : 0;
 #pragma unroll
-          for (int i = 0; i < DEC_MAX_D / 64; ++i)
-            if (i < nv) {
-              v[i] = p.X[(size_t)r * p.ldx + lane + 64 * i] + p.Y2[(size_t)r * p.ldy2 + lane + 64 * i];
-              s += v[i];
-            }
-          const float mean = wave_sum(s) / (float)p.K;
-          float q = 0.f;
-#pragma unroll
-          for (int i = 0; i < DEC_MAX_D / 64; ++i)
-            if (i < nv) { const float dl = v[i] - mean; q = fmaf(dl, dl, q); }
-          const float rstd = rsqrtf(wave_sum(q) / (float)p.K + 1e-5f);
-#pragma unroll
-          for (int i = 0; i < DEC_MAX_D / 64; ++i)
-            if (i < nv) v[i] = (v[i] - mean) * rstd * p.ln_w[lane + 64 * i] + p.ln_b[lane + 64 * i];
-        }
+        for (int i = 0; i < NV; ++i)
+          v[rr][i] = (ok && i < nv) ? p.emb[(size_t)w * p.K + lane + 64 * i] * p.emb_scale +
+                                          p.pe[(size_t)p.t * p.K + lane + 64 * i]
+                                    : 0.f;
       } else {
 #pragma unroll
-        for (int i = 0; i < DEC_MAX_D / 64; ++i) v[i] = 0.f;
+        for (int i = 0; i < NV; ++i)
+          v[rr][i] = (ok && i < nv) ? p.X[(size_t)r * p.ldx + lane + 64 * i] + p.Y2[(size_t)r * p.ldy2 + lane + 64 * i]
+                                    : 0.f;
+      }
+    }
+    if (PRO == PRO_ADDLN) {
+      float g[NV], b[NV];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        g[i] = i < nv ? p.ln_w[lane + 64 * i] : 0.f;
+        b[i] = i < nv ? p.ln_b[lane + 64 * i] : 0.f;
       }
 #pragma unroll
-      for (int i = 0; i < DEC_MAX_D / 64; ++i)
+      for (int rr = 0; rr < RPW; ++rr) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s += v[rr][i];
+        const float mean = wave_sum(s) / (float)p.K;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+          if (i < nv) { const float dl = v[rr][i] - mean; q = fmaf(dl, dl, q); }
+        const float rstd = rsqrtf(wave_sum(q) / (float)p.K + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[rr][i] = (v[rr][i] - mean) * rstd * g[i] + b[i];
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int row = wave * RPW + rr, r = m0 + row;
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
         if (i < nv) {
-          sX[row * ldsx + lane + 64 * i] = v[i];
-          if (blockIdx.x == 0 && p.xout && r < p.M) p.xout[(size_t)r * p.ldxo + lane + 64 * i] = v[i];
+          sX[row * ldsx + lane + 64 * i] = (r < p.M) ? v[rr][i] : 0.f;
+          if (blockIdx.x == 0 && p.xout && r < p.M) p.xout[(size_t)r * p.ldxo + lane + 64 * i] = v[rr][i];
         }
     }
     __syncthreads();
   }
-  const int kw = p.K >> 2;
-  const int gm_l = m0 + (lane & 31), gn_l = n0 + (lane & 31);
-  const bool mv = gm_l < p.M, nv_ = gn_l < p.N;
   const float* xa = (PRO == PRO_PLAIN) ? p.X + (size_t)(mv ? gm_l : 0) * p.ldx + wave * kw + half * 4
                                        : sX + (lane & 31) * ldsx + wave * kw + half * 4;
-  const float* wb = p.W + (size_t)(nv_ ? gn_l : 0) * p.ldw + wave * kw + half * 4;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (int k0 = 0; k0 < kw; k0 += 64) {  // up to 8 steps of 8: all loads of the batch issued before the MFMAs
+  for (int k0 = 0; k0 < kw; k0 += 64) {  // batches of up to 8 steps of 8: all loads issued before the MFMAs
     f32x4 a[8], b[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int k = k0 + 8 * u;
-      if (k < kw) {
-        a[u] = *(const f32x4*)(xa + k);
-        b[u] = *(const f32x4*)(wb + k);
-      }
+      const bool in = k < kw;
+      a[u] = *(const f32x4*)(xa + (in ? k : 0));
+      b[u] = (k0 == 0) ? b0[u] : *(const f32x4*)(wb + (in ? k : 0));
+      if (!in || (PRO == PRO_PLAIN && !mv)) a[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (!nv_) b[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int k = k0 + 8 * u;
-      if (k < kw) {
-        f32x4 av = a[u], bv = b[u];
-        if (PRO == PRO_PLAIN && !mv) av = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (!nv_) bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (k0 + 8 * u < kw) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc = mfma32(av[s], bv[s], acc);
+        for (int s = 0; s < 4; ++s) acc = mfma32(a[u][s], b[u][s], acc);
       }
     }
   }
+  if (PRO != PRO_PLAIN) __syncthreads();  // the A tile is dead: its LDS becomes the reduction buffer
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[wave * (32 * 33) + ((r & 3) + 8 * (r >> 2) + 4 * half) * 33 + (lane & 31)] = acc[r];
   __syncthreads();
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int e = tid + u * 256, i = e >> 5, jn = e & 31;
+  for (int u = 0; u < 1024 / (64 * DEC_WAVES); ++u) {
+    const int e = tid + u * 64 * DEC_WAVES, i = e >> 5, jn = e & 31;
     const int gm = m0 + i, gn = n0 + jn;
     if (gm < p.M && gn < p.N) {
       const int o = i * 33 + jn;
-      float y = (red[o] + red[32 * 33 + o]) + (red[2 * 32 * 33 + o] + red[3 * 32 * 33 + o]);
+      float y = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < DEC_WAVES; ++w2) y += red[w2 * (32 * 33) + o];
       if (p.bias) y += p.bias[gn];
       if (p.relu) y = fmaxf(y, 0.f);
       p.Y[(size_t)gm * p.ldy + gn] = y;
@@ -282,15 +304,17 @@ __global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmParams p) {
 
 template <int PRO>
 int launch_dec_gemm(const DecGemmParams& p, hipStream_t s) {
-  if (p.K % 32 || (PRO != PRO_PLAIN && (p.K > DEC_MAX_D || p.K % 64))) return AC_ERR_ARG;
-  const size_t lds = (4 * 32 * 33 + (PRO != PRO_PLAIN ? 32 * (p.K + 4) : 0)) * sizeof(float);
+  if (p.K % 64 || (PRO != PRO_PLAIN && p.K > DEC_MAX_D)) return AC_ERR_ARG;
+  size_t lds = (size_t)DEC_WAVES * 32 * 33;
+  if (PRO != PRO_PLAIN && (size_t)32 * (p.K + 4) > lds) lds = (size_t)32 * (p.K + 4);
+  lds *= sizeof(float);
   dim3 grid((p.N + 31) / 32, (p.M + 31) / 32);
   if (lds > 64 * 1024) {  // d_model 512: opt in to a larger dynamic LDS window
     if (hipFuncSetAttribute((const void*)dec_gemm_kernel<PRO>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
       return AC_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL((dec_gemm_kernel<PRO>), grid, dim3(256), lds, s, p);
+  hipLaunchKernelGGL((dec_gemm_kernel<PRO>), grid, dim3(64 * DEC_WAVES), lds, s, p);
   return ac_check_launch();
 }
 

@@ -10,6 +10,7 @@ decoder step against a self-attention KV cache.
 """
 import ctypes
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -75,6 +76,7 @@ class TransformerDecoder(BaseDecoder):
         self._w_key = None
         self._w_keep = None
         self._ws = {}
+        self._greedy_state = None
 
     def load_pretrained(self, pretrained, output_fn=print):
         """Reference transformer_decoder.py:56-72: take the ``decoder.*`` entries of a model checkpoint."""
@@ -91,10 +93,12 @@ class TransformerDecoder(BaseDecoder):
                 param.requires_grad = name not in loaded
 
     # ------------------------------------------------------------------------------------------
+    def _weights_key(self):
+        return tuple((t.data_ptr(), t._version, t.dtype) for t in self.parameters())
+
     def weights(self):
         """ac_trm_weights struct of device pointers (rebuilt when a parameter changes)."""
-        params = list(self.parameters())
-        key = tuple((t.data_ptr(), t._version, t.dtype) for t in params)
+        key = self._weights_key()
         if self._w is not None and key == self._w_key:
             return self._w
         keep = []
@@ -169,23 +173,60 @@ class TransformerDecoder(BaseDecoder):
               "ac_trm_forward_tokens")
         return {"embed": embed, "logit": logit}
 
-    def greedy(self, attn_emb, attn_emb_len, max_length, start_idx, end_idx, pad_idx):
-        """On-device greedy search.  Returns device tensors seq (int64), logit, logprob, embed, cnt."""
+    def _greedy_launch(self, st, max_length, start_idx, end_idx, pad_idx):
+        """Memory preparation + the whole on-device greedy loop on the current stream (capturable)."""
         lib = _lib.load()
+        B, Tm, _ = st["attn_emb"].shape
+        w = ctypes.byref(self.weights())
+        check(lib.ac_trm_memory(w, ptr(st["attn_emb"]), B, Tm, ptr(st["memkv"]), ptr(st["tmp"]), stream()),
+              "ac_trm_memory")
+        check(lib.ac_trm_greedy(w, ptr(st["memkv"]), ptr(st["mem_len"]), B, Tm, max_length, start_idx, end_idx,
+                                pad_idx, ptr(st["seq"]), ptr(st["logit"]), ptr(st["sampled_logprob"]),
+                                ptr(st["embed"]), ptr(st["unfinished_cnt"]), ptr(st["ws"]), stream()),
+              "ac_trm_greedy")
+
+    def greedy(self, attn_emb, attn_emb_len, max_length, start_idx, end_idx, pad_idx):
+        """On-device greedy search.  Returns device tensors seq (int64), logit, logprob, embed, cnt.
+
+        The ~370 short launches of a decode are latency-bound, so the fixed launch sequence (memory
+        preparation + max_length decoder steps) is captured ONCE per shape into a HIP graph over static
+        buffers and replayed; inputs are copied in, outputs are cloned out (fresh tensors per call, as the
+        reference returns).  Set AUDIOCAPTION_DECODE_GRAPH=0 to launch eagerly."""
         dev = attn_emb.device
-        B, Tm, _ = attn_emb.shape
-        mem_len = torch.as_tensor(attn_emb_len).to(device=dev, dtype=torch.int32)
-        memkv = self.memory(attn_emb)
-        seq = torch.empty(B, max_length, device=dev, dtype=torch.int64)
-        logit = torch.empty(B, max_length, self.vocab_size, device=dev, dtype=torch.float32)
-        logprob = torch.empty(B, max_length, device=dev, dtype=torch.float32)
-        embed = torch.empty(B, max_length, self.d_model, device=dev, dtype=torch.float32)
-        cnt = torch.empty(max_length, device=dev, dtype=torch.int32)
-        ws = self.workspace(B, max_length, dev)
-        check(lib.ac_trm_greedy(ctypes.byref(self.weights()), ptr(memkv), ptr(mem_len), B, Tm, max_length,
-                                start_idx, end_idx, pad_idx, ptr(seq), ptr(logit), ptr(logprob), ptr(embed),
-                                ptr(cnt), ptr(ws), stream()), "ac_trm_greedy")
-        return {"seq": seq, "logit": logit, "sampled_logprob": logprob, "embed": embed, "unfinished_cnt": cnt}
+        B, Tm, A = attn_emb.shape
+        use_graph = os.environ.get("AUDIOCAPTION_DECODE_GRAPH", "1") != "0"
+        key = (dev, B, Tm, max_length, start_idx, end_idx, pad_idx, self._weights_key())
+        st = self._greedy_state if self._greedy_state is not None and self._greedy_state["key"] == key else None
+        if st is None:
+            f32 = dict(device=dev, dtype=torch.float32)
+            ws_n = _lib.load().ac_trm_workspace_floats(ctypes.byref(self.weights()), B, max_length)
+            st = {
+                "key": key, "graph": None,
+                "attn_emb": torch.empty(B, Tm, A, **f32), "mem_len": torch.empty(B, device=dev, dtype=torch.int32),
+                "memkv": torch.empty(self.nlayers, B * Tm, 2 * self.d_model, **f32),
+                "tmp": torch.empty(B * Tm, self.d_model, **f32), "ws": torch.empty(ws_n, **f32),
+                "seq": torch.empty(B, max_length, device=dev, dtype=torch.int64),
+                "logit": torch.empty(B, max_length, self.vocab_size, **f32),
+                "sampled_logprob": torch.empty(B, max_length, **f32),
+                "embed": torch.empty(B, max_length, self.d_model, **f32),
+                "unfinished_cnt": torch.empty(max_length, device=dev, dtype=torch.int32),
+            }
+            self._greedy_state = st
+        st["attn_emb"].copy_(attn_emb)
+        st["mem_len"].copy_(torch.as_tensor(attn_emb_len).to(device=dev, dtype=torch.int32))
+        if not use_graph:
+            self._greedy_launch(st, max_length, start_idx, end_idx, pad_idx)
+        else:
+            if st["graph"] is None:
+                # warm-up launch outside capture (module load, LDS attribute calls), then capture
+                self._greedy_launch(st, max_length, start_idx, end_idx, pad_idx)
+                torch.cuda.synchronize(dev)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self._greedy_launch(st, max_length, start_idx, end_idx, pad_idx)
+                st["graph"] = graph
+            st["graph"].replay()
+        return {k: st[k].clone() for k in ("seq", "logit", "sampled_logprob", "embed", "unfinished_cnt")}
 
     def beam_step(self, memkv, mem_len, B, beam, Tm, max_length, t, temp, tokens, mask, cum, ws):
         lib = _lib.load()
