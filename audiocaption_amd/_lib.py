@@ -26,7 +26,7 @@ class AcTrmLayer(ctypes.Structure):
 class AcTrmWeights(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "d_model", "nhead", "nlayers", "dim_ff", "vocab", "max_pos", "attn_emb_dim", "reserved")] + [
-        (n, ctypes.c_void_p) for n in ("emb", "pe", "cls_w", "proj_w", "proj_b", "proj_ln_w", "proj_ln_b")] + [
+        (n, ctypes.c_void_p) for n in ("emb", "pe", "cls_w", "proj_w", "proj_b", "proj_ln_w", "proj_ln_b", "step_pk")] + [
         ("layer", AcTrmLayer * AC_MAX_LAYERS)]
 
 
@@ -45,6 +45,8 @@ SIGNATURES = {
     "ac_mean_with_lens": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "ac_add_layernorm": (_I, [_P, _P, _P, _P, _P, _I, _I, _L, _L, _L, _P]),
     "ac_trm_memory": (_I, [_WP, _P, _I, _I, _P, _P, _P]),
+    "ac_trm_step_pack_floats": (_L, [_WP]),
+    "ac_trm_pack_step_weights": (_I, [_WP, _P, _P]),
     "ac_trm_workspace_floats": (_L, [_WP, _I, _I]),
     "ac_trm_greedy": (_I, [_WP, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "ac_trm_forward_tokens": (_I, [_WP, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P]),

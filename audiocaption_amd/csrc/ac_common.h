@@ -21,16 +21,42 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// 64-lane reductions on the DPP cross-lane network (quad permutes, row mirrors) plus four scalar lane
+// reads: ~10x cheaper than a ds_bpermute butterfly, which goes through the LDS crossbar at every step.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+constexpr int DPP_QUAD_XOR1 = 0xB1;   // quad_perm [1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;   // quad_perm [2,3,0,1]
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;
+constexpr int DPP_ROW_MIRROR = 0x140;
+
+// sum / max over each 16-lane row, result in every lane of the row
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<DPP_QUAD_XOR1>(v);
+  v += dpp_mov<DPP_QUAD_XOR2>(v);
+  v += dpp_mov<DPP_ROW_HALF_MIRROR>(v);
+  v += dpp_mov<DPP_ROW_MIRROR>(v);
   return v;
 }
-
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_mov<DPP_QUAD_XOR1>(v));
+  v = fmaxf(v, dpp_mov<DPP_QUAD_XOR2>(v));
+  v = fmaxf(v, dpp_mov<DPP_ROW_HALF_MIRROR>(v));
+  v = fmaxf(v, dpp_mov<DPP_ROW_MIRROR>(v));
   return v;
+}
+__device__ __forceinline__ float lane_read(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row16_sum(v);
+  return (lane_read(v, 0) + lane_read(v, 16)) + (lane_read(v, 32) + lane_read(v, 48));
+}
+__device__ __forceinline__ float wave_max(float v) {
+  v = row16_max(v);
+  return fmaxf(fmaxf(lane_read(v, 0), lane_read(v, 16)), fmaxf(lane_read(v, 32), lane_read(v, 48)));
 }
 
 static inline int ac_check_launch() {

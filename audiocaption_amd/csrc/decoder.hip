@@ -101,22 +101,25 @@ __global__ __launch_bounds__(64) void attn_step_kernel(AttnParams p) {
   const float* Kb = p.K + (size_t)kr * p.row_stride + hoff;
   const float* Vb = p.V + (size_t)kr * p.row_stride + hoff;
   const int klen = p.key_len ? p.key_len[kr] : p.nkeys;
-  // scores: lane j owns key j (independent 16-byte loads of its whole K row: no serial latency chain)
+  if (lane < 32 && lane >= p.nkeys) sc[lane] = 0.f;  // the unrolled value loop reads sc[0..31]
+  // scores: a wave-instruction covers FOUR keys (16 lanes x 16 bytes = one 256-byte K row each), so a
+  // fragment costs 8 cache-line requests; the 4-element partial dots are reduced over the 16-lane groups
   if (p.hd == 64) {
-    f32x4 q[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) q[i] = *(const f32x4*)(qp + 4 * i);
-    for (int j = lane; j < p.nkeys; j += 64) {
-      const float* kp = Kb + (size_t)j * p.key_stride;
-      f32x4 kv[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) kv[i] = *(const f32x4*)(kp + 4 * i);
+    const int ks = lane >> 4, d4 = lane & 15;
+    const f32x4 q4 = *(const f32x4*)(qp + 4 * d4);
+#pragma unroll 4
+    for (int j0 = 0; j0 < p.nkeys; j0 += 4) {
+      const int j = j0 + ks;
       float s = 0.f;
-#pragma unroll
-      for (int i = 0; i < 16; ++i)
-        s += (q[i][0] * kv[i][0] + q[i][1] * kv[i][1]) + (q[i][2] * kv[i][2] + q[i][3] * kv[i][3]);
-      const bool masked = (j >= klen) || (p.key_mask && p.key_mask[(size_t)r * p.mask_stride + j]);
-      sc[j] = masked ? -INFINITY : s * p.scale;
+      if (j < p.nkeys) {
+        const f32x4 kv = *(const f32x4*)(Kb + (size_t)j * p.key_stride + 4 * d4);
+        s = (q4[0] * kv[0] + q4[1] * kv[1]) + (q4[2] * kv[2] + q4[3] * kv[3]);
+      }
+      s = row16_sum(s);
+      if (d4 == 0 && j < p.nkeys) {
+        const bool masked = (j >= klen) || (p.key_mask && p.key_mask[(size_t)r * p.mask_stride + j]);
+        sc[j] = masked ? -INFINITY : s * p.scale;
+      }
     }
   } else {
     for (int j = lane; j < p.nkeys; j += 64) {
@@ -127,6 +130,12 @@ __global__ __launch_bounds__(64) void attn_step_kernel(AttnParams p) {
       sc[j] = masked ? -INFINITY : s * p.scale;
     }
   }
+  // the value rows do not depend on the softmax: request them now (coalesced, one row per instruction) so
+  // their latency overlaps the score reductions
+  constexpr int VPRE = 32;
+  float vpre[VPRE];
+#pragma unroll
+  for (int j = 0; j < VPRE; ++j) vpre[j] = (act && j < p.nkeys) ? Vb[(size_t)j * p.key_stride + lane] : 0.f;
   __syncthreads();
   float m = -INFINITY;
   for (int j = lane; j < p.nkeys; j += 64) m = fmaxf(m, sc[j]);
@@ -140,18 +149,16 @@ __global__ __launch_bounds__(64) void attn_step_kernel(AttnParams p) {
   den = wave_sum(den);
   __syncthreads();
   if (act) {
-    // lane d owns output channel d; the value rows are coalesced and independent of each other
+    // lane d owns output channel d
     float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
-    int j = 0;
-    for (; j + 4 <= p.nkeys; j += 4) {
-      const float v0 = Vb[(size_t)(j + 0) * p.key_stride + lane], v1 = Vb[(size_t)(j + 1) * p.key_stride + lane];
-      const float v2 = Vb[(size_t)(j + 2) * p.key_stride + lane], v3 = Vb[(size_t)(j + 3) * p.key_stride + lane];
-      o0 = fmaf(sc[j], v0, o0);
-      o1 = fmaf(sc[j + 1], v1, o1);
-      o2 = fmaf(sc[j + 2], v2, o2);
-      o3 = fmaf(sc[j + 3], v3, o3);
+#pragma unroll
+    for (int j = 0; j < VPRE; j += 4) {
+      o0 = fmaf(sc[j], vpre[j], o0);  // sc[j] = 0 and vpre[j] = 0 beyond nkeys
+      o1 = fmaf(sc[j + 1], vpre[j + 1], o1);
+      o2 = fmaf(sc[j + 2], vpre[j + 2], o2);
+      o3 = fmaf(sc[j + 3], vpre[j + 3], o3);
     }
-    for (; j < p.nkeys; ++j) o0 = fmaf(sc[j], Vb[(size_t)j * p.key_stride + lane], o0);
+    for (int j = VPRE; j < p.nkeys; ++j) o0 = fmaf(sc[j], Vb[(size_t)j * p.key_stride + lane], o0);
     p.out[(size_t)r * p.ldo + hoff + lane] = ((o0 + o1) + (o2 + o3)) / den;
   }
 }
@@ -175,145 +182,203 @@ struct DecGemmParams {
   const int* tok; long tok_stride; int t;  // EMBED
   const float* emb; const float* pe; float emb_scale;
   float* xout; long ldxo;            // where column-tile-0 blocks store the produced A rows (may be null)
-  const float* W; long ldw; const float* bias;
+  const float* Wp; const float* bias;  // Wp: fragment-packed weights [ceil(N/16)][K/16][64][4]
   float* Y; long ldy;
   int M, N, K, relu;
+  int ntb;  // consecutive 16-column tiles per block (1 unless K fits one chunk)
 };
 
-constexpr int DEC_WAVES = 8;  // waves per block: they split K (and the 32 producer rows)
+#ifdef AC_DEC_STAMPS  // development probe only (tools/dec_probe.hip): phase timestamps of block (0,0), wave 0
+__device__ long long g_dec_stamps[16];
+#define DEC_STAMP(k) do { if (blockIdx.x == 1 && blockIdx.y == 0 && threadIdx.x == 0) g_dec_stamps[k] = clock64(); } while (0)
+#else
+#define DEC_STAMP(k) do { } while (0)
+#endif
+
+constexpr int DEC_WAVES = 4;   // waves per block: they split K (and the 16 producer rows)
+constexpr int DEC_KC = 512;    // K chunk staged in LDS at a time
+constexpr int DEC_T = 16;      // output tile: 16 rows x 16 columns (v_mfma_f32_16x16x4_f32)
+
+// A decode step is ~0.36 GFLOP spread over 18 dependent launches: what matters is how many CUs each
+// launch reaches and how few cache-line requests each block issues, not MFMA efficiency.  Hence small
+// 16 x 16 tiles (64 ... 1092 blocks per projection) and weights pre-packed in MFMA fragment order
+// (ac_trm_pack_step_weights):
+//   Wp[n_tile][k_group][lane][4],  16 columns x 16 k per group, lane = (n % 16) + 16 * ((k % 16) / 4),
+//   element = k % 4: a wave's B fragment is ONE contiguous 1 KiB read.
+__global__ void pack_frag_kernel(const float* W, long ldw, int N, int K, float* out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 of the packed matrix
+  const int kgs = K >> 4;
+  const size_t total = (size_t)((N + DEC_T - 1) / DEC_T) * kgs * 64;
+  if (i >= total) return;
+  const int lane = (int)(i & 63);
+  const size_t g = i >> 6;
+  const int kg = (int)(g % kgs), nt = (int)(g / kgs);
+  const int n = nt * DEC_T + (lane & 15), k = kg * 16 + (lane >> 4) * 4;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (n < N) v = *(const f32x4*)(W + (size_t)n * ldw + k);
+  *(f32x4*)(out + i * 4) = v;
+}
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  // lane l: A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15]; result reg r: D[(l >> 4) * 4 + r][l & 15]
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
 
 template <int PRO>
 __global__ __launch_bounds__(64 * DEC_WAVES) void dec_gemm_kernel(DecGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];
-  float* sX = dsm;   // [32][K + 4] A tile of the fused producers
-  float* red = dsm;  // [DEC_WAVES][32*33] split-K partials (re-uses the A tile after a barrier)
+  float* sX = dsm;   // [16][KC + 4] A tile: the fused producer's rows, or a coalesced copy of X
+  float* red = dsm + DEC_T * (DEC_KC + 4);  // [DEC_WAVES][16*17] split-K partials
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int half = lane >> 5;
-  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-  const int ldsx = p.K + 4;
-  const int kw = p.K / DEC_WAVES;  // K % 64 == 0 => kw % 8 == 0
-  const int gm_l = m0 + (lane & 31), gn_l = n0 + (lane & 31);
-  const bool mv = gm_l < p.M, nv_ = gn_l < p.N;
-  const float* wb = p.W + (size_t)(nv_ ? gn_l : 0) * p.ldw + wave * kw + half * 4;
-  // the weight fragments of the first K batch do not depend on the producer: request them first so their
-  // latency overlaps the residual/LayerNorm prologue
+  const int kq = lane >> 4;           // which 4 of the 16 k of a group this lane feeds
+  const int m0 = blockIdx.y * DEC_T;
+  const int nt0 = blockIdx.x * p.ntb;  // first of the ntb consecutive column tiles of this block
+  const int KC = p.K < DEC_KC ? p.K : DEC_KC;
+  const int ldsx = KC + 4;
+  const int kwc = KC / DEC_WAVES;     // k range of one wave inside a chunk (multiple of 16)
+  const int nsteps = kwc >> 4;        // MFMA groups of 16 k per wave per chunk (<= 8)
+  const size_t wtile = (size_t)(p.K >> 4) * 64;  // float4 per packed column tile
+  const f32x4* wp0 = (const f32x4*)p.Wp + (size_t)nt0 * wtile + (size_t)wave * nsteps * 64 + lane;
+  DEC_STAMP(0);
+  // the weight fragments of the first chunk do not depend on the producer: request them first
   f32x4 b0[8];
 #pragma unroll
-  for (int u = 0; u < 8; ++u) b0[u] = *(const f32x4*)(wb + (8 * u < kw ? 8 * u : 0));
+  for (int u = 0; u < 8; ++u) b0[u] = wp0[(size_t)(u < nsteps ? u : 0) * 64];
+
   if (PRO != PRO_PLAIN) {
-    constexpr int RPW = 32 / DEC_WAVES;   // rows per wave
-    constexpr int NV = DEC_MAX_D / 64;    // a row is K = d_model <= 512 floats = up to 8 per lane
-    const int nv = p.K >> 6;
-    float v[RPW][NV];
-    // every load of the wave's rows is issued before anything is reduced (no serial latency chain)
+    // Fused producer of the 16 A rows.  A wave owns 4 rows, ONE ROW PER 16-LANE GROUP: lane (g = lane >> 4,
+    // s = lane & 15) holds the row's float4 columns s, s + 16, ... so that loads are 16-byte, a group reads
+    // 256 contiguous bytes, and the LayerNorm reductions are 4 DPP steps inside the group (no cross-row
+    // traffic, all four rows of the wave advance together).
+    constexpr int NF = DEC_MAX_D / 64;  // float4 per lane: K = d_model <= 512 -> up to 8
+    const int nf = p.K >> 6;
+    const int grp = lane >> 4, sub = lane & 15;
+    const int row = wave * 4 + grp, r = m0 + row;
+    const bool ok = r < p.M;
+    f32x4 v[NF], gw[NF], gb[NF];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    if (PRO == PRO_EMBED) {
+      const int w = ok ? p.tok[(size_t)r * p.tok_stride + p.t] : 0;
+      const f32x4* e4 = (const f32x4*)(p.emb + (size_t)w * p.K);
+      const f32x4* p4 = (const f32x4*)(p.pe + (size_t)p.t * p.K);
 #pragma unroll
-    for (int rr = 0; rr < RPW; ++rr) {
-      const int r = m0 + wave * RPW + rr;
-      const bool ok = r < p.M;
-      if (PRO == PRO_EMBED) {
-        const int w = ok ? p.tok[(size_t)r * p.tok_stride + p.t] : 0;
+      for (int i = 0; i < NF; ++i)
+        v[i] = (ok && i < nf) ? e4[sub + 16 * i] * p.emb_scale + p4[sub + 16 * i] : zero4;
+    } else {
+      const f32x4* x4 = (const f32x4*)(p.X + (size_t)(ok ? r : 0) * p.ldx);
+      const f32x4* y4 = (const f32x4*)(p.Y2 + (size_t)(ok ? r : 0) * p.ldy2);
 #pragma unroll
-        for (int i = 0; i < NV; ++i)
-          v[rr][i] = (ok && i < nv) ? p.emb[(size_t)w * p.K + lane + 64 * i] * p.emb_scale +
-                                          p.pe[(size_t)p.t * p.K + lane + 64 * i]
-                                    : 0.f;
-      } else {
-#pragma unroll
-        for (int i = 0; i < NV; ++i)
-          v[rr][i] = (ok && i < nv) ? p.X[(size_t)r * p.ldx + lane + 64 * i] + p.Y2[(size_t)r * p.ldy2 + lane + 64 * i]
-                                    : 0.f;
+      for (int i = 0; i < NF; ++i) {
+        gw[i] = i < nf ? ((const f32x4*)p.ln_w)[sub + 16 * i] : zero4;
+        gb[i] = i < nf ? ((const f32x4*)p.ln_b)[sub + 16 * i] : zero4;
+        v[i] = (ok && i < nf) ? x4[sub + 16 * i] + y4[sub + 16 * i] : zero4;
       }
-    }
-    if (PRO == PRO_ADDLN) {
-      float g[NV], b[NV];
+      DEC_STAMP(1);
+      float sm = 0.f;
 #pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        g[i] = i < nv ? p.ln_w[lane + 64 * i] : 0.f;
-        b[i] = i < nv ? p.ln_b[lane + 64 * i] : 0.f;
-      }
+      for (int i = 0; i < NF; ++i) sm += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+      const float mean = row16_sum(sm) / (float)p.K;
+      float q = 0.f;
 #pragma unroll
-      for (int rr = 0; rr < RPW; ++rr) {
-        float s = 0.f;
+      for (int i = 0; i < NF; ++i)
+        if (i < nf) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) s += v[rr][i];
-        const float mean = wave_sum(s) / (float)p.K;
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < NV; ++i)
-          if (i < nv) { const float dl = v[rr][i] - mean; q = fmaf(dl, dl, q); }
-        const float rstd = rsqrtf(wave_sum(q) / (float)p.K + 1e-5f);
-#pragma unroll
-        for (int i = 0; i < NV; ++i) v[rr][i] = (v[rr][i] - mean) * rstd * g[i] + b[i];
-      }
-    }
-#pragma unroll
-    for (int rr = 0; rr < RPW; ++rr) {
-      const int row = wave * RPW + rr, r = m0 + row;
-#pragma unroll
-      for (int i = 0; i < NV; ++i)
-        if (i < nv) {
-          sX[row * ldsx + lane + 64 * i] = (r < p.M) ? v[rr][i] : 0.f;
-          if (blockIdx.x == 0 && p.xout && r < p.M) p.xout[(size_t)r * p.ldxo + lane + 64 * i] = v[rr][i];
+          for (int e = 0; e < 4; ++e) { const float dl = v[i][e] - mean; q = fmaf(dl, dl, q); }
         }
+      const float rstd = rsqrtf(row16_sum(q) / (float)p.K + 1e-5f);
+#pragma unroll
+      for (int i = 0; i < NF; ++i) v[i] = (v[i] - mean) * rstd * gw[i] + gb[i];
     }
-    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+      if (i < nf) {
+        *(f32x4*)(sX + row * ldsx + (sub + 16 * i) * 4) = ok ? v[i] : zero4;
+        if (blockIdx.x == 0 && p.xout && ok) *(f32x4*)(p.xout + (size_t)r * p.ldxo + (sub + 16 * i) * 4) = v[i];
+      }
   }
-  const float* xa = (PRO == PRO_PLAIN) ? p.X + (size_t)(mv ? gm_l : 0) * p.ldx + wave * kw + half * 4
-                                       : sX + (lane & 31) * ldsx + wave * kw + half * 4;
-  f32x16 acc;
+  DEC_STAMP(2);
+  const float* xa = sX + (lane & 15) * ldsx + wave * kwc + kq * 4;
+  // PRO_PLAIN: the X chunk is copied into the LDS tile with coalesced 16-byte loads (row = 4*KC bytes);
+  // chunk c+1 is requested into registers before the MFMAs of chunk c
+  constexpr int XLD = DEC_T * (DEC_KC / 4) / (64 * DEC_WAVES);  // float4 per thread per chunk (8)
+  const int c4n = KC >> 2;
+  f32x4 xr[XLD];
+  auto x_load = [&](int c0) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (int k0 = 0; k0 < kw; k0 += 64) {  // batches of up to 8 steps of 8: all loads issued before the MFMAs
-    f32x4 a[8], b[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int k = k0 + 8 * u;
-      const bool in = k < kw;
-      a[u] = *(const f32x4*)(xa + (in ? k : 0));
-      b[u] = (k0 == 0) ? b0[u] : *(const f32x4*)(wb + (in ? k : 0));
-      if (!in || (PRO == PRO_PLAIN && !mv)) a[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (!nv_) b[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < XLD; ++u) {
+      const int idx = tid + u * 64 * DEC_WAVES;
+      const int row = idx / (DEC_KC / 4), c4 = idx % (DEC_KC / 4);  // constants: shifts
+      const bool okr = c4 < c4n && m0 + row < p.M;
+      xr[u] = okr ? *(const f32x4*)(p.X + (size_t)(m0 + row) * p.ldx + c0 + c4 * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+  };
+  auto x_store = [&]() {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      if (k0 + 8 * u < kw) {
+    for (int u = 0; u < XLD; ++u) {
+      const int idx = tid + u * 64 * DEC_WAVES;
+      const int row = idx / (DEC_KC / 4), c4 = idx % (DEC_KC / 4);
+      if (c4 < c4n) *(f32x4*)(sX + row * ldsx + c4 * 4) = xr[u];
+    }
+  };
+  if (PRO == PRO_PLAIN) x_load(0);
+  // ntb consecutive column tiles re-use the A tile (single-chunk K only; the launcher enforces it)
+  for (int nt = 0; nt < p.ntb; ++nt) {
+    const int n0 = (nt0 + nt) * DEC_T;
+    if (n0 >= p.N) break;
+    const f32x4* wp = wp0 + (size_t)nt * wtile;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < p.K; c0 += KC) {
+      f32x4 b[8];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc = mfma32(a[u][s], b[u][s], acc);
+      for (int u = 0; u < 8; ++u)
+        b[u] = (c0 == 0 && nt == 0) ? b0[u] : wp[((size_t)(c0 >> 4) + (u < nsteps ? u : 0)) * 64];
+      if (PRO == PRO_PLAIN) {
+        if (c0 > 0) __syncthreads();
+        if (nt == 0) {
+          x_store();
+          if (c0 + KC < p.K) x_load(c0 + KC);
+        }
+      }
+      if (nt == 0) __syncthreads();
+      DEC_STAMP(3);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (u < nsteps) {
+          const f32x4 a = *(const f32x4*)(xa + 16 * u);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc = mfma16(a[s], b[u][s], acc);
+        }
+      }
+    }
+    DEC_STAMP(4);
+    if (nt > 0) __syncthreads();  // the previous tile's partials have been consumed
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave * (DEC_T * 17) + (kq * 4 + r) * 17 + (lane & 15)] = acc[r];
+    __syncthreads();
+    {
+      const int i = tid >> 4, jn = tid & 15;  // 256 threads = the 16 x 16 outputs
+      const int gm = m0 + i, gn = n0 + jn;
+      if (gm < p.M && gn < p.N) {
+        const int o = i * 17 + jn;
+        float y = (red[o] + red[DEC_T * 17 + o]) + (red[2 * DEC_T * 17 + o] + red[3 * DEC_T * 17 + o]);
+        if (p.bias) y += p.bias[gn];
+        if (p.relu) y = fmaxf(y, 0.f);
+        p.Y[(size_t)gm * p.ldy + gn] = y;
       }
     }
   }
-  if (PRO != PRO_PLAIN) __syncthreads();  // the A tile is dead: its LDS becomes the reduction buffer
-#pragma unroll
-  for (int r = 0; r < 16; ++r) red[wave * (32 * 33) + ((r & 3) + 8 * (r >> 2) + 4 * half) * 33 + (lane & 31)] = acc[r];
-  __syncthreads();
-#pragma unroll
-  for (int u = 0; u < 1024 / (64 * DEC_WAVES); ++u) {
-    const int e = tid + u * 64 * DEC_WAVES, i = e >> 5, jn = e & 31;
-    const int gm = m0 + i, gn = n0 + jn;
-    if (gm < p.M && gn < p.N) {
-      const int o = i * 33 + jn;
-      float y = 0.f;
-#pragma unroll
-      for (int w2 = 0; w2 < DEC_WAVES; ++w2) y += red[w2 * (32 * 33) + o];
-      if (p.bias) y += p.bias[gn];
-      if (p.relu) y = fmaxf(y, 0.f);
-      p.Y[(size_t)gm * p.ldy + gn] = y;
-    }
-  }
+  DEC_STAMP(5);
 }
 
 template <int PRO>
 int launch_dec_gemm(const DecGemmParams& p, hipStream_t s) {
-  if (p.K % 64 || (PRO != PRO_PLAIN && p.K > DEC_MAX_D)) return AC_ERR_ARG;
-  size_t lds = (size_t)DEC_WAVES * 32 * 33;
-  if (PRO != PRO_PLAIN && (size_t)32 * (p.K + 4) > lds) lds = (size_t)32 * (p.K + 4);
-  lds *= sizeof(float);
-  dim3 grid((p.N + 31) / 32, (p.M + 31) / 32);
-  if (lds > 64 * 1024) {  // d_model 512: opt in to a larger dynamic LDS window
-    if (hipFuncSetAttribute((const void*)dec_gemm_kernel<PRO>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
-      return AC_ERR_LAUNCH;
-  }
+  if (p.K % 64 || (PRO != PRO_PLAIN && p.K > DEC_MAX_D) || (p.K > DEC_KC && p.K % DEC_KC)) return AC_ERR_ARG;
+  const int KC = p.K < DEC_KC ? p.K : DEC_KC;
+  (void)KC;
+  if (p.ntb < 1 || (p.ntb > 1 && p.K > DEC_KC)) return AC_ERR_ARG;
+  const size_t lds = ((size_t)DEC_T * (DEC_KC + 4) + (size_t)DEC_WAVES * DEC_T * 17) * sizeof(float);
+  const int ntiles = (p.N + DEC_T - 1) / DEC_T;
+  dim3 grid((ntiles + p.ntb - 1) / p.ntb, (p.M + DEC_T - 1) / DEC_T);
   hipLaunchKernelGGL((dec_gemm_kernel<PRO>), grid, dim3(64 * DEC_WAVES), lds, s, p);
   return ac_check_launch();
 }
@@ -334,6 +399,8 @@ __device__ __forceinline__ void argmax_merge(float& v, int& i, float ov, int oi)
   if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
 }
 
+constexpr int PICK_MAXV = 16384;  // logits of a row are held in registers: <= 64 per thread
+
 __global__ __launch_bounds__(256) void greedy_pick_kernel(PickParams p) {
   __shared__ float sv[4];
   __shared__ int si[4];
@@ -341,9 +408,17 @@ __global__ __launch_bounds__(256) void greedy_pick_kernel(PickParams p) {
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (p.t > 0 && p.cnt[p.t - 1] == 0) return;  // the reference loop has already stopped (base.py:167)
   const float* row = p.logit + (size_t)b * p.ldl;
+  // one pass over memory: all loads in flight at once, max / arg-max / exp-sum from registers
+  float x[PICK_MAXV / 256];
+#pragma unroll
+  for (int i = 0; i < PICK_MAXV / 256; ++i) {
+    const int c = tid + 256 * i;
+    x[i] = c < p.V ? row[c] : -INFINITY;
+  }
   float v = -INFINITY;
   int idx = 0x7fffffff;
-  for (int c = tid; c < p.V; c += 256) argmax_merge(v, idx, row[c], c);
+#pragma unroll
+  for (int i = 0; i < PICK_MAXV / 256; ++i) argmax_merge(v, idx, x[i], tid + 256 * i);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const float ov = __shfl_xor(v, o, 64);
@@ -356,7 +431,9 @@ __global__ __launch_bounds__(256) void greedy_pick_kernel(PickParams p) {
 #pragma unroll
   for (int k = 1; k < 4; ++k) argmax_merge(v, idx, sv[k], si[k]);
   float s = 0.f;
-  for (int c = tid; c < p.V; c += 256) s += expf(row[c] - v);
+#pragma unroll
+  for (int i = 0; i < PICK_MAXV / 256; ++i)
+    if (tid + 256 * i < p.V) s += expf(x[i] - v);
   s = wave_sum(s);
   if (lane == 0) ssum[wave] = s;
   __syncthreads();
@@ -538,6 +615,30 @@ int launch_ln(const float* x, const float* y, const float* w, const float* b, fl
 // cache: active KV cache set.  Returns through `fin` the operands of the LAST residual join
 // (embed = LayerNorm(fin.x + fin.y) with the last layer's norm3), which the caller fuses into the
 // classifier projection; 8 launches per layer: the residual joins and the embedding never run alone.
+// Offsets (in floats) of the fragment-packed step weights inside ac_trm_weights::step_pk, fixed order:
+// per layer sa_in, sa_out, ca_q, ca_out, l1, l2; then the classifier.
+struct PackLayout {
+  size_t sa_in, sa_out, ca_q, ca_out, l1, l2;
+};
+inline size_t packed_floats(int N, int K) { return (size_t)((N + DEC_T - 1) / DEC_T) * DEC_T * K; }
+inline size_t pack_layout(const ac_trm_weights* w, PackLayout* L /* [nlayers] or null */, size_t* cls_off) {
+  const int d = w->d_model, ff = w->dim_ff;
+  size_t off = 0;
+  for (int l = 0; l < w->nlayers; ++l) {
+    PackLayout t;
+    t.sa_in = off; off += packed_floats(3 * d, d);
+    t.sa_out = off; off += packed_floats(d, d);
+    t.ca_q = off; off += packed_floats(d, d);
+    t.ca_out = off; off += packed_floats(d, d);
+    t.l1 = off; off += packed_floats(ff, d);
+    t.l2 = off; off += packed_floats(d, ff);
+    if (L) L[l] = t;
+  }
+  if (cls_off) *cls_off = off;
+  off += packed_floats(w->vocab, d);
+  return off;
+}
+
 struct StepOut {
   const float* x;
   const float* y;
@@ -550,19 +651,22 @@ int decoder_step(const ac_trm_weights* w, const float* memkv, const int* mem_len
                  const Ws& ws, StepOut* fin, hipStream_t s) {
   const int d = w->d_model, hd = d / w->nhead;
   const float scale = 1.0f / sqrtf((float)hd);
-  if (t >= w->max_pos || d > DEC_MAX_D || d % 64) return AC_ERR_ARG;
+  if (t >= w->max_pos || d > DEC_MAX_D || d % 64 || w->dim_ff % 64 || !w->step_pk) return AC_ERR_ARG;
+  PackLayout PL[AC_MAX_LAYERS];
+  pack_layout(w, PL, nullptr);
+  const float* pk = w->step_pk;
   const size_t Rm = (size_t)(R / row_div) * Tm;  // memory rows
   float* xa = ws.x;    // residual stream, ping-pong: a join reads one and writes the other
   float* xb = ws.x2;
   DecGemmParams g;
   g.tok = tok; g.tok_stride = tok_stride; g.t = t; g.emb = w->emb; g.pe = w->pe; g.emb_scale = sqrtf((float)d);
-  g.M = R;
+  g.M = R; g.ntb = 1;
   // pending join carried into the next projection: x_next = LayerNorm(jx + jy) * jw + jb
   const float *jx = nullptr, *jy = nullptr, *jw = nullptr, *jb = nullptr;
   for (int l = 0; l < w->nlayers; ++l) {
     const ac_trm_layer& L = w->layer[l];
     // ---- self attention: QKV projection with the layer input produced in its prologue ----
-    g.W = L.sa_in_w; g.ldw = d; g.bias = L.sa_in_b; g.Y = ws.qkv; g.ldy = 3 * d; g.N = 3 * d; g.K = d; g.relu = 0;
+    g.Wp = pk + PL[l].sa_in; g.bias = L.sa_in_b; g.Y = ws.qkv; g.ldy = 3 * d; g.N = 3 * d; g.K = d; g.relu = 0;
     g.xout = xa; g.ldxo = d;
     if (l == 0) {
       AC_TRY(launch_dec_gemm<PRO_EMBED>(g, s));
@@ -581,12 +685,12 @@ int decoder_step(const ac_trm_weights* w, const float* memkv, const int* mem_len
     a.out = ws.att; a.ldo = d; a.hd = hd; a.scale = scale;
     hipLaunchKernelGGL(attn_step_kernel, dim3(R, w->nhead), dim3(64), 0, s, a);
     AC_TRY(ac_check_launch());
-    g.X = ws.att; g.ldx = d; g.W = L.sa_out_w; g.ldw = d; g.bias = L.sa_out_b; g.Y = ws.tmp; g.ldy = d;
+    g.X = ws.att; g.ldx = d; g.Wp = pk + PL[l].sa_out; g.bias = L.sa_out_b; g.Y = ws.tmp; g.ldy = d;
     g.N = d; g.K = d; g.relu = 0; g.xout = nullptr;
     AC_TRY(launch_dec_gemm<PRO_PLAIN>(g, s));
     // ---- cross attention: query projection of x1 = LN1(x + self_attn) ----
     g.X = xa; g.ldx = d; g.Y2 = ws.tmp; g.ldy2 = d; g.ln_w = L.n1_w; g.ln_b = L.n1_b;
-    g.W = L.ca_in_w; g.ldw = d; g.bias = L.ca_in_b; g.Y = ws.q2; g.ldy = d; g.N = d; g.K = d; g.relu = 0;
+    g.Wp = pk + PL[l].ca_q; g.bias = L.ca_in_b; g.Y = ws.q2; g.ldy = d; g.N = d; g.K = d; g.relu = 0;
     g.xout = xb; g.ldxo = d;
     AC_TRY(launch_dec_gemm<PRO_ADDLN>(g, s));
     const float* mk = memkv + (size_t)l * Rm * 2 * d;
@@ -597,15 +701,15 @@ int decoder_step(const ac_trm_weights* w, const float* memkv, const int* mem_len
     a.new_k = nullptr; a.new_v = nullptr; a.ld_new = 0;
     hipLaunchKernelGGL(attn_step_kernel, dim3(R, w->nhead), dim3(64), 0, s, a);
     AC_TRY(ac_check_launch());
-    g.X = ws.att; g.ldx = d; g.W = L.ca_out_w; g.ldw = d; g.bias = L.ca_out_b; g.Y = ws.tmp; g.ldy = d;
+    g.X = ws.att; g.ldx = d; g.Wp = pk + PL[l].ca_out; g.bias = L.ca_out_b; g.Y = ws.tmp; g.ldy = d;
     g.N = d; g.K = d; g.relu = 0; g.xout = nullptr;
     AC_TRY(launch_dec_gemm<PRO_PLAIN>(g, s));
     // ---- feed forward on x2 = LN2(x1 + cross_attn) ----
     g.X = xb; g.ldx = d; g.Y2 = ws.tmp; g.ldy2 = d; g.ln_w = L.n2_w; g.ln_b = L.n2_b;
-    g.W = L.l1_w; g.ldw = d; g.bias = L.l1_b; g.Y = ws.ff; g.ldy = w->dim_ff; g.N = w->dim_ff; g.K = d; g.relu = 1;
+    g.Wp = pk + PL[l].l1; g.bias = L.l1_b; g.Y = ws.ff; g.ldy = w->dim_ff; g.N = w->dim_ff; g.K = d; g.relu = 1;
     g.xout = xa; g.ldxo = d;
     AC_TRY(launch_dec_gemm<PRO_ADDLN>(g, s));
-    g.X = ws.ff; g.ldx = w->dim_ff; g.W = L.l2_w; g.ldw = w->dim_ff; g.bias = L.l2_b; g.Y = ws.tmp; g.ldy = d;
+    g.X = ws.ff; g.ldx = w->dim_ff; g.Wp = pk + PL[l].l2; g.bias = L.l2_b; g.Y = ws.tmp; g.ldy = d;
     g.N = d; g.K = w->dim_ff; g.relu = 0; g.xout = nullptr;
     AC_TRY(launch_dec_gemm<PRO_PLAIN>(g, s));
     // x3 = LN3(x2 + ff) is produced by the next consumer (next layer's QKV or the caller's projection)
@@ -622,8 +726,11 @@ int classifier_step(const ac_trm_weights* w, const StepOut& fin, int R, float* x
   DecGemmParams g;
   g.tok = nullptr; g.tok_stride = 0; g.t = 0; g.emb = nullptr; g.pe = nullptr; g.emb_scale = 0.f;
   g.M = R; g.N = w->vocab; g.K = w->d_model; g.relu = 0;
+  g.ntb = 4;  // 1092 column tiles: four per block keep the grid near one resident wave of blocks
   g.X = fin.x; g.ldx = w->d_model; g.Y2 = fin.y; g.ldy2 = w->d_model; g.ln_w = fin.ln_w; g.ln_b = fin.ln_b;
-  g.W = w->cls_w; g.ldw = w->d_model; g.bias = nullptr; g.Y = logit; g.ldy = ldl; g.xout = xout; g.ldxo = ldxo;
+  size_t cls_off;
+  pack_layout(w, nullptr, &cls_off);
+  g.Wp = w->step_pk + cls_off; g.bias = nullptr; g.Y = logit; g.ldy = ldl; g.xout = xout; g.ldxo = ldxo;
   return launch_dec_gemm<PRO_ADDLN>(g, s);
 }
 
@@ -656,6 +763,36 @@ extern "C" int ac_trm_memory(const ac_trm_weights* w, const float* attn_emb, int
   return AC_OK;
 }
 
+extern "C" long ac_trm_step_pack_floats(const ac_trm_weights* w) {
+  if (check_weights(w) != AC_OK) return -1;
+  return (long)pack_layout(w, nullptr, nullptr);
+}
+
+extern "C" int ac_trm_pack_step_weights(const ac_trm_weights* w, float* out, void* stream) {
+  AC_TRY(check_weights(w));
+  if (!out || w->d_model % 64 || w->dim_ff % 64) return AC_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int d = w->d_model, ff = w->dim_ff;
+  PackLayout PL[AC_MAX_LAYERS];
+  size_t cls_off;
+  pack_layout(w, PL, &cls_off);
+  auto pack = [&](const float* W, int N, int K, float* dst) {
+    const size_t n4 = packed_floats(N, K) / 4;
+    hipLaunchKernelGGL(pack_frag_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, W, (long)K, N, K, dst);
+    return ac_check_launch();
+  };
+  for (int l = 0; l < w->nlayers; ++l) {
+    const ac_trm_layer& L = w->layer[l];
+    AC_TRY(pack(L.sa_in_w, 3 * d, d, out + PL[l].sa_in));
+    AC_TRY(pack(L.sa_out_w, d, d, out + PL[l].sa_out));
+    AC_TRY(pack(L.ca_in_w, d, d, out + PL[l].ca_q));  // rows 0..d-1 of in_proj = the query projection
+    AC_TRY(pack(L.ca_out_w, d, d, out + PL[l].ca_out));
+    AC_TRY(pack(L.l1_w, ff, d, out + PL[l].l1));
+    AC_TRY(pack(L.l2_w, d, ff, out + PL[l].l2));
+  }
+  return pack(w->cls_w, w->vocab, d, out + cls_off);
+}
+
 extern "C" long ac_trm_workspace_floats(const ac_trm_weights* w, int rows, int max_len) {
   if (check_weights(w) != AC_OK || rows <= 0 || max_len <= 0) return -1;
   return (long)carve(w, rows, max_len, nullptr).total;
@@ -667,6 +804,7 @@ extern "C" int ac_trm_greedy(const ac_trm_weights* w, const float* memkv, const 
   AC_TRY(check_weights(w));
   if (!memkv || !mem_len || !seq || !logit || !logprob || !embed || !unfinished_cnt || !ws_base) return AC_ERR_ARG;
   if (B <= 0 || Tm <= 0 || Tm > MAX_KEYS || max_len <= 0 || max_len > w->max_pos) return AC_ERR_ARG;
+  if (w->vocab > PICK_MAXV) return AC_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   const Ws ws = carve(w, B, max_len, ws_base);
   const int d = w->d_model, V = w->vocab;

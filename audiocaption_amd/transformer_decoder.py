@@ -126,6 +126,15 @@ class TransformerDecoder(BaseDecoder):
             wl.n1_w, wl.n1_b = P(L.norm1.weight), P(L.norm1.bias)
             wl.n2_w, wl.n2_b = P(L.norm2.weight), P(L.norm2.bias)
             wl.n3_w, wl.n3_b = P(L.norm3.weight), P(L.norm3.bias)
+        # fragment-packed copy of the step projections (read by every decode position)
+        lib = _lib.load()
+        n = lib.ac_trm_step_pack_floats(ctypes.byref(w))
+        if n <= 0:
+            raise _lib.HipLibraryError("ac_trm_step_pack_floats rejected the decoder configuration")
+        pk = torch.empty(n, device=self.word_embedding.weight.device, dtype=torch.float32)
+        check(lib.ac_trm_pack_step_weights(ctypes.byref(w), ptr(pk), stream()), "ac_trm_pack_step_weights")
+        keep.append(pk)
+        w.step_pk = ctypes.c_void_p(pk.data_ptr())
         self._w, self._w_key, self._w_keep = w, key, keep
         return w
 

@@ -98,6 +98,7 @@ typedef struct {
   const float* proj_b;    /* attn_proj.0.bias                        */
   const float* proj_ln_w; /* attn_proj.3 (LayerNorm)                 */
   const float* proj_ln_b;
+  const float* step_pk;   /* fragment-packed step weights from ac_trm_pack_step_weights */
   ac_trm_layer layer[AC_MAX_LAYERS];
 } ac_trm_weights;
 
@@ -111,6 +112,14 @@ int ac_add_layernorm(const float* x, const float* y, const float* w, const float
  *   attn_emb [R*Tm][attn_emb_dim] -> memkv [nlayers][R*Tm][2*d]  (K then V);  tmp: R*Tm*d floats. */
 int ac_trm_memory(const ac_trm_weights* w, const float* attn_emb, int R, int Tm, float* memkv, float* tmp,
                   void* stream);
+
+/* The per-position projections read their weights in MFMA fragment order (one contiguous 1 KiB read per
+ * wave and fragment).  ac_trm_step_pack_floats = size of that copy; ac_trm_pack_step_weights writes it from
+ * the row-major pointers of `w` (w->step_pk itself is not read); the caller then stores `out` in
+ * w->step_pk.  Required by ac_trm_greedy / ac_trm_forward_tokens / ac_trm_beam_step; redo it whenever the
+ * weights change. */
+long ac_trm_step_pack_floats(const ac_trm_weights* w);
+int ac_trm_pack_step_weights(const ac_trm_weights* w, float* out, void* stream);
 
 /* Number of workspace floats ac_trm_greedy / ac_trm_forward_tokens / ac_trm_beam need. */
 long ac_trm_workspace_floats(const ac_trm_weights* w, int rows, int max_len);
