@@ -83,6 +83,7 @@ def main():
     events = []
 
     def hook(phase, info):
+        # the dominant kernel instance: conv2 + BN + ReLU + 2x2 pool of blocks 2-5 (4 launches per step)
         if info["mode"] == 1 and info["Cout"] % 128 == 0:
             e = torch.cuda.Event(enable_timing=True)
             e.record()  # on torch's current stream == the kernel's launch stream
@@ -99,14 +100,12 @@ def main():
     sync_all()
     t1 = time.perf_counter()
     K.CONV_LAUNCH_HOOK = None
-    elapsed = t1 - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from audiocaption_amd.sharding import reduce_max_seconds
+    elapsed = reduce_max_seconds(t1 - t0, device=dev)
 
-    steps_exec = int((out["unfinished_cnt"].cpu() > 0).sum().item()) + 1
-    steps_exec = min(steps_exec, args.max_length)
+    ref_steps = min(int((out["unfinished_cnt"].cpu() > 0).sum().item()) + 1, args.max_length)
+    algo = model.encoder.cnn.conv_algo
+    mult_ratio = 2.25 if algo == "winograd" else 1.0  # F(2x2,3x3): 16 instead of 36 products per tile
 
     # dominant kernel: conv3x3_mfma_kernel<128, POOL> (conv2 of blocks 2-5)
     flops = sum(2.0 * 9 * i["Cin"] * i["Cout"] * i["H"] * i["W"] * i["B"] for _, _, i in events)
@@ -114,6 +113,13 @@ def main():
     n_launch = len(events)
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
 
+    # HBM traffic of the dominant kernel comes from PMC passes (rocprofv3 cannot run inside the timed job):
+    # the committed measurement of the same command is attached when present
+    traffic = None
+    tpath = os.path.join(REPO, "profiles", "r01_traffic.json")
+    if algo == "winograd" and os.path.exists(tpath):
+        with open(tpath) as f:
+            traffic = json.load(f).get("hbm_bytes_per_launch")
     result = None
     if rank == 0:
         clips = world * B * args.steps
@@ -132,11 +138,17 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"Cnn14Rnn-Trm greedy decode, batch {B} per GPU, {args.seconds:g} s @ 32 kHz "
                                    f"synthetic clips, max_length {args.max_length}, vocab {vocab} (BASELINE configs[1])",
-                       "global_batch": world * B, "decode_steps_executed": steps_exec,
+                       "global_batch": world * B, "decode_steps_executed": args.max_length,
+                       "decode_steps_reference_would_run": ref_steps, "conv_algo": algo,
                        "sharding": f"clips sharded over {world} rank(s), no data-path collective"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "conv3x3_mfma_kernel<128, POOL> (f32 MFMA implicit GEMM, conv2 of blocks 2-5)",
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "kernel": ("conv3x3_wino_kernel<POOL>" if algo == "winograd" else "conv3x3_mfma_kernel<128, POOL>")
+                                   + " (f32 MFMA, conv2+BN+ReLU+pool of blocks 2-5)",
+                         "note": "achieved = ALGORITHMIC direct-convolution FLOPs / time; the Winograd kernel issues "
+                                 "1/2.25 of them as MFMA work, see mfma_issue_frac" if algo == "winograd" else
+                                 "achieved = algorithmic FLOPs / time = MFMA FLOPs issued",
+                         "mfma_issue_frac": achieved / mult_ratio / FP32_MFMA_PEAK_TFLOPS,
                          "launches_timed": n_launch,
                          "avg_launch_ms": ms / n_launch if n_launch else None,
                          "algorithmic_gflop_per_launch": flops / n_launch / 1e9 if n_launch else None},
