@@ -57,7 +57,8 @@ class Cnn14Encoder(nn.Module):
         nn.init.zeros_(self.fc1.bias)
         self.fc_emb_size = 2048
         self.freeze = freeze
-        # "winograd": F(2x2,3x3) MFMA kernel (2.25x fewer multiplications, fp32); "direct": 9-tap implicit GEMM
+        # "winograd": F(2x2,3x3) f32-MFMA kernel (2.25x fewer multiplications); "direct": 9-tap f32 implicit GEMM;
+        # "bf16x3": 9-tap implicit GEMM on split-bf16 operands (1e-3-logit tier)
         self.conv_algo = os.environ.get("AUDIOCAPTION_CONV_ALGO", "winograd")
         self._tables = None
         self._packed = None
@@ -108,6 +109,8 @@ class Cnn14Encoder(nn.Module):
                         wp = K.pack_conv_weight_winograd(w)
                     elif self.conv_algo == "direct":
                         wp = K.pack_conv_weight(w)
+                    elif self.conv_algo == "bf16x3":
+                        wp = K.pack_conv_weight_bf16x3(w)
                     else:
                         raise ValueError(f"unknown conv_algo {self.conv_algo!r}")
                     sc, sh = K.fold_bn(bn.weight.float(), bn.bias.float(), bn.running_mean.float(),
@@ -148,7 +151,8 @@ class Cnn14Encoder(nn.Module):
         full = self._buf("full", B * Hp[0] * 64 * 64, dev)      # conv1 outputs (largest: level 1)
         pooled = self._buf("pooled", B * Hp[1] * 32 * 64, dev)  # block outputs (largest: block 1)
         W = 64
-        conv = K.conv3x3_bn_relu_winograd if self.conv_algo == "winograd" else K.conv3x3_bn_relu
+        conv = {"winograd": K.conv3x3_bn_relu_winograd, "direct": K.conv3x3_bn_relu,
+                "bf16x3": K.conv3x3_bn_relu_bf16x3}[self.conv_algo]
         for b in range(6):
             cin, cout = CHANNELS[b], CHANNELS[b + 1]
             w1, s1, t1 = pk["convs"][2 * b]

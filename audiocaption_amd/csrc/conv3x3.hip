@@ -41,6 +41,82 @@ struct ConvParams {
 
 enum { MODE_FULL = 0, MODE_POOL = 1, MODE_MEANW = 2 };
 
+// ---- block -> (m_tile, n_tile); block b runs on XCD b % 8 (speed only, never correctness) ----
+__device__ __forceinline__ bool conv_block_map(const ConvParams& p, int& m_tile, int& n_tile) {
+  const int bid = blockIdx.x;
+  if (p.map_mode == 1) {         // weight-heavy layers: one XCD streams one weight column slab
+    const int xcd = bid & 7, seq = bid >> 3;
+    n_tile = xcd + 8 * (seq / p.MT);
+    m_tile = seq % p.MT;
+  } else if (p.map_mode == 2) {  // activation-heavy layers: blocks sharing a halo patch share an L2
+    const int xcd = bid & 7, seq = bid >> 3;
+    n_tile = seq % p.NT;
+    m_tile = (seq / p.NT) * 8 + xcd;
+    if (m_tile >= p.MT) return false;
+  } else {
+    n_tile = bid % p.NT;
+    m_tile = bid / p.NT;
+  }
+  return true;
+}
+
+// ---- epilogue: BN scale/shift, ReLU, pooling, zero rows; lanes 0..31 store 32 consecutive channels ----
+// acc[m][n] = 32x32 tile (m-th pixel tile, n-th channel tile of this wave), MFMA row i = 4*window + 2*dy + dx
+template <int BN, int MODE>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 (&acc)[2][BN / 64], int n_tile, int row0,
+                                              int col0, int wm, int wn, int lane) {
+  constexpr int NTW = BN / 64;
+  const int half = lane >> 5;
+  const int TC = 1 << p.tc_log2;
+  const int QR2 = 32 >> p.tc_log2;
+#pragma unroll
+  for (int n = 0; n < NTW; ++n) {
+    const int ch = n_tile * BN + (wn * NTW + n) * 32 + (lane & 31);
+    const float sc = p.scale[ch], sh = p.shift[ch];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        // window q = 2*rq + half of this MFMA tile; registers 4*rq + (2*dy + dx)
+        const int q = 2 * rq + half;
+        const int qc = q & ((TC >> 1) - 1);
+        const int qr = q >> (p.tc_log2 - 1);
+        const int wy = row0 + (2 * wm + m) * QR2 + 2 * qr;  // physical row of the window's dy = 0
+        const int wx = col0 + 2 * qc;
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = fmaxf(fmaf(acc[m][n][4 * rq + e], sc, sh), 0.f);
+        if (MODE == MODE_FULL) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int gr = wy + (e >> 1), gc = wx + (e & 1);
+            if (gr < p.rows_total) {
+              const bool valid = (gr % p.Hp) < p.H;
+              p.out[((size_t)gr * p.W + gc) * p.Cout + ch] = valid ? y[e] : 0.f;
+            }
+          }
+        } else if (MODE == MODE_POOL) {
+          const int orow = wy >> 1, ocol = wx >> 1;
+          if (wy < p.rows_total) {
+            const bool valid = (orow % p.Hp_out) < p.H_out;
+            const float o = 0.25f * ((y[0] + y[1]) + (y[2] + y[3]));
+            p.out[((size_t)orow * p.W_out + ocol) * p.Cout + ch] = valid ? o : 0.f;
+          }
+        } else {  // MODE_MEANW: W == 2, mean over the two mel columns, dense (B, H, Cout) output
+#pragma unroll
+          for (int dy = 0; dy < 2; ++dy) {
+            const int gr = wy + dy;
+            if (gr < p.rows_total) {
+              const int b = gr / p.Hp, h = gr - b * p.Hp;
+              if (h < p.H) p.out[((size_t)b * p.H + h) * p.Cout + ch] = 0.5f * (y[2 * dy] + y[2 * dy + 1]);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
 template <int BN, int MODE>
 __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(ConvParams p) {
   constexpr int NTW = BN / 64;  // 32-wide MFMA column tiles per wave
@@ -53,24 +129,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(ConvParams p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int half = lane >> 5;
 
-  // ---- block -> (m_tile, n_tile); block b runs on XCD b % 8 (speed only, never correctness) ----
   int m_tile, n_tile;
-  {
-    const int bid = blockIdx.x;
-    if (p.map_mode == 1) {         // weight-heavy layers: one XCD streams one weight column slab
-      const int xcd = bid & 7, seq = bid >> 3;
-      n_tile = xcd + 8 * (seq / p.MT);
-      m_tile = seq % p.MT;
-    } else if (p.map_mode == 2) {  // activation-heavy layers: blocks sharing a halo patch share an L2
-      const int xcd = bid & 7, seq = bid >> 3;
-      n_tile = seq % p.NT;
-      m_tile = (seq / p.NT) * 8 + xcd;
-      if (m_tile >= p.MT) return;
-    } else {
-      n_tile = bid % p.NT;
-      m_tile = bid / p.NT;
-    }
-  }
+  if (!conv_block_map(p, m_tile, n_tile)) return;
   const int TC = 1 << p.tc_log2;
   const int TR = 128 >> p.tc_log2;
   const int PW = TC + 2, PH = TR + 2;
@@ -178,53 +238,193 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(ConvParams p) {
     }
   }
 
-  // ---- epilogue: BN scale/shift, ReLU, pooling, zero rows; lanes 0..31 store 32 consecutive channels ----
+  conv_epilogue<BN, MODE>(p, acc, n_tile, row0, col0, wm, wn, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Split-bf16 ("bf16x3") variant of the same implicit GEMM for the 1e-3-logit precision tier:
+// every f32 operand is split into two bf16 numbers, x = hi + lo (hi = RNE(x), lo = RNE(x - hi), 16
+// significant bits together), and the product is accumulated in f32 as hi*hi + hi*lo + lo*hi on
+// v_mfma_f32_32x32x16_bf16.  Three bf16 MFMAs replace eight f32 MFMAs (K = 16): 5.3x the matrix rate of
+// the exact-f32 path at ~2^-16 relative operand error.  Activations stay f32 in HBM: the halo patch is
+// split once when it is staged (and then re-used by 9 taps x all channel tiles), weights are split
+// offline.  LDS holds a hi and a lo plane of bf16 rows: 32 channels = 64 bytes + 16 pad (80-byte rows keep
+// the 16-byte fragment reads aligned and spread over the banks).
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+constexpr int BROW = 40;  // bf16 elements per LDS row (32 + 8 pad)
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+// x (4 floats) -> packed hi (2 dwords) and lo (2 dwords) bf16 quadruples
+__device__ __forceinline__ void split_bf16x4(const f32x4 x, u32x2& hi, u32x2& lo) {
+  hi.x = cvt_pk_bf16(x[0], x[1]);
+  hi.y = cvt_pk_bf16(x[2], x[3]);
+  const float h0 = __builtin_bit_cast(float, hi.x << 16), h1 = __builtin_bit_cast(float, hi.x & 0xffff0000u);
+  const float h2 = __builtin_bit_cast(float, hi.y << 16), h3 = __builtin_bit_cast(float, hi.y & 0xffff0000u);
+  lo.x = cvt_pk_bf16(x[0] - h0, x[1] - h1);
+  lo.y = cvt_pk_bf16(x[2] - h2, x[3] - h3);
+}
+
+template <int BN, int MODE>
+__global__ __launch_bounds__(256, 1) void conv3x3_bf16x3_kernel(ConvParams p) {
+  constexpr int NTW = BN / 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm_raw[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int half = lane >> 5;
+
+  int m_tile, n_tile;
+  if (!conv_block_map(p, m_tile, n_tile)) return;
+  const int TC = 1 << p.tc_log2;
+  const int TR = 128 >> p.tc_log2;
+  const int PW = TC + 2, PH = TR + 2;
+  const int NPIX = PW * PH;
+  const int row0 = (m_tile / p.mt_cols) * TR;
+  const int col0 = (m_tile % p.mt_cols) * TC;
+
+  // LDS carve: patch hi | patch lo | weights [2 buffers][hi, lo][BN rows]
+  __bf16* sAh = (__bf16*)dsm_raw;
+  __bf16* sAl = sAh + NPIX * BROW;
+  __bf16* sBq = sAl + NPIX * BROW;
+  constexpr int BPLANE = BN * BROW;  // elements of one weight plane
+
+  const int QR2 = 32 >> p.tc_log2;
+  int pbase[2];
+  {
+    const int i = lane & 31;
+    const int q = i >> 2, dy = (i >> 1) & 1, dx = i & 1;
+    const int qc = q & ((TC >> 1) - 1);
+    const int qr = q >> (p.tc_log2 - 1);
 #pragma unroll
-  for (int n = 0; n < NTW; ++n) {
-    const int ch = n_tile * BN + (wn * NTW + n) * 32 + (lane & 31);
-    const float sc = p.scale[ch], sh = p.shift[ch];
+    for (int m = 0; m < 2; ++m)
+      pbase[m] = (((2 * wm + m) * QR2 + 2 * qr + dy) * PW + 2 * qc + dx) * BROW + half * 8;
+  }
+  int nbase[NTW];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+  for (int n = 0; n < NTW; ++n) nbase[n] = ((wn * NTW + n) * 32 + (lane & 31)) * BROW + half * 8;
+
+  f32x16 acc[2][NTW];
 #pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        // window q = 2*rq + half of this MFMA tile; registers 4*rq + (2*dy + dx)
-        const int q = 2 * rq + half;
-        const int qc = q & ((TC >> 1) - 1);
-        const int qr = q >> (p.tc_log2 - 1);
-        const int wy = row0 + (2 * wm + m) * QR2 + 2 * qr;  // physical row of the window's dy = 0
-        const int wx = col0 + 2 * qc;
-        float y[4];
+  for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = fmaxf(fmaf(acc[m][n][4 * rq + e], sc, sh), 0.f);
-        if (MODE == MODE_FULL) {
+    for (int n = 0; n < NTW; ++n)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int gr = wy + (e >> 1), gc = wx + (e & 1);
-            if (gr < p.rows_total) {
-              const bool valid = (gr % p.Hp) < p.H;
-              p.out[((size_t)gr * p.W + gc) * p.Cout + ch] = valid ? y[e] : 0.f;
-            }
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  const int rc0 = row0 % p.Hp;
+  const bool all_pad = (rc0 >= p.H && rc0 + TR <= p.Hp) || row0 >= p.rows_total;
+  const int nchunk = p.Cin >> 5;
+  constexpr int BLD = 2 * BN * 4 / 256;  // 16-byte weight loads per thread per tap (hi + lo planes)
+  if (!all_pad) {
+    // packed weights: [Cin/32][9][2 planes][Cout][32] bf16; one (chunk, tap, plane) slab = Cout x 64 bytes
+    const unsigned char* wsrc = (const unsigned char*)p.wpk + (size_t)n_tile * BN * 64;
+    const size_t plane_bytes = (size_t)p.Cout * 64;
+    const int total = nchunk * 9;
+    auto w_load = [&](int it, u32x4 (&reg)[BLD]) {
+#pragma unroll
+      for (int u = 0; u < BLD; ++u) {
+        const int idx = tid + u * 256;               // 16-byte unit: plane = idx / (BN*4), row = (idx / 4) % BN
+        const int plane = idx / (BN * 4), rem = idx - plane * (BN * 4);
+        reg[u] = *(const u32x4*)(wsrc + ((size_t)it * 2 + plane) * plane_bytes + (size_t)rem * 16);
+      }
+    };
+    auto w_store = [&](int buf, const u32x4 (&reg)[BLD]) {
+#pragma unroll
+      for (int u = 0; u < BLD; ++u) {
+        const int idx = tid + u * 256;
+        const int plane = idx / (BN * 4), rem = idx - plane * (BN * 4);
+        *(u32x4*)(sBq + (buf * 2 + plane) * BPLANE + (rem >> 2) * BROW + (rem & 3) * 8) = reg[u];
+      }
+    };
+    auto stage_patch = [&](int c) {
+      for (int idx = tid; idx < NPIX * 8; idx += 256) {
+        const int pix = idx >> 3, c4 = idx & 7;
+        const int pr = pix / PW, pc = pix - pr * PW;
+        const int gr = row0 - 1 + pr, gc = col0 - 1 + pc;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gr >= 0 && gr < p.rows_total && gc >= 0 && gc < p.W)
+          v = *(const f32x4*)(p.in + ((size_t)gr * p.W + gc) * p.Cin + c * 32 + c4 * 4);
+        u32x2 hi, lo;
+        split_bf16x4(v, hi, lo);
+        *(u32x2*)(sAh + pix * BROW + c4 * 4) = hi;
+        *(u32x2*)(sAl + pix * BROW + c4 * 4) = lo;
+      }
+    };
+    u32x4 breg[BLD];
+    stage_patch(0);
+    w_load(0, breg);
+    w_store(0, breg);
+    __syncthreads();
+    int tap = 0, c = 0;
+#pragma unroll 1
+    for (int it = 0; it < total; ++it) {
+      w_load(it + 1 < total ? it + 1 : it, breg);
+      __builtin_amdgcn_sched_barrier(0);
+      const int ky = tap / 3, kx = tap - 3 * ky;
+      const int aoff = (ky * PW + kx) * BROW;
+      const __bf16* bh = sBq + ((it & 1) * 2 + 0) * BPLANE;
+      const __bf16* bl = sBq + ((it & 1) * 2 + 1) * BPLANE;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {  // two K = 16 steps per 32-channel chunk
+        bf16x8 ah[2], al[2], wh[NTW], wl[NTW];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          ah[m] = *(const bf16x8*)(sAh + aoff + pbase[m] + ks * 16);
+          al[m] = *(const bf16x8*)(sAl + aoff + pbase[m] + ks * 16);
+        }
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+          wh[n] = *(const bf16x8*)(bh + nbase[n] + ks * 16);
+          wl[n] = *(const bf16x8*)(bl + nbase[n] + ks * 16);
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < NTW; ++n) {
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], wh[n], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], wl[n], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], wh[n], acc[m][n], 0, 0, 0);
           }
-        } else if (MODE == MODE_POOL) {
-          const int orow = wy >> 1, ocol = wx >> 1;
-          if (wy < p.rows_total) {
-            const bool valid = (orow % p.Hp_out) < p.H_out;
-            const float o = 0.25f * ((y[0] + y[1]) + (y[2] + y[3]));
-            p.out[((size_t)orow * p.W_out + ocol) * p.Cout + ch] = valid ? o : 0.f;
-          }
-        } else {  // MODE_MEANW: W == 2, mean over the two mel columns, dense (B, H, Cout) output
-#pragma unroll
-          for (int dy = 0; dy < 2; ++dy) {
-            const int gr = wy + dy;
-            if (gr < p.rows_total) {
-              const int b = gr / p.Hp, h = gr - b * p.Hp;
-              if (h < p.H) p.out[((size_t)b * p.H + h) * p.Cout + ch] = 0.5f * (y[2 * dy] + y[2 * dy + 1]);
-            }
-          }
+      }
+      w_store((it + 1) & 1, breg);
+      __syncthreads();
+      if (++tap == 9) {
+        tap = 0;
+        if (++c < nchunk) {
+          stage_patch(c);
+          __syncthreads();
         }
       }
     }
   }
+  conv_epilogue<BN, MODE>(p, acc, n_tile, row0, col0, wm, wn, lane);
+}
+
+template <int BN, int MODE>
+int launch_conv_bf16x3(const ConvParams& p, hipStream_t s) {
+  unsigned grid;
+  if (p.map_mode == 2) grid = (unsigned)(((p.MT + 7) / 8) * 8 * p.NT);
+  else grid = (unsigned)(p.MT * p.NT);
+  const int TC = 1 << p.tc_log2, TR = 128 >> p.tc_log2;
+  const size_t lds = ((size_t)(TC + 2) * (TR + 2) * 2 + (size_t)4 * BN) * BROW * 2;  // bytes (bf16)
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)conv3x3_bf16x3_kernel<BN, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(((size_t)MAX_NPIX * 2 + 4 * BN) * BROW * 2)) != hipSuccess)
+      return AC_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3x3_bf16x3_kernel<BN, MODE>), dim3(grid), dim3(256), lds, s, p);
+  return ac_check_launch();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -330,6 +530,42 @@ extern "C" int ac_conv3x3_bn_relu(const float* in, const float* wpk, const float
     if (mode == MODE_FULL) return launch_conv<64, MODE_FULL>(p, s);
     if (mode == MODE_POOL) return launch_conv<64, MODE_POOL>(p, s);
     return launch_conv<64, MODE_MEANW>(p, s);
+  }
+}
+
+extern "C" int ac_conv3x3_bn_relu_bf16x3(const float* in, const void* wpk, const float* scale, const float* shift,
+                                         float* out, int B, int Hp, int H, int W, int Cin, int Cout, int mode,
+                                         int map_mode, void* stream) {
+  if (!in || !wpk || !scale || !shift || !out) return AC_ERR_ARG;
+  if (B <= 0 || Hp <= H || W < 2 || (W & (W - 1)) || Cin % 32 || Cout % 64) return AC_ERR_ARG;
+  if (mode < 0 || mode > 2) return AC_ERR_ARG;
+  if (mode == MODE_POOL && (Hp & 1)) return AC_ERR_ARG;
+  if (mode == MODE_MEANW && W != 2) return AC_ERR_ARG;
+  ConvParams p;
+  p.in = in; p.wpk = (const float*)wpk; p.scale = scale; p.shift = shift; p.out = out;
+  p.rows_total = B * Hp; p.Hp = Hp; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+  const int TC = W < 16 ? W : 16;
+  int l2 = 0;
+  while ((1 << l2) < TC) ++l2;
+  p.tc_log2 = l2;
+  const int TR = 128 / TC;
+  p.mt_cols = W / TC;
+  p.MT = ((p.rows_total + TR - 1) / TR) * p.mt_cols;
+  const int BN = (Cout % 128 == 0) ? 128 : 64;
+  p.NT = Cout / BN;
+  p.Hp_out = Hp / 2; p.H_out = H / 2; p.W_out = W / 2;
+  if (map_mode < 0) map_mode = (p.NT % 8 == 0) ? 1 : 2;
+  if (map_mode == 1 && p.NT % 8 != 0) return AC_ERR_ARG;
+  p.map_mode = map_mode;
+  hipStream_t s = (hipStream_t)stream;
+  if (BN == 128) {
+    if (mode == MODE_FULL) return launch_conv_bf16x3<128, MODE_FULL>(p, s);
+    if (mode == MODE_POOL) return launch_conv_bf16x3<128, MODE_POOL>(p, s);
+    return launch_conv_bf16x3<128, MODE_MEANW>(p, s);
+  } else {
+    if (mode == MODE_FULL) return launch_conv_bf16x3<64, MODE_FULL>(p, s);
+    if (mode == MODE_POOL) return launch_conv_bf16x3<64, MODE_POOL>(p, s);
+    return launch_conv_bf16x3<64, MODE_MEANW>(p, s);
   }
 }
 

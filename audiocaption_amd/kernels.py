@@ -75,6 +75,32 @@ def conv3x3_bn_relu_winograd(x, upk, scale, shift, out, B, Hp, H, W, Cin, Cout, 
     return out
 
 
+def conv3x3_bn_relu_bf16x3(x, wpk, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode=-1):
+    lib = _lib.load()
+    hook = CONV_LAUNCH_HOOK
+    if hook is not None:
+        info = {"B": B, "H": H, "Hp": Hp, "W": W, "Cin": Cin, "Cout": Cout, "mode": mode, "algo": "bf16x3"}
+        hook("pre", info)
+    check(lib.ac_conv3x3_bn_relu_bf16x3(ptr(x), ptr(wpk), ptr(scale), ptr(shift), ptr(out), B, Hp, H, W, Cin, Cout,
+                                        mode, map_mode, stream()), "ac_conv3x3_bn_relu_bf16x3")
+    if hook is not None:
+        hook("post", info)
+    return out
+
+
+def pack_conv_weight_bf16x3(w):
+    """OIHW f32 -> split bf16 planes [Cin/32][9][2 (hi, lo)][Cout][32] (csrc/conv3x3.hip, bf16x3 kernel).
+    hi = RNE_bf16(w), lo = RNE_bf16(w - hi)."""
+    cout, cin = w.shape[0], w.shape[1]
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+
+    def lay(t):
+        return t.permute(1, 2, 3, 0).reshape(cin // 32, 32, 9, cout).permute(0, 2, 3, 1)
+
+    return torch.stack([lay(hi), lay(lo)], dim=2).contiguous()
+
+
 def pack_conv_weight_winograd(w):
     """OIHW (Cout, Cin, 3, 3) -> U = G g G^T as [Cin/32][4 j][4 i][Cout][32] (csrc/conv3x3_winograd.hip).
     The transform is evaluated in float64 and rounded once to fp32."""

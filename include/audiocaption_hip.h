@@ -60,6 +60,12 @@ int ac_conv3x3_bn_relu(const float* in, const float* wpk, const float* scale, co
 int ac_conv3x3_bn_relu_winograd(const float* in, const float* upk, const float* scale, const float* shift,
                                 float* out, int B, int Hp, int H, int W, int Cin, int Cout, int mode,
                                 int map_mode, void* stream);
+/* Same operation on split-bf16 operands ("bf16x3": x = hi + lo in bf16, hi*hi + hi*lo + lo*hi accumulated in
+ * f32 on v_mfma_f32_32x32x16_bf16; ~2^-16 relative operand error, 5.3x the f32 matrix rate) - the 1e-3-logit
+ * precision tier.  Activations in/out stay f32; wpk = weights split offline and packed as
+ * [Cin/32][9][2 (hi, lo)][Cout][32] bf16. */
+int ac_conv3x3_bn_relu_bf16x3(const float* in, const void* wpk, const float* scale, const float* shift, float* out,
+                              int B, int Hp, int H, int W, int Cin, int Cout, int mode, int map_mode, void* stream);
 /* First conv (Cin = 1): in [B*Hp][64], w [64][9] (OIHW), out [B*Hp][64][64]. */
 int ac_conv3x3_first(const float* in, const float* w, const float* scale, const float* shift, float* out,
                      int B, int Hp, int H, int W, void* stream);

@@ -35,7 +35,8 @@ def _cnn_from_logmel(cnn, lms):
     pooled = torch.empty(B * Hp[1] * 32 * 64, device=lms.device)
     W = 64
     from audiocaption_amd.cnn_encoder import CHANNELS
-    conv = K.conv3x3_bn_relu_winograd if cnn.conv_algo == "winograd" else K.conv3x3_bn_relu
+    conv = {"winograd": K.conv3x3_bn_relu_winograd, "direct": K.conv3x3_bn_relu,
+            "bf16x3": K.conv3x3_bn_relu_bf16x3}[cnn.conv_algo]
     blocks = []
     for b in range(6):
         cin, cout = CHANNELS[b], CHANNELS[b + 1]
