@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaudiocaption_hip.so")
+LIB_PATH = os.environ.get("AUDIOCAPTION_HIP_LIB") or os.path.join(_HERE, "libaudiocaption_hip.so")  # env: development builds
 
 AC_MAX_LAYERS = 8
 
@@ -40,6 +40,7 @@ SIGNATURES = {
     "ac_conv3x3_bn_relu": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ac_conv3x3_bn_relu_winograd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ac_conv3x3_bn_relu_bf16x3": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ac_conv3x3_bn_relu_bf16x3_gw": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ac_conv3x3_first": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ac_linear": (_I, [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _P]),
     "ac_gru_layer": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),

@@ -58,8 +58,9 @@ class Cnn14Encoder(nn.Module):
         self.fc_emb_size = 2048
         self.freeze = freeze
         # "winograd": F(2x2,3x3) f32-MFMA kernel (2.25x fewer multiplications); "direct": 9-tap f32 implicit GEMM;
-        # "bf16x3": 9-tap implicit GEMM on split-bf16 operands (1e-3-logit tier)
-        self.conv_algo = os.environ.get("AUDIOCAPTION_CONV_ALGO", "winograd")
+        # "bf16x3": 9-tap implicit GEMM on split-bf16 operands, weight fragments straight from L2 (1e-3-logit
+        # tier; "bf16x3_lds" = the same with an LDS weight ring)
+        self.conv_algo = os.environ.get("AUDIOCAPTION_CONV_ALGO", "bf16x3")
         self._tables = None
         self._packed = None
         self._packed_key = None
@@ -110,6 +111,8 @@ class Cnn14Encoder(nn.Module):
                     elif self.conv_algo == "direct":
                         wp = K.pack_conv_weight(w)
                     elif self.conv_algo == "bf16x3":
+                        wp = K.pack_conv_weight_bf16x3_frag(w)
+                    elif self.conv_algo == "bf16x3_lds":
                         wp = K.pack_conv_weight_bf16x3(w)
                     else:
                         raise ValueError(f"unknown conv_algo {self.conv_algo!r}")
@@ -152,7 +155,7 @@ class Cnn14Encoder(nn.Module):
         pooled = self._buf("pooled", B * Hp[1] * 32 * 64, dev)  # block outputs (largest: block 1)
         W = 64
         conv = {"winograd": K.conv3x3_bn_relu_winograd, "direct": K.conv3x3_bn_relu,
-                "bf16x3": K.conv3x3_bn_relu_bf16x3}[self.conv_algo]
+                "bf16x3": K.conv3x3_bn_relu_bf16x3_gw, "bf16x3_lds": K.conv3x3_bn_relu_bf16x3}[self.conv_algo]
         for b in range(6):
             cin, cout = CHANNELS[b], CHANNELS[b + 1]
             w1, s1, t1 = pk["convs"][2 * b]

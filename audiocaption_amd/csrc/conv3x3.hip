@@ -53,12 +53,24 @@ __device__ __forceinline__ bool conv_block_map(const ConvParams& p, int& m_tile,
     n_tile = seq % p.NT;
     m_tile = (seq / p.NT) * 8 + xcd;
     if (m_tile >= p.MT) return false;
+  } else if (p.map_mode == 3) {  // NT in {1,2,4,8}: every XCD owns ONE weight column slab (L2-resident),
+    const int xcd = bid & 7, seq = bid >> 3;  //          the 8/NT XCDs of a slab interleave the pixel tiles
+    const int per = 8 / p.NT;
+    n_tile = xcd % p.NT;
+    m_tile = seq * per + xcd / p.NT;
+    if (m_tile >= p.MT) return false;
   } else {
     n_tile = bid % p.NT;
     m_tile = bid / p.NT;
   }
   return true;
 }
+
+// Window order inside a 32-pixel MFMA tile.  A ds_read_b128 is serviced in 16-lane groups
+// {0-3,12-15,20-27} / {4-11,16-19,28-31} (per 32-lane half), i.e. windows q in {0,3,5,6} / {1,2,4,7}.
+// Mapping those to window POSITIONS 0-3 / 4-7 makes each hardware group read one compact half of the tile
+// (2x8, 4x4 or 8x2 pixels), which a suitable patch row pitch then spreads over all 16 bank slots.
+__device__ __forceinline__ int window_pos(int q) { return (0x73261540 >> (4 * q)) & 7; }  // [0,4,5,1,6,2,3,7]
 
 // ---- epilogue: BN scale/shift, ReLU, pooling, zero rows; lanes 0..31 store 32 consecutive channels ----
 // acc[m][n] = 32x32 tile (m-th pixel tile, n-th channel tile of this wave), MFMA row i = 4*window + 2*dy + dx
@@ -78,7 +90,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
         // window q = 2*rq + half of this MFMA tile; registers 4*rq + (2*dy + dx)
-        const int q = 2 * rq + half;
+        const int q = window_pos(2 * rq + half);
         const int qc = q & ((TC >> 1) - 1);
         const int qr = q >> (p.tc_log2 - 1);
         const int wy = row0 + (2 * wm + m) * QR2 + 2 * qr;  // physical row of the window's dy = 0
@@ -144,7 +156,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(ConvParams p) {
   int pbase[2];
   {
     const int i = lane & 31;
-    const int q = i >> 2, dy = (i >> 1) & 1, dx = i & 1;
+    const int q = window_pos(i >> 2), dy = (i >> 1) & 1, dx = i & 1;
     const int qc = q & ((TC >> 1) - 1);
     const int qr = q >> (p.tc_log2 - 1);
     tx0 = 2 * qc;
@@ -251,6 +263,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(ConvParams p) {
 // offline.  LDS holds a hi and a lo plane of bf16 rows: 32 channels = 64 bytes + 16 pad (80-byte rows keep
 // the 16-byte fragment reads aligned and spread over the banks).
 // ------------------------------------------------------------------------------------------------
+// pad (in 16-byte slots) that brings a patch row of (TC + 2) pixels x 5 slots to a pitch of 8 mod 16 (TC >= 8),
+// 4 mod 8 (TC = 4) or 2 mod 4 (TC = 2)
+__host__ __device__ __forceinline__ int patch_row_pad_slots(int TC) {
+  const int base = (TC + 2) * 5;
+  return TC >= 8 ? ((8 - base) & 15) : (TC == 4 ? ((4 - base) & 7) : ((2 - base) & 3));
+}
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -291,22 +310,27 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16x3_kernel(ConvParams p) {
   const int row0 = (m_tile / p.mt_cols) * TR;
   const int col0 = (m_tile % p.mt_cols) * TC;
 
+  // Patch rows are PW pixels of 80 bytes (5 bank slots of 16 bytes) plus a pad chosen so that the row pitch
+  // is = 8 (TC >= 8), 4 (TC = 4) or 2 (TC = 2) slots mod 16: together with window_pos() the 16 lanes of
+  // every ds_read_b128 group then hit 16 different slots (conflict-free A fragments).
+  const int PITCH = PW * BROW + patch_row_pad_slots(TC) * 8;  // bf16 elements per patch row
+  const int PLANE = PH * PITCH;
   // LDS carve: patch hi | patch lo | weights [2 buffers][hi, lo][BN rows]
   __bf16* sAh = (__bf16*)dsm_raw;
-  __bf16* sAl = sAh + NPIX * BROW;
-  __bf16* sBq = sAl + NPIX * BROW;
+  __bf16* sAl = sAh + PLANE;
+  __bf16* sBq = sAl + PLANE;
   constexpr int BPLANE = BN * BROW;  // elements of one weight plane
 
   const int QR2 = 32 >> p.tc_log2;
   int pbase[2];
   {
     const int i = lane & 31;
-    const int q = i >> 2, dy = (i >> 1) & 1, dx = i & 1;
+    const int q = window_pos(i >> 2), dy = (i >> 1) & 1, dx = i & 1;
     const int qc = q & ((TC >> 1) - 1);
     const int qr = q >> (p.tc_log2 - 1);
 #pragma unroll
     for (int m = 0; m < 2; ++m)
-      pbase[m] = (((2 * wm + m) * QR2 + 2 * qr + dy) * PW + 2 * qc + dx) * BROW + half * 8;
+      pbase[m] = ((2 * wm + m) * QR2 + 2 * qr + dy) * PITCH + (2 * qc + dx) * BROW + half * 8;
   }
   int nbase[NTW];
 #pragma unroll
@@ -355,8 +379,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16x3_kernel(ConvParams p) {
           v = *(const f32x4*)(p.in + ((size_t)gr * p.W + gc) * p.Cin + c * 32 + c4 * 4);
         u32x2 hi, lo;
         split_bf16x4(v, hi, lo);
-        *(u32x2*)(sAh + pix * BROW + c4 * 4) = hi;
-        *(u32x2*)(sAl + pix * BROW + c4 * 4) = lo;
+        *(u32x2*)(sAh + pr * PITCH + pc * BROW + c4 * 4) = hi;
+        *(u32x2*)(sAl + pr * PITCH + pc * BROW + c4 * 4) = lo;
       }
     };
     u32x4 breg[BLD];
@@ -364,27 +388,42 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16x3_kernel(ConvParams p) {
     w_load(0, breg);
     w_store(0, breg);
     __syncthreads();
+#ifdef AC_ABL_NOFRAG
+    bf16x8 ah[2], al[2], wh[NTW], wl[NTW];
+#endif
     int tap = 0, c = 0;
 #pragma unroll 1
     for (int it = 0; it < total; ++it) {
+#ifndef AC_ABL_NORING
       w_load(it + 1 < total ? it + 1 : it, breg);
+#endif
       __builtin_amdgcn_sched_barrier(0);
       const int ky = tap / 3, kx = tap - 3 * ky;
-      const int aoff = (ky * PW + kx) * BROW;
+      const int aoff = ky * PITCH + kx * BROW;
       const __bf16* bh = sBq + ((it & 1) * 2 + 0) * BPLANE;
       const __bf16* bl = sBq + ((it & 1) * 2 + 1) * BPLANE;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {  // two K = 16 steps per 32-channel chunk
+#ifndef AC_ABL_NOFRAG
         bf16x8 ah[2], al[2], wh[NTW], wl[NTW];
+#endif
+#ifdef AC_ABL_NOFRAG  // development build: fragments read once (tap 0 addresses), isolates the MFMA issue rate
+        const int aoff_ = 0;
+        if (it == 0)
+#else
+        const int aoff_ = aoff;
+#endif
+        {
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          ah[m] = *(const bf16x8*)(sAh + aoff + pbase[m] + ks * 16);
-          al[m] = *(const bf16x8*)(sAl + aoff + pbase[m] + ks * 16);
-        }
+          for (int m = 0; m < 2; ++m) {
+            ah[m] = *(const bf16x8*)(sAh + aoff_ + pbase[m] + ks * 16);
+            al[m] = *(const bf16x8*)(sAl + aoff_ + pbase[m] + ks * 16);
+          }
 #pragma unroll
-        for (int n = 0; n < NTW; ++n) {
-          wh[n] = *(const bf16x8*)(bh + nbase[n] + ks * 16);
-          wl[n] = *(const bf16x8*)(bl + nbase[n] + ks * 16);
+          for (int n = 0; n < NTW; ++n) {
+            wh[n] = *(const bf16x8*)(bh + nbase[n] + ks * 16);
+            wl[n] = *(const bf16x8*)(bl + nbase[n] + ks * 16);
+          }
         }
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -395,8 +434,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16x3_kernel(ConvParams p) {
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], wh[n], acc[m][n], 0, 0, 0);
           }
       }
+#ifndef AC_ABL_NORING
       w_store((it + 1) & 1, breg);
       __syncthreads();
+#endif
       if (++tap == 9) {
         tap = 0;
         if (++c < nchunk) {
@@ -409,17 +450,158 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16x3_kernel(ConvParams p) {
   conv_epilogue<BN, MODE>(p, acc, n_tile, row0, col0, wm, wn, lane);
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16x3, weights straight from L2 ("gw"): the B fragments never touch LDS.  Weights are pre-packed in MFMA
+// fragment order, [Cin/32][9 taps][2 k-steps][Cout/32][hi, lo][64 lanes][8 bf16], so a wave's fragment is
+// one contiguous 1 KiB read; the fragments of tap t+1 are requested into VGPRs while tap t runs on the
+// matrix cores.  LDS then holds only the split halo patch: no weight ring, no per-tap barrier (2 barriers
+// per 32-channel chunk = per 216 MFMAs of a wave), half the LDS fragment reads.
+// ------------------------------------------------------------------------------------------------
+template <int BN, int MODE>
+__global__ __launch_bounds__(256, 1) void conv3x3_bf16x3_gw_kernel(ConvParams p) {
+  constexpr int NTW = BN / 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm_raw[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int half = lane >> 5;
+
+  int m_tile, n_tile;
+  if (!conv_block_map(p, m_tile, n_tile)) return;
+  const int TC = 1 << p.tc_log2;
+  const int TR = 128 >> p.tc_log2;
+  const int PW = TC + 2, PH = TR + 2;
+  const int NPIX = PW * PH;
+  const int row0 = (m_tile / p.mt_cols) * TR;
+  const int col0 = (m_tile % p.mt_cols) * TC;
+  const int PITCH = PW * BROW + patch_row_pad_slots(TC) * 8;
+  const int PLANE = PH * PITCH;
+  __bf16* sAh = (__bf16*)dsm_raw;
+  __bf16* sAl = sAh + PLANE;
+
+  const int QR2 = 32 >> p.tc_log2;
+  int pbase[2];
+  {
+    const int i = lane & 31;
+    const int q = window_pos(i >> 2), dy = (i >> 1) & 1, dx = i & 1;
+    const int qc = q & ((TC >> 1) - 1);
+    const int qr = q >> (p.tc_log2 - 1);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+      pbase[m] = ((2 * wm + m) * QR2 + 2 * qr + dy) * PITCH + (2 * qc + dx) * BROW + half * 8;
+  }
+
+  f32x16 acc[2][NTW];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < NTW; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  const int rc0 = row0 % p.Hp;
+  const bool all_pad = (rc0 >= p.H && rc0 + TR <= p.Hp) || row0 >= p.rows_total;
+  const int nchunk = p.Cin >> 5;
+  if (!all_pad) {
+    // fragment (it = chunk*9 + tap, ks, n-tile nt32, plane) = 1 KiB at ((it*2 + ks)*NT32 + nt32)*2 + plane
+    const int NT32 = p.Cout >> 5;
+    const bf16x8* wf = (const bf16x8*)p.wpk + (size_t)(n_tile * (BN / 32) + wn * NTW) * 2 * 64 + lane;
+    const size_t ks_stride = (size_t)NT32 * 2 * 64;  // in bf16x8 units
+    auto w_load = [&](int it, bf16x8 (&w)[2][NTW][2]) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) w[ks][n][pl] = wf[((size_t)it * 2 + ks) * ks_stride + (n * 2 + pl) * 64];
+    };
+    auto stage_patch = [&](int c) {
+      for (int idx = tid; idx < NPIX * 8; idx += 256) {
+        const int pix = idx >> 3, c4 = idx & 7;
+        const int pr = pix / PW, pc = pix - pr * PW;
+        const int gr = row0 - 1 + pr, gc = col0 - 1 + pc;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gr >= 0 && gr < p.rows_total && gc >= 0 && gc < p.W)
+          v = *(const f32x4*)(p.in + ((size_t)gr * p.W + gc) * p.Cin + c * 32 + c4 * 4);
+        u32x2 hi, lo;
+        split_bf16x4(v, hi, lo);
+        *(u32x2*)(sAh + pr * PITCH + pc * BROW + c4 * 4) = hi;
+        *(u32x2*)(sAl + pr * PITCH + pc * BROW + c4 * 4) = lo;
+      }
+    };
+    const int total = nchunk * 9;
+    bf16x8 wc[2][NTW][2], wnx[2][NTW][2];
+    w_load(0, wc);
+    stage_patch(0);
+    __syncthreads();
+    int tap = 0, c = 0;
+#pragma unroll 1
+    for (int it = 0; it < total; ++it) {
+      w_load(it + 1 < total ? it + 1 : it, wnx);
+      const int ky = tap / 3, kx = tap - 3 * ky;
+      const int aoff = ky * PITCH + kx * BROW;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 ah[2], al[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          ah[m] = *(const bf16x8*)(sAh + aoff + pbase[m] + ks * 16);
+          al[m] = *(const bf16x8*)(sAl + aoff + pbase[m] + ks * 16);
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < NTW; ++n) {
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], wc[ks][n][0], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], wc[ks][n][1], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], wc[ks][n][0], acc[m][n], 0, 0, 0);
+          }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) wc[ks][n][pl] = wnx[ks][n][pl];
+      if (++tap == 9) {
+        tap = 0;
+        if (++c < nchunk) {
+          __syncthreads();  // every wave is done with the patch of the previous chunk
+          stage_patch(c);
+          __syncthreads();
+        }
+      }
+    }
+  }
+  conv_epilogue<BN, MODE>(p, acc, n_tile, row0, col0, wm, wn, lane);
+}
+
+template <int BN, int MODE>
+int launch_conv_bf16x3_gw(const ConvParams& p, hipStream_t s) {
+  unsigned grid;
+  if (p.map_mode == 2) grid = (unsigned)(((p.MT + 7) / 8) * 8 * p.NT);
+  else if (p.map_mode == 3) grid = (unsigned)(((p.MT + 8 / p.NT - 1) / (8 / p.NT)) * 8);
+  else grid = (unsigned)(p.MT * p.NT);
+  const int TC = 1 << p.tc_log2, TR = 128 >> p.tc_log2;
+  const int pitch = (TC + 2) * BROW + patch_row_pad_slots(TC) * 8;
+  const size_t lds = (size_t)(TR + 2) * pitch * 2 * 2;  // hi + lo planes, bf16
+  hipLaunchKernelGGL((conv3x3_bf16x3_gw_kernel<BN, MODE>), dim3(grid), dim3(256), lds, s, p);
+  return ac_check_launch();
+}
+
 template <int BN, int MODE>
 int launch_conv_bf16x3(const ConvParams& p, hipStream_t s) {
   unsigned grid;
   if (p.map_mode == 2) grid = (unsigned)(((p.MT + 7) / 8) * 8 * p.NT);
   else grid = (unsigned)(p.MT * p.NT);
   const int TC = 1 << p.tc_log2, TR = 128 >> p.tc_log2;
-  const size_t lds = ((size_t)(TC + 2) * (TR + 2) * 2 + (size_t)4 * BN) * BROW * 2;  // bytes (bf16)
+  const int pitch = (TC + 2) * BROW + patch_row_pad_slots(TC) * 8;
+  const size_t lds = ((size_t)(TR + 2) * pitch * 2 + (size_t)4 * BN * BROW) * 2;  // bytes (bf16 elements x 2)
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)conv3x3_bf16x3_kernel<BN, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(((size_t)MAX_NPIX * 2 + 4 * BN) * BROW * 2)) != hipSuccess)
+                            160 * 1024) != hipSuccess)
       return AC_ERR_LAUNCH;
     attr_set = true;
   }
@@ -566,6 +748,43 @@ extern "C" int ac_conv3x3_bn_relu_bf16x3(const float* in, const void* wpk, const
     if (mode == MODE_FULL) return launch_conv_bf16x3<64, MODE_FULL>(p, s);
     if (mode == MODE_POOL) return launch_conv_bf16x3<64, MODE_POOL>(p, s);
     return launch_conv_bf16x3<64, MODE_MEANW>(p, s);
+  }
+}
+
+extern "C" int ac_conv3x3_bn_relu_bf16x3_gw(const float* in, const void* wfrag, const float* scale, const float* shift,
+                                            float* out, int B, int Hp, int H, int W, int Cin, int Cout, int mode,
+                                            int map_mode, void* stream) {
+  if (!in || !wfrag || !scale || !shift || !out) return AC_ERR_ARG;
+  if (B <= 0 || Hp <= H || W < 2 || (W & (W - 1)) || Cin % 32 || Cout % 64) return AC_ERR_ARG;
+  if (mode < 0 || mode > 2) return AC_ERR_ARG;
+  if (mode == MODE_POOL && (Hp & 1)) return AC_ERR_ARG;
+  if (mode == MODE_MEANW && W != 2) return AC_ERR_ARG;
+  ConvParams p;
+  p.in = in; p.wpk = (const float*)wfrag; p.scale = scale; p.shift = shift; p.out = out;
+  p.rows_total = B * Hp; p.Hp = Hp; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+  const int TC = W < 16 ? W : 16;
+  int l2 = 0;
+  while ((1 << l2) < TC) ++l2;
+  p.tc_log2 = l2;
+  const int TR = 128 / TC;
+  p.mt_cols = W / TC;
+  p.MT = ((p.rows_total + TR - 1) / TR) * p.mt_cols;
+  const int BN = (Cout % 128 == 0) ? 128 : 64;
+  p.NT = Cout / BN;
+  p.Hp_out = Hp / 2; p.H_out = H / 2; p.W_out = W / 2;
+  if (map_mode < 0) map_mode = (p.NT % 8 == 0) ? 1 : 2;
+  if (map_mode == 1 && p.NT % 8 != 0) return AC_ERR_ARG;
+  if (map_mode == 3 && (p.NT > 8 || (8 % p.NT) != 0)) return AC_ERR_ARG;
+  p.map_mode = map_mode;
+  hipStream_t s = (hipStream_t)stream;
+  if (BN == 128) {
+    if (mode == MODE_FULL) return launch_conv_bf16x3_gw<128, MODE_FULL>(p, s);
+    if (mode == MODE_POOL) return launch_conv_bf16x3_gw<128, MODE_POOL>(p, s);
+    return launch_conv_bf16x3_gw<128, MODE_MEANW>(p, s);
+  } else {
+    if (mode == MODE_FULL) return launch_conv_bf16x3_gw<64, MODE_FULL>(p, s);
+    if (mode == MODE_POOL) return launch_conv_bf16x3_gw<64, MODE_POOL>(p, s);
+    return launch_conv_bf16x3_gw<64, MODE_MEANW>(p, s);
   }
 }
 

@@ -101,6 +101,34 @@ def pack_conv_weight_bf16x3(w):
     return torch.stack([lay(hi), lay(lo)], dim=2).contiguous()
 
 
+def conv3x3_bn_relu_bf16x3_gw(x, wfrag, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode=-1):
+    lib = _lib.load()
+    hook = CONV_LAUNCH_HOOK
+    if hook is not None:
+        info = {"B": B, "H": H, "Hp": Hp, "W": W, "Cin": Cin, "Cout": Cout, "mode": mode, "algo": "bf16x3"}
+        hook("pre", info)
+    check(lib.ac_conv3x3_bn_relu_bf16x3_gw(ptr(x), ptr(wfrag), ptr(scale), ptr(shift), ptr(out), B, Hp, H, W, Cin,
+                                           Cout, mode, map_mode, stream()), "ac_conv3x3_bn_relu_bf16x3_gw")
+    if hook is not None:
+        hook("post", info)
+    return out
+
+
+def pack_conv_weight_bf16x3_frag(w):
+    """OIHW f32 -> split bf16 in MFMA fragment order [Cin/32][9][2 ks][Cout/32][2 (hi, lo)][64 lanes][8]:
+    lane = (cout % 32) + 32 * ((cin % 16) // 8), element = cin % 8 (csrc/conv3x3.hip, "gw" kernel)."""
+    cout, cin = w.shape[0], w.shape[1]
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+
+    def lay(t):
+        # (cout, cin, 3, 3) -> (cin, tap, cout) -> [c][ks][h][e][tap][nt][r] -> [c][tap][ks][nt][h][r][e]
+        t = t.permute(1, 2, 3, 0).reshape(cin // 32, 2, 2, 8, 9, cout // 32, 32)
+        return t.permute(0, 4, 1, 5, 2, 6, 3).reshape(cin // 32, 9, 2, cout // 32, 64, 8)
+
+    return torch.stack([lay(hi), lay(lo)], dim=4).contiguous()
+
+
 def pack_conv_weight_winograd(w):
     """OIHW (Cout, Cin, 3, 3) -> U = G g G^T as [Cin/32][4 j][4 i][Cout][32] (csrc/conv3x3_winograd.hip).
     The transform is evaluated in float64 and rounded once to fp32."""

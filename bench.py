@@ -24,6 +24,7 @@ if REPO not in sys.path:
 import torch
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
 
 
 def main():
@@ -35,6 +36,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=10.0, help="clip duration")
     ap.add_argument("--max-length", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f32-path", action="store_true", help="skip the secondary exact-f32 measurement")
     ap.add_argument("--cpu-clips", type=int, default=4, help="clips per CPU-baseline pass")
     ap.add_argument("--cpu-reps", type=int, default=3)
     args = ap.parse_args()
@@ -105,7 +107,12 @@ def main():
 
     ref_steps = min(int((out["unfinished_cnt"].cpu() > 0).sum().item()) + 1, args.max_length)
     algo = model.encoder.cnn.conv_algo
-    mult_ratio = 2.25 if algo == "winograd" else 1.0  # F(2x2,3x3): 16 instead of 36 products per tile
+    # MFMA work issued per algorithmic FLOP: Winograd F(2x2,3x3) needs 16 instead of 36 products per tile;
+    # the split-bf16 path issues three bf16 products (hi*hi, hi*lo, lo*hi) per f32 product
+    issue_ratio = {"winograd": 1.0 / 2.25, "direct": 1.0, "bf16x3": 3.0, "bf16x3_lds": 3.0}[algo]
+    peak = BF16_MFMA_PEAK_TFLOPS if algo.startswith("bf16x3") else FP32_MFMA_PEAK_TFLOPS
+    kname = {"winograd": "conv3x3_wino_kernel<POOL>", "direct": "conv3x3_mfma_kernel<128, POOL>",
+             "bf16x3": "conv3x3_bf16x3_gw_kernel<128, POOL>", "bf16x3_lds": "conv3x3_bf16x3_kernel<128, POOL>"}[algo]
 
     # dominant kernel: conv3x3_mfma_kernel<128, POOL> (conv2 of blocks 2-5)
     flops = sum(2.0 * 9 * i["Cin"] * i["Cout"] * i["H"] * i["W"] * i["B"] for _, _, i in events)
@@ -116,10 +123,27 @@ def main():
     # HBM traffic of the dominant kernel comes from PMC passes (rocprofv3 cannot run inside the timed job):
     # the committed measurement of the same command is attached when present
     traffic = None
-    tpath = os.path.join(REPO, "profiles", "r01_traffic.json")
-    if algo == "winograd" and os.path.exists(tpath):
+    tpath = os.path.join(REPO, "profiles", "r01_traffic_bf16x3.json")
+    if algo == "bf16x3" and os.path.exists(tpath):
         with open(tpath) as f:
             traffic = json.load(f).get("hbm_bytes_per_launch")
+    # the exact-f32 tier (Winograd f32-MFMA convolutions) timed beside the default split-bf16 tier
+    extra = {}
+    if algo.startswith("bf16x3") and not args.no_f32_path:
+        cnn = model.encoder.cnn
+        cnn.conv_algo, cnn._packed = "winograd", None
+        for _ in range(2):
+            model(dict(inp))
+        sync_all()
+        f0 = time.perf_counter()
+        for _ in range(max(2, args.steps // 2)):
+            model(dict(inp))
+        sync_all()
+        fdt = reduce_max_seconds(time.perf_counter() - f0, device=dev)
+        extra["f32_path"] = {"conv_algo": "winograd", "dtype": "f32", "steps": max(2, args.steps // 2),
+                             "ms_per_step": fdt / max(2, args.steps // 2) * 1e3,
+                             "value": world * B * max(2, args.steps // 2) / fdt, "unit": "clips/s"}
+        cnn.conv_algo, cnn._packed = algo, None
     result = None
     if rank == 0:
         clips = world * B * args.steps
@@ -134,25 +158,30 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "bf16x3" if algo.startswith("bf16x3") else "f32",
             "data": "synthetic",
             "config": {"workload": f"Cnn14Rnn-Trm greedy decode, batch {B} per GPU, {args.seconds:g} s @ 32 kHz "
                                    f"synthetic clips, max_length {args.max_length}, vocab {vocab} (BASELINE configs[1])",
                        "global_batch": world * B, "decode_steps_executed": args.max_length,
                        "decode_steps_reference_would_run": ref_steps, "conv_algo": algo,
                        "sharding": f"clips sharded over {world} rank(s), no data-path collective"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": ("conv3x3_wino_kernel<POOL>" if algo == "winograd" else "conv3x3_mfma_kernel<128, POOL>")
-                                   + " (f32 MFMA, conv2+BN+ReLU+pool of blocks 2-5)",
-                         "note": "achieved = ALGORITHMIC direct-convolution FLOPs / time; the Winograd kernel issues "
-                                 "1/2.25 of them as MFMA work, see mfma_issue_frac" if algo == "winograd" else
-                                 "achieved = algorithmic FLOPs / time = MFMA FLOPs issued",
-                         "mfma_issue_frac": achieved / mult_ratio / FP32_MFMA_PEAK_TFLOPS,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic,
+                         "kernel": kname + " (conv2+BN+ReLU+pool of blocks 2-5)",
+                         "note": "achieved = ALGORITHMIC direct-convolution f32 FLOPs / kernel time; "
+                                 "mfma_issue_frac = MFMA FLOPs actually issued (x%.3g) / the MFMA peak of the "
+                                 "operand type" % issue_ratio,
+                         "mfma_issue_frac": achieved * issue_ratio / peak,
                          "launches_timed": n_launch,
                          "avg_launch_ms": ms / n_launch if n_launch else None,
                          "algorithmic_gflop_per_launch": flops / n_launch / 1e9 if n_launch else None},
         }
+        result["config"]["precision"] = (
+            "split-bf16 convolutions (x = hi + lo, hi*hi + hi*lo + lo*hi, f32 accumulate: 2^-16 relative operand "
+            "error), everything else f32; parity: identical greedy/beam token ids, logits within 3e-5 of the "
+            "reference on the golden fixtures" if algo.startswith("bf16x3") else "f32 end to end")
+        if "f32_path" in extra:
+            result["f32_path"] = extra["f32_path"]
         if not args.no_cpu_baseline and world == 1:
             from oracle import cpu_path as O  # the CPU restatement, timed as a reported baseline only
             nc = args.cpu_clips

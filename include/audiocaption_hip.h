@@ -66,6 +66,12 @@ int ac_conv3x3_bn_relu_winograd(const float* in, const float* upk, const float* 
  * [Cin/32][9][2 (hi, lo)][Cout][32] bf16. */
 int ac_conv3x3_bn_relu_bf16x3(const float* in, const void* wpk, const float* scale, const float* shift, float* out,
                               int B, int Hp, int H, int W, int Cin, int Cout, int mode, int map_mode, void* stream);
+/* bf16x3 with the weight fragments read straight from L2 (no LDS weight ring, no per-tap barrier):
+ * wfrag = split weights in MFMA fragment order [Cin/32][9][2 k-steps][Cout/32][2 (hi, lo)][64 lanes][8] bf16,
+ * lane = (cout % 32) + 32 * ((cin % 16) / 8), element = cin % 8. */
+int ac_conv3x3_bn_relu_bf16x3_gw(const float* in, const void* wfrag, const float* scale, const float* shift,
+                                 float* out, int B, int Hp, int H, int W, int Cin, int Cout, int mode,
+                                 int map_mode, void* stream);
 /* First conv (Cin = 1): in [B*Hp][64], w [64][9] (OIHW), out [B*Hp][64][64]. */
 int ac_conv3x3_first(const float* in, const float* w, const float* scale, const float* shift, float* out,
                      int B, int Hp, int H, int W, void* stream);

@@ -135,7 +135,7 @@ def _to_rows(x_nchw, Hp):
     (2, 11, 16, 128, 256, 0), (2, 9, 8, 256, 512, 1), (3, 7, 4, 512, 1024, 0), (3, 6, 4, 1024, 1024, 1),
     (5, 3, 2, 1024, 2048, 0), (5, 3, 2, 2048, 2048, 2), (1, 31, 2, 64, 128, 2), (2, 30, 16, 32, 64, 1)])
 @pytest.mark.parametrize("map_mode", [-1, 0])
-@pytest.mark.parametrize("algo", ["direct", "winograd", "bf16x3"])
+@pytest.mark.parametrize("algo", ["direct", "winograd", "bf16x3", "bf16x3_gw"])
 def test_conv3x3_bn_relu(K, B, H, W, Cin, Cout, mode, map_mode, algo):
     """conv3x3+BN+ReLU(+pool / +mean over W) vs F.conv2d on the CPU.  Tolerance 1e-4 * sqrt(K/576) abs on
     O(1) activations (fp32 accumulation-order differences only)."""
@@ -165,11 +165,14 @@ def test_conv3x3_bn_relu(K, B, H, W, Cin, Cout, mode, map_mode, algo):
     elif algo == "winograd":
         K.conv3x3_bn_relu_winograd(_to_rows(x, Hp).cuda(), K.pack_conv_weight_winograd(w.cuda()), sc.cuda(),
                                    sh.cuda(), out, B, Hp, H, W, Cin, Cout, mode, map_mode)
-    else:
+    elif algo == "bf16x3":
         K.conv3x3_bn_relu_bf16x3(_to_rows(x, Hp).cuda(), K.pack_conv_weight_bf16x3(w.cuda()), sc.cuda(),
                                  sh.cuda(), out, B, Hp, H, W, Cin, Cout, mode, map_mode)
+    else:
+        K.conv3x3_bn_relu_bf16x3_gw(_to_rows(x, Hp).cuda(), K.pack_conv_weight_bf16x3_frag(w.cuda()), sc.cuda(),
+                                    sh.cuda(), out, B, Hp, H, W, Cin, Cout, mode, map_mode)
     tol = 1e-4 * max(1.0, math.sqrt(9 * Cin / 576))
-    if algo == "bf16x3":
+    if algo.startswith("bf16x3"):
         tol *= 10  # split-bf16 tier: 2^-16 relative operand error (f32: 2^-24) on O(1..10) outputs
     assert _report(f"conv[{algo}] {B}x{H}x{W} {Cin}->{Cout} mode{mode}", out.reshape(want_rows.shape), want_rows) < tol
 

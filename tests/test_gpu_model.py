@@ -36,7 +36,7 @@ def _cnn_from_logmel(cnn, lms):
     W = 64
     from audiocaption_amd.cnn_encoder import CHANNELS
     conv = {"winograd": K.conv3x3_bn_relu_winograd, "direct": K.conv3x3_bn_relu,
-            "bf16x3": K.conv3x3_bn_relu_bf16x3}[cnn.conv_algo]
+            "bf16x3": K.conv3x3_bn_relu_bf16x3_gw, "bf16x3_lds": K.conv3x3_bn_relu_bf16x3}[cnn.conv_algo]
     blocks = []
     for b in range(6):
         cin, cout = CHANNELS[b], CHANNELS[b + 1]
@@ -69,6 +69,24 @@ def test_g1_cnn14_vs_reference_golden(hip_model, golden_dir):
         np.testing.assert_allclose(blk.double().sum(dim=(2, 3)).numpy(), g[f"block{b + 1}_sum"], rtol=2e-5, atol=5e-2)
     assert attn.shape == (2, 31, 2048)
     assert _maxdiff("attn_emb", attn, g["attn_emb"]) < 2e-4
+
+
+@pytest.mark.parametrize("algo", ["direct", "winograd", "bf16x3", "bf16x3_lds"])
+def test_g1_cnn14_every_conv_algorithm(hip_model, golden_dir, algo):
+    """Every conv kernel family against the reference's attn_emb (bar 2e-4 abs; f32 kernels land at ~5e-6,
+    the split-bf16 ones at ~2e-5)."""
+    from audiocaption_amd import procedural as P
+    g = _load(golden_dir, "g1_cnn14.npz")
+    cnn = hip_model.encoder.cnn
+    saved = cnn.conv_algo
+    try:
+        cnn.conv_algo = algo
+        lms = torch.from_numpy(P.synthetic_logmel(2, 1001)).cuda()
+        attn, _ = _cnn_from_logmel(cnn, lms)
+        assert _maxdiff(f"attn_emb[{algo}]", attn, g["attn_emb"]) < 2e-4
+    finally:
+        cnn.conv_algo = saved
+        cnn._packed = None
 
 
 def test_g2_gru_vs_reference_golden(hip_model, golden_dir):

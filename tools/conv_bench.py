@@ -50,9 +50,12 @@ def main():
             elif algo == "winograd":
                 wp = K.pack_conv_weight_winograd(w)
                 fn = lambda: K.conv3x3_bn_relu_winograd(x, wp, sc, sh, out, B, Hp, H, W, Cin, Cout, mode)
-            else:
+            elif algo == "bf16x3":
                 wp = K.pack_conv_weight_bf16x3(w)
                 fn = lambda: K.conv3x3_bn_relu_bf16x3(x, wp, sc, sh, out, B, Hp, H, W, Cin, Cout, mode)
+            else:
+                wp = K.pack_conv_weight_bf16x3_frag(w)
+                fn = lambda: K.conv3x3_bn_relu_bf16x3_gw(x, wp, sc, sh, out, B, Hp, H, W, Cin, Cout, mode)
             fn()
             torch.cuda.synchronize()
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
