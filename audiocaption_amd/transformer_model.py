@@ -90,10 +90,74 @@ class CaptionModel(nn.Module, CaptionMetaMixin):
             "(dbs / gumbel / top-k / top-p sampling are out of scope, SURVEY.md §2.1 row 7)")
 
 
+class PendingCaption:
+    """Handle of a batch submitted with ``TransformerModel.forward_async``: ``result()`` blocks until the
+    batch's token ids have reached the host and returns the same dict ``model(input_dict)`` would."""
+
+    def __init__(self, done_event, host_seq, host_logprob, output):
+        self._done, self._seq, self._lp, self._out = done_event, host_seq, host_logprob, output
+
+    def result(self):
+        self._done.synchronize()
+        out = dict(self._out)
+        out["seq"] = self._seq.clone()
+        out["sampled_logprob"] = self._lp.clone()
+        release = getattr(self, "_release", None)
+        if release is not None:  # hand the pinned staging buffers back to the pool
+            release()
+            self._release = None
+        return out
+
+
 class TransformerModel(CaptionModel):
 
     def __init__(self, encoder, decoder, **kwargs):
         super().__init__(encoder, decoder, **kwargs)
+        self._streams = None
+        self._pinned = {}
+
+    # ---- throughput mode: encoder of batch i+1 overlaps the (latency-bound) decode of batch i ---------
+    def forward_async(self, input_dict):
+        """Submit one greedy-decoding batch without waiting for it.  The encoder runs on one HIP stream, the
+        decoder (a chain of ~370 tiny latency-bound kernels) on another, so consecutive submissions overlap:
+        the decode of batch i fills the gaps of the matrix-bound encoder of batch i+1.  Results are identical
+        to ``model(input_dict)``; only the schedule differs.  Returns a ``PendingCaption``."""
+        if input_dict.get("mode") != "inference" or input_dict.get("sample_method", "greedy") != "greedy":
+            raise NotImplementedError("forward_async: greedy inference only; use model(input_dict) otherwise")
+        dev = input_dict["wav"].device
+        if self._streams is None or self._streams[0].device != dev:
+            self._streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+        enc_s, dec_s = self._streams
+        cur = torch.cuda.current_stream(dev)
+        enc_s.wait_stream(cur)  # inputs produced on the caller's stream
+        with torch.cuda.stream(enc_s):
+            enc = self.encoder(input_dict)
+            enc_done = torch.cuda.Event()
+            enc_done.record(enc_s)
+        max_length = int(input_dict.get("max_length", self.max_length))
+        B = enc["attn_emb"].shape[0]
+        with torch.cuda.stream(dec_s):
+            dec_s.wait_event(enc_done)
+            for t in enc.values():
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(dec_s)
+            res = self.decoder.greedy(enc["attn_emb"], enc["attn_emb_len"], max_length, self.start_idx,
+                                      self.end_idx, self.pad_idx)
+            key = (B, max_length)
+            pool = self._pinned.setdefault(key, [])
+            if not pool:
+                pool.append((torch.empty(B, max_length, dtype=torch.int64).pin_memory(),
+                             torch.empty(B, max_length, dtype=torch.float32).pin_memory()))
+            host_seq, host_lp = pool.pop()
+            host_seq.copy_(res["seq"], non_blocking=True)
+            host_lp.copy_(res["sampled_logprob"], non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(dec_s)
+        out = {"logit": res["logit"], "embed": res["embed"], "unfinished_cnt": res["unfinished_cnt"]}
+        out.update(enc)
+        pending = PendingCaption(done, host_seq, host_lp, out)
+        pending._release = lambda: pool.append((host_seq, host_lp))
+        return pending
 
     # ---- greedy (base.py:152-218) -----------------------------------------------------------------
     def greedy_search(self, input_dict):

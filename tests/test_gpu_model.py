@@ -178,3 +178,18 @@ def test_cnn14_standalone_fc_emb(hip_model, state4981):
     pooled = a.masked_fill(~mask, float("-inf")).max(1).values + (a * mask).sum(1) / lens[:, None]
     fc = F.relu(F.linear(pooled, state4981["encoder.cnn.fc1.weight"], state4981["encoder.cnn.fc1.bias"]))
     assert _maxdiff("cnn fc_emb", out["fc_emb"], fc) < 5e-4
+
+
+def test_forward_async_equals_blocking_forward(hip_model):
+    """Throughput mode (two streams, overlapped steps) returns exactly what the blocking call returns."""
+    from audiocaption_amd import procedural as P
+    wavs = [torch.from_numpy(P.synthetic_wav(3, 48000, seed=s_, varied=True)).cuda() for s_ in (1, 2, 3)]
+    inputs = [{"mode": "inference", "wav": w, "wav_len": [48000, 40000, 33000], "specaug": False,
+               "sample_method": "greedy", "max_length": 8} for w in wavs]
+    want = [hip_model(dict(i)) for i in inputs]
+    pend = [hip_model.forward_async(dict(i)) for i in inputs]
+    got = [p.result() for p in pend]
+    for w, g in zip(want, got):
+        assert torch.equal(w["seq"], g["seq"])
+        assert torch.equal(w["logit"], g["logit"]) and torch.equal(w["attn_emb"], g["attn_emb"])
+        assert torch.equal(w["sampled_logprob"], g["sampled_logprob"])
