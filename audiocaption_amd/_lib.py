@@ -31,6 +31,7 @@ class AcTrmWeights(ctypes.Structure):
 
 
 _I, _L, _F, _P = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p
+_U64 = ctypes.c_ulonglong
 _WP = ctypes.POINTER(AcTrmWeights)
 
 # name -> (restype, argtypes); must list every symbol of include/audiocaption_hip.h
@@ -54,6 +55,33 @@ SIGNATURES = {
     "ac_trm_forward_tokens": (_I, [_WP, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
     "ac_trm_beam_step": (_I, [_WP, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P]),
     "ac_trm_beam_reorder": (_I, [_WP, _I, _I, _I, _P, _P, _P]),
+    # training step (csrc/train.hip)
+    "ac_gemm": (_I, [_P, _L, _L, _P, _L, _L, _P, _L, _I, _I, _I, _P, _I, _F, _I, _F, _U64, _P, _L, _P]),
+    "ac_dropout": (_I, [_P, _P, _L, _F, _U64, _P, _L, _P]),
+    "ac_mask_pos_scale": (_I, [_P, _P, _L, _F, _P]),
+    "ac_build_prefix": (_I, [_P, _I, _P, _I, _P, _I, _I, _P, _L, _I, _I, _P]),
+    "ac_embed_fwd": (_I, [_P, _P, _P, _P, _P, _L, _L, _I, _F, _U64, _F, _U64, _P, _P]),
+    "ac_embed_bwd": (_I, [_P, _P, _P, _L, _I, _F, _U64, _F, _U64, _P, _P]),
+    "ac_dropadd_ln_fwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _L, _L, _I, _F, _U64, _P, _F, _P]),
+    "ac_dropadd_ln_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _L, _P, _P, _L, _I, _F, _U64, _P, _F, _P]),
+    "ac_attn_seq_fwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I,
+                             _I, _I, _I, _F, _U64, _P, _P]),
+    "ac_attn_seq_bwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _I, _I, _P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _I,
+                             _I, _I, _I, _I, _I, _F, _U64, _P, _P]),
+    "ac_gather_rows": (_I, [_P, _P, _P, _L, _I, _P]),
+    "ac_scatter_add_rows": (_I, [_P, _P, _P, _L, _I, _P]),
+    "ac_sum_replicas": (_I, [_P, _P, _L, _I, _P]),
+    "ac_rows_mean_w": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "ac_transpose": (_I, [_P, _P, _I, _I, _I, _P]),
+    "ac_colsum": (_I, [_P, _L, _P, _L, _I, _P]),
+    "ac_argmax_rows": (_I, [_P, _L, _I, _I, _P, _L, _P]),
+    "ac_label_smoothing_loss": (_I, [_P, _P, _L, _P, _I, _I, _I, _F, _F, _P, _P, _P, _F, _P]),
+    "ac_gru_layer_train": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "ac_gru_layer_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "ac_grad_sumsq": (_I, [_P, _L, _P, _P]),
+    "ac_clip_coef": (_I, [_P, _F, _F, _P]),
+    "ac_scale_by_coef": (_I, [_P, _L, _P, _P]),
+    "ac_adam_step": (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _I, _P]),
 }
 
 _lib = None

@@ -168,6 +168,106 @@ int ac_trm_beam_step(const ac_trm_weights* w, const float* memkv, const int* mem
 int ac_trm_beam_reorder(const ac_trm_weights* w, int R, int max_len, int t, const int* src_row, float* ws,
                         void* stream);
 
+/* ================================== training step ==================================
+ * The reference trains GRU + decoder on the frozen Cnn14 with scheduled sampling: step t runs the decoder on a
+ * (N, t+1) prefix and keeps the last position's logit (base.py:131-137,152-199, transformer_model.py:34-57).  The
+ * host keeps every prefix pass in one row space (row = one token position of one pass); forward kernels work on the
+ * row range of a pass, backward kernels on all rows at once.  Dropout masks are a counter hash of
+ * (seed, element index) - splitmix64, keep iff the top 32 bits >= p * 2^32, kept values scaled by 1/(1-p) - so the
+ * backward regenerates them and the CPU oracle reproduces them.  Every dropout site takes `seed` plus an optional
+ * device word `seed_dev`: the effective seed is seed + (*seed_dev << 16), which lets a captured HIP graph draw fresh
+ * masks on every replay (the host bumps the device word between replays).                                          */
+
+/* C[M][N] (row pitch ldc) = epi( sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] ): X W^T / dY W / dY^T X with one kernel
+ * (replaces F.linear and its autograd, e.g. transformer_decoder.py:86-101, rnn_encoder.py:41).
+ * epi: + bias[n], ReLU, dropout(drop_p, drop_seed, index (row0+m)*N+n), + beta*C.  splitk > 1: K is cut into splitk
+ * slices whose partial sums are atomically ADDED to C (weight gradients; needs beta == 1, no bias/relu/dropout). */
+int ac_gemm(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc, int M, int N,
+            int K, const float* bias, int relu, float beta, int splitk, float drop_p, unsigned long long drop_seed,
+            const unsigned long long* seed_dev, long row0, void* stream);
+/* y[i] = x[i] * mask(seed, idx0 + i): F.dropout (cnn_encoder.py:432-442, nn.GRU inter-layer dropout); applying it to
+ * a gradient with the same seed is its backward. */
+int ac_dropout(const float* x, float* y, long n, float p, unsigned long long seed, const unsigned long long* seed_dev,
+               long idx0, void* stream);
+/* g[i] = h[i] > 0 ? g[i] * scale : 0 - backward of dropout(relu(.)) given its output h (FFN hidden). */
+int ac_mask_pos_scale(float* g, const float* h, long n, float scale, void* stream);
+/* Decoder input tokens of scheduled-sampling step t (transformer_model.py:44-52): word[row0 + n*L + l] =
+ * use_cap[t] ? cap[n][l] : (l == 0 ? start_idx : seq[n][l-1]); cap int64 [N][cap_ld], seq int32 [N][seq_ld]. */
+int ac_build_prefix(const long long* cap, int cap_ld, const int* seq, int seq_ld, const int* use_cap, int t,
+                    int start_idx, int* word, long row0, int N, int L, void* stream);
+/* x[row] = dropB(dropA(E[word[row]]) * sqrt(d) + pe[pos[row]]) for rows row0..row0+rows (transformer_decoder.py:88-90;
+ * in_dropout and PositionalEncoding's dropout), and its backward into the embedding table (atomic adds, all rows). */
+int ac_embed_fwd(const float* emb, const float* pe, const int* word, const int* pos, float* x, long row0, long rows,
+                 int d, float pa, unsigned long long seed_a, float pb, unsigned long long seed_b,
+                 const unsigned long long* seed_dev, void* stream);
+int ac_embed_bwd(const float* dx, const int* word, float* demb, long rows, int d, float pa, unsigned long long seed_a,
+                 float pb, unsigned long long seed_b, const unsigned long long* seed_dev, void* stream);
+/* pre = res + dropout(x); y = LayerNorm(pre) over d = 256 columns (post-LN residual blocks of
+ * nn.TransformerDecoderLayer; attn_proj's Dropout -> LayerNorm with res = NULL, transformer_decoder.py:38-43).
+ * xmod > 0: x has only xmod rows and row r reads x[r % xmod] (the projected audio memory is shared by all passes, only
+ * its dropout mask differs). */
+int ac_dropadd_ln_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* pre, float* y,
+                      long row0, long rows, long xmod, int d, float p, unsigned long long seed,
+                      const unsigned long long* seed_dev, float eps, void* stream);
+/* Backward over rows 0..rows: dpre -> dres (= or += when accumulate), dpre * mask [* (relu_src > 0)] -> dx,
+ * dgamma / dbeta accumulated atomically.  dx or dres may be NULL. */
+int ac_dropadd_ln_bwd(const float* dy, const float* pre, const float* gamma, float* dx, float* dres, int accumulate,
+                      const float* relu_src, long relu_mod, float* dgamma, float* dbeta, long rows, int d, float p,
+                      unsigned long long seed, const unsigned long long* seed_dev, float eps, void* stream);
+/* Multi-head attention over short sequences (nn.MultiheadAttention inside nn.TransformerDecoderLayer), head_dim 64,
+ * one workgroup per (sequence, head).  Sequence s: qlen[s] queries at rows qrow0[s].., klen[s] keys at rows
+ * krow0[s]...  Key j is visible to query i iff j < kvalid[s] (if given), j <= i (if causal) and
+ * word[krow0[s] + j] != pad_idx (if word given).  P (softmax before dropout) is kept at
+ * P[((s*nhead + h)*pl + i)*ptk + j]; that index also drives the attention dropout.  Launch covers sequences
+ * seq0 .. seq0+nseq; lmax / tkmax bound qlen / klen over the launch. */
+int ac_attn_seq_fwd(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv, float* o, long ldo,
+                    float* P, int pl, int ptk, const int* qrow0, const int* qlen, const int* krow0, const int* klen,
+                    const int* kvalid, const int* word, int pad_idx, int causal, int seq0, int nseq, int nhead,
+                    int head_dim, int lmax, int tkmax, float drop_p, unsigned long long seed,
+                    const unsigned long long* seed_dev, void* stream);
+int ac_attn_seq_bwd(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv, const float* P, int pl,
+                    int ptk, const float* dout, long lddo, float* dq, long lddq, float* dk, long lddk, float* dv,
+                    long lddv, const int* qrow0, const int* qlen, const int* krow0, const int* klen, int seq0, int nseq,
+                    int nhead, int head_dim, int lmax, int tkmax, float drop_p, unsigned long long seed,
+                    const unsigned long long* seed_dev, void* stream);
+/* dst[i] = src[index[i]] / dst[index[i]] += src[i] over rows of C floats (classifier on each pass's last position,
+ * base.py:181-183). */
+int ac_gather_rows(const float* src, const int* index, float* dst, long nrows, int C, void* stream);
+int ac_scatter_add_rows(const float* src, const int* index, float* dst, long nrows, int C, void* stream);
+/* out[r] = sum_t x[t*n + r], t < reps (gradient of the projected audio memory shared by all passes). */
+int ac_sum_replicas(const float* x, float* out, long n, int reps, void* stream);
+/* Cnn14 head when dropout sits between the last block and the mel mean (train mode, cnn_encoder.py:441-444):
+ * out[b][h][c] = mean_w x[(b*Hp + h)][w][c] for h < H. */
+int ac_rows_mean_w(const float* x, float* out, int B, int Hp, int H, int W, int C, void* stream);
+/* dst[b][c][r] = src[b][r][c] (k-major copy of W_hh for the recurrence kernel). */
+int ac_transpose(const float* src, float* dst, int batch, int rows, int cols, void* stream);
+/* out[n] += sum_m x[m*ld + n] (bias gradients). */
+int ac_colsum(const float* x, long ld, float* out, long M, int N, void* stream);
+/* out[r*out_ld] = argmax_v logit[r*ld + v], first index on ties (sample_next_word "greedy", base.py:206-209). */
+int ac_argmax_rows(const float* logit, long ld, int rows, int V, int* out, long out_ld, void* stream);
+/* LabelSmoothingLoss (loss.py:51-74): logit [N][T][V], tgt int64 [N][tgt_ld], tgt_len int32 [N]; row_loss [N*T];
+ * loss[0] = inv_count * sum(row_loss); dlogit (optional) = gscale * (softmax - q) on valid rows, 0 elsewhere. */
+int ac_label_smoothing_loss(const float* logit, const long long* tgt, long tgt_ld, const int* tgt_len, int N, int T, int V,
+                            float smoothing, float inv_count, float* row_loss, float* loss, float* dlogit, float gscale,
+                            void* stream);
+/* ac_gru_layer that also keeps (r, z, n, W_hn h + b_hn) per (clip, step, direction): save [B][T][2][4H]. */
+int ac_gru_layer_train(const float* gx, const float* whhT, const float* bhh, const int* lens, float* out, float* save,
+                       int B, int T, int hidden, void* stream);
+/* Backward through time of one bidirectional layer (autograd of nn.GRU under pack_padded_sequence,
+ * model_util.py:10-27): dout/out [B][T][2H], whh [2][3H][H] -> gate gradients dgx (input side), dgh (hidden side)
+ * [B][T][2][3H] and the previous hidden state of every step hprev [B][T][2][H]; weight gradients are GEMMs on those. */
+int ac_gru_layer_bwd(const float* dout, const float* out, const float* save, const float* whh, const int* lens,
+                     float* dgx, float* dgh, float* hprev, int B, int T, int hidden, void* stream);
+/* Optimiser on flat buffers (run.py:122-126, torch.optim.Adam with L2 weight decay, cnn14rnn_trm.yaml:42-46):
+ * norm_state[0] += sum g^2;  ac_clip_coef: [1] = sqrt([0]) / grad_div (total norm of the averaged gradient),
+ * [2] = min(1, max_norm / (norm + 1e-6)) / grad_div (max_norm <= 0: no clipping);  ac_scale_by_coef: x *= [2];
+ * ac_adam_step: g' = g * [2] (norm_state may be NULL) + wd * p, then Adam's update for 1-based `step`. */
+int ac_grad_sumsq(const float* g, long n, float* norm_state, void* stream);
+int ac_clip_coef(float* norm_state, float max_norm, float grad_div, void* stream);
+int ac_scale_by_coef(float* x, long n, const float* norm_state, void* stream);
+int ac_adam_step(float* p, const float* g, float* m, float* v, long n, const float* norm_state, float lr, float beta1,
+                 float beta2, float eps, float weight_decay, int step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -202,6 +202,90 @@ def main():
                         loss=np.array(float(loss)))
     print(f"  G7 label-smoothing loss = {float(loss):.6f}")
 
+
+    # ---- G8: one TRAINING step (A13-A16), dropout p = 0 so that it is deterministic --------------------
+    # scheduled-sampling forward (base.py:131-199, transformer_model.py:34-57), LabelSmoothingLoss, backward,
+    # clip_grad_norm_(1.0) and one torch.optim.Adam(lr 5e-4, weight_decay 1e-6) update, all by the reference.
+    import copy
+    import random
+    from oracle import train_path as OT
+    torch.set_grad_enabled(True)
+    cfg0 = copy.deepcopy(cfg["model"])
+    cfg0["decoder"]["args"]["dropout"] = 0.0
+    cfg0["encoder"]["rnn"]["args"]["dropout"] = 0.0
+    model0 = train_util.init_model_from_config(cfg0, print_fn=lambda s: None)
+    model0.load_state_dict(state, strict=True)
+    model0.train()
+    model0.encoder.cnn.eval()   # no F.dropout inside the frozen Cnn14 (cnn_encoder.py:432-442) for this fixture
+    gen = torch.Generator().manual_seed(11)
+    cap = torch.randint(4, V, (4, 13), generator=gen)
+    cap_len = np.array([13, 10, 8, 12])
+    cap[:, 0] = 1
+    for i, n in enumerate(cap_len):
+        cap[i, n - 1] = 2
+        cap[i, n:] = 0
+    _PRESET["lms"] = lms4
+    loss_fn = LabelSmoothingLoss(smoothing=0.1)
+    g8 = {"cap": cap.numpy(), "cap_len": cap_len, "wav_len": np.array(wav_len)}
+    trainable = [(k, p_) for k, p_ in model0.named_parameters() if p_.requires_grad]
+    assert sorted(k for k, _ in trainable) == sorted(OT.trainable_keys(state)), "trainable key sets differ"
+    idx_gen = np.random.default_rng(3)
+    sample_idx = {k: idx_gen.integers(0, p_.numel(), size=min(64, p_.numel())) for k, p_ in trainable}
+    for tag, ss_ratio in (("ss", 0.7), ("tf", 1)):
+        model0.load_state_dict(state, strict=True)
+        model0.zero_grad(set_to_none=True)
+        random.seed(5)
+        use_cap = [random.random() < ss_ratio for _ in range(cap.shape[1] - 1)] if ss_ratio != 1 else []
+        random.seed(5)
+        out = model0({"mode": "train", "wav": torch.zeros(4, 320000), "wav_len": wav_len, "specaug": False,
+                      "cap": cap, "cap_len": cap_len, "ss_ratio": ss_ratio})
+        out["tgt"] = cap[:, 1:]
+        out["tgt_len"] = torch.as_tensor(cap_len - 1)
+        loss = loss_fn(out)
+        loss.backward()
+        total_norm = torch.nn.utils.clip_grad_norm_(model0.parameters(), 1.0)
+        raw = {k: p_.grad.detach().clone() / min(1.0, float(1.0 / (total_norm + 1e-6))) for k, p_ in trainable}
+        opt = torch.optim.Adam([p_ for _, p_ in trainable], lr=5e-4, weight_decay=1e-6)
+        before = {k: p_.detach().clone() for k, p_ in trainable}
+        opt.step()
+        # the same step in the oracle
+        o = OT.train_step_grads(state, O.cnn14_from_logmel(state, lms4), O.cnn14_feat_len(wav_len), cap, cap_len,
+                                use_cap, p_dec=0.0, p_rnn=0.0, teacher_forcing=(ss_ratio == 1))
+        cmp(f"G8 {tag} logit", o["logit"], out["logit"].detach())
+        report[f"G8 {tag} loss"] = abs(float(o["loss"]) - float(loss))
+        worst_g = 0.0
+        for k, _ in trainable:
+            scale = float(raw[k].abs().max()) + 1e-12
+            worst_g = max(worst_g, float((o["grads"][k] - raw[k]).abs().max()) / scale)
+        report[f"G8 {tag} grads (rel. to max)"] = worst_g
+        print(f"  oracle vs reference  G8 {tag} loss {float(loss):.6f}  worst relative grad diff {worst_g:.3e}")
+        if ss_ratio != 1:
+            assert torch.equal(o["seq"], out["seq"]), "greedy tokens of the training forward differ"
+        params = {k: state[k].clone() for k, _ in trainable}
+        m1 = {k: torch.zeros_like(v) for k, v in params.items()}
+        m2 = {k: torch.zeros_like(v) for k, v in params.items()}
+        o_norm = OT.clip_and_adam(params, o["grads"], m1, m2, 1)
+        report[f"G8 {tag} grad norm (relative)"] = abs(float(o_norm) - float(total_norm)) / float(total_norm)
+        worst_p = max(float((params[k] - p_.detach()).abs().max()) for k, p_ in trainable)
+        report[f"G8 {tag} params after Adam"] = worst_p
+        print(f"  G8 {tag}: grad norm {float(total_norm):.6f}; worst |param diff| after Adam {worst_p:.3e}")
+        g8[f"{tag}_use_cap"] = np.array(use_cap, dtype=np.int32)
+        g8[f"{tag}_loss"] = np.array(float(loss))
+        g8[f"{tag}_total_norm"] = np.array(float(total_norm))
+        if "seq" in out:
+            g8[f"{tag}_seq"] = out["seq"].numpy()
+        g8[f"{tag}_logit_top_val"] = out["logit"].detach().topk(8, dim=-1).values.numpy()
+        g8[f"{tag}_logit_top_idx"] = out["logit"].detach().topk(8, dim=-1).indices.numpy()
+        for k, p_ in trainable:
+            g8[f"{tag}_gnorm/{k}"] = np.array(float(raw[k].norm()))
+            g8[f"{tag}_gsum/{k}"] = np.array(float(raw[k].double().sum()))
+            g8[f"{tag}_gsample/{k}"] = raw[k].reshape(-1)[sample_idx[k]].numpy()
+            g8[f"{tag}_delta/{k}"] = (p_.detach() - before[k]).reshape(-1)[sample_idx[k]].numpy()
+    for k in sample_idx:
+        g8[f"sample_idx/{k}"] = sample_idx[k]
+    np.savez_compressed(os.path.join(out_dir, "g8_train.npz"), **g8)
+    torch.set_grad_enabled(False)
+
     with open(os.path.join(out_dir, "REPORT.txt"), "w") as f:
         f.write("max |oracle - reference| per fixture (written by make_golden.py, torch %s)\n" % torch.__version__)
         for k, v in report.items():

@@ -31,6 +31,31 @@ def test_library_exports_every_declared_symbol(lib_path):
     assert lib.ac_abi_version() == 1
 
 
+def test_ctypes_signatures_match_the_header_prototypes():
+    """Argument count and coarse type (pointer / integer / float) of every prototype vs the ctypes table."""
+    header = open(os.path.join(REPO, "include", "audiocaption_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    protos = re.findall(r"\b(?:int|long)\s+(ac_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", header)
+    assert len(protos) == len(_lib.SIGNATURES)
+    for name, args in protos:
+        args = [a.strip() for a in args.split(",") if a.strip() and a.strip() != "void"]
+        want = _lib.SIGNATURES[name][1]
+        assert len(args) == len(want), f"{name}: header has {len(args)} parameters, ctypes table {len(want)}"
+        for a, w in zip(args, want):
+            if "*" in a:
+                kind = "ptr"
+            elif a.startswith("float"):
+                kind = "float"
+            else:
+                kind = "int"
+            got = ("ptr" if w in (ctypes.c_void_p, _lib._WP) else
+                   "float" if w is ctypes.c_float else "int")
+            assert kind == got, f"{name}: parameter '{a}' is declared {kind} but bound as {got}"
+            if kind == "int":
+                size = 8 if ("long" in a.split() or "int64_t" in a) else 4
+                assert ctypes.sizeof(w) == size, f"{name}: parameter '{a}' width mismatch"
+
+
 def test_argument_validation_without_gpu(lib_path):
     lib = _lib.load()
     # rejected before any HIP call: null pointers / bad sizes -> AC_ERR_ARG
