@@ -75,7 +75,7 @@ SIGNATURES = {
     "ac_transpose": (_I, [_P, _P, _I, _I, _I, _P]),
     "ac_colsum": (_I, [_P, _L, _P, _L, _I, _P]),
     "ac_argmax_rows": (_I, [_P, _L, _I, _I, _P, _L, _P]),
-    "ac_label_smoothing_loss": (_I, [_P, _P, _L, _P, _I, _I, _I, _F, _F, _P, _P, _P, _F, _P]),
+    "ac_label_smoothing_loss": (_I, [_P, _P, _L, _P, _I, _I, _I, _F, _F, _P, _P, _P, _F, _P, _P]),
     "ac_gru_layer_train": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ac_gru_layer_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ac_grad_sumsq": (_I, [_P, _L, _P, _P]),
@@ -85,6 +85,19 @@ SIGNATURES = {
 }
 
 _lib = None
+
+# Bumped whenever a HIP kernel rewrites parameters in place (fused Adam, parameter flattening): torch's tensor
+# version counters do not see those writes, so the packed-weight caches of the inference path key on this as well.
+PARAM_GENERATION = 0
+
+
+def bump_param_generation():
+    global PARAM_GENERATION
+    PARAM_GENERATION += 1
+
+
+def param_generation():
+    return PARAM_GENERATION
 
 
 class HipLibraryError(RuntimeError):

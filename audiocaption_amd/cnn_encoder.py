@@ -94,7 +94,7 @@ class Cnn14Encoder(nn.Module):
             blk = getattr(self, f"conv_block{b + 1}")
             for conv, bn in ((blk.conv1, blk.bn1), (blk.conv2, blk.bn2)):
                 tensors += [conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var]
-        key = tuple((t.data_ptr(), t._version) for t in tensors) + (self.conv_algo,)
+        key = tuple((t.data_ptr(), t._version) for t in tensors) + (self.conv_algo, K._lib.param_generation())
         if self._packed is not None and key == self._packed_key:
             return self._packed
         with torch.no_grad():
@@ -139,8 +139,12 @@ class Cnn14Encoder(nn.Module):
         Hp = [hp6 << (5 - k) for k in range(6)]
         return T, H, Hp
 
-    def encode(self, wav):
-        """wav (B, L) on the ROCm device -> attn_emb (B, T // 32, 2048)."""
+    def encode(self, wav, dropout=None):
+        """wav (B, L) on the ROCm device -> attn_emb (B, T // 32, 2048).
+
+        ``dropout = (p, op_code, seed_dev_ptr)``: the train-mode forward of the frozen network, F.dropout(p) after
+        every conv block (cnn_encoder.py:431-442); the mask of block b is the counter hash of csrc/train.hip with seed
+        op_code + b (+ the device-side step seed) over the block's output buffer."""
         if wav.dim() != 2:
             raise ValueError("wav must be (batch, samples)")
         dev = wav.device
@@ -167,16 +171,25 @@ class Cnn14Encoder(nn.Module):
             if b < 5:
                 conv(full, w2, s2, t2, pooled, B, Hp[b], H[b], W, cout, cout, 1)
                 W //= 2
+                if dropout is not None:
+                    K.dropout_(pooled, B * Hp[b + 1] * W * cout, dropout[0], dropout[1] + b, dropout[2])
             else:
                 attn = torch.empty(B, H[5], cout, device=dev, dtype=torch.float32)
-                conv(full, w2, s2, t2, attn, B, Hp[b], H[b], W, cout, cout, 2)
+                if dropout is None:
+                    conv(full, w2, s2, t2, attn, B, Hp[b], H[b], W, cout, cout, 2)
+                else:  # dropout sits between the last block and the mean over mel bins
+                    last = self._buf("last", B * Hp[5] * W * cout, dev)
+                    conv(full, w2, s2, t2, last, B, Hp[b], H[b], W, cout, cout, 0)
+                    K.dropout_(last, B * Hp[5] * W * cout, dropout[0], dropout[1] + b, dropout[2])
+                    K.rows_mean_w(last, attn, B, Hp[5], H[5], W, cout)
         return attn
 
     def forward(self, input_dict, skip_fc=False):
         if self.training:
             raise NotImplementedError(
-                "Cnn14Encoder (HIP path): only the eval-mode forward exists so far; the training forward "
-                "(dropout, SpecAugment, backward) is not built yet")
+                "Cnn14Encoder (HIP path): in train mode the (frozen) Cnn14 only runs inside the whole-model training "
+                "step (audiocaption_amd.train.TrainEngine); SpecAugment and the backward through the convolutions "
+                "are not built")
         wav = input_dict["wav"]
         attn_emb = self.encode(wav)
         feat_length = cnn14_feat_len(input_dict["wav_len"], self.hop_length, self.downsample_ratio)

@@ -530,7 +530,8 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* logit, lo
 // =========================================================================================================
 __global__ __launch_bounds__(256) void xent_kernel(const float* logit, const long long* tgt, long tgt_ld,
                                                    const int* tgt_len, int T, int V, float smoothing,
-                                                   float* row_loss, float* dlogit, float gscale) {
+                                                   float* row_loss, float* dlogit, float gscale,
+                                                   const float* gscale_dev) {
   __shared__ float red[4];
   const int row = blockIdx.x, n = row / T, t = row % T;
   const float* z = logit + (long)row * V;
@@ -571,6 +572,7 @@ __global__ __launch_bounds__(256) void xent_kernel(const float* logit, const lon
     row_loss[row] = lse - off * (sz - z[target]) - conf * z[target];
   }
   if (dlogit) {
+    if (gscale_dev) gscale *= gscale_dev[0];
     const float inv = 1.0f / se;
     for (int v = threadIdx.x; v < V; v += 256) {
       const float q = v == target ? conf : off;
@@ -935,10 +937,10 @@ int ac_argmax_rows(const float* logit, long ld, int rows, int V, int* out, long 
 
 int ac_label_smoothing_loss(const float* logit, const long long* tgt, long tgt_ld, const int* tgt_len, int N, int T, int V,
                             float smoothing, float inv_count, float* row_loss, float* loss, float* dlogit, float gscale,
-                            void* stream) {
+                            const float* gscale_dev, void* stream) {
   if (!logit || !tgt || !tgt_len || !row_loss || !loss || N <= 0 || T <= 0 || V <= 1) return AC_ERR_ARG;
   hipLaunchKernelGGL(xent_kernel, dim3(N * T), dim3(256), 0, (hipStream_t)stream, logit, tgt, tgt_ld, tgt_len, T, V,
-                     smoothing, row_loss, dlogit, gscale);
+                     smoothing, row_loss, dlogit, gscale, gscale_dev);
   hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, row_loss, (long)N * T, inv_count, loss);
   return ac_check_launch();
 }

@@ -192,3 +192,16 @@ def add_layernorm(x, y, w, b, out=None):
     check(lib.ac_add_layernorm(ptr(x), ptr(y), ptr(w), ptr(b), ptr(out), rows, d, x.stride(0),
                                y.stride(0) if y is not None else 0, out.stride(0), stream()), "ac_add_layernorm")
     return out
+
+
+def dropout_(x, n, p, seed, seed_dev=None):
+    """In-place counter-hash dropout over the first n floats of x (csrc/train.hip)."""
+    lib = _lib.load()
+    check(lib.ac_dropout(ptr(x), ptr(x), n, float(p), int(seed), seed_dev, 0, stream()), "ac_dropout")
+    return x
+
+
+def rows_mean_w(x, out, B, Hp, H, W, C):
+    lib = _lib.load()
+    check(lib.ac_rows_mean_w(ptr(x), ptr(out), B, Hp, H, W, C, stream()), "ac_rows_mean_w")
+    return out

@@ -40,7 +40,7 @@ class RnnEncoder(nn.Module):
 
     def _pack(self):
         ps = dict(self.network.named_parameters())
-        key = tuple((t.data_ptr(), t._version) for t in ps.values())
+        key = tuple((t.data_ptr(), t._version) for t in ps.values()) + (K._lib.param_generation(),)
         if self._packed is not None and key == self._packed_key:
             return self._packed
         layers = []
@@ -57,7 +57,9 @@ class RnnEncoder(nn.Module):
 
     def forward(self, input_dict):
         if self.training:
-            raise NotImplementedError("RnnEncoder (HIP path): the training forward/backward is not built yet")
+            raise NotImplementedError(
+                "RnnEncoder (HIP path): in train mode the GRU only runs inside the whole-model training step "
+                "(audiocaption_amd.train.TrainEngine / TransformerModel.forward with mode='train')")
         x = input_dict["attn"]
         lens = torch.as_tensor(input_dict["attn_len"]).cpu().long()
         B, T, _ = x.shape

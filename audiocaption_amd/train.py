@@ -1,0 +1,622 @@
+"""Training step of the Cnn14Rnn-Trm captioner on the MI355X path.
+
+What the reference does per iteration (run.py:77-148): ``model.train()``; ``output = model(input_dict)`` with
+``mode="train"`` - the frozen Cnn14 (dropout active, BatchNorm in eval mode), the 3-layer bi-GRU and the
+scheduled-sampling stepwise decoder (base.py:131-199, transformer_model.py:34-57) -; LabelSmoothingLoss;
+``loss.backward()``; ``clip_grad_norm_``; ``Adam.step()``; under DDP the gradients are all-reduced.
+
+Here the whole step is HIP kernels driven from this file through the C ABI (csrc/train.hip):
+
+* every decoder prefix pass of the scheduled-sampling loop lives in one ROW SPACE (pass t owns rows
+  ``off_t + n*(t+1) + l``); the forward runs pass by pass (the greedy token of step t feeds step t+1 on the device,
+  no host synchronisation), the backward runs ONCE over all rows because the passes are independent given the tokens;
+* weight gradients are split-K MFMA GEMMs over all rows that accumulate straight into ONE flat gradient buffer whose
+  views are the parameters' ``.grad`` - so the DDP all-reduce is one RCCL call and clip + Adam are three launches;
+* dropout masks come from a counter hash, regenerated in the backward (nothing stored) and reproducible by the CPU
+  oracle; the per-step seed lives in device memory so that a captured HIP graph draws fresh masks when replayed.
+
+``TrainEngine`` is the fast path (``engine.step(batch)``); ``TransformerModel.forward`` with ``mode="train"`` goes
+through the same engine and returns ``logit`` attached to torch.autograd by ONE bridge node, so the reference's
+runner (``loss.backward()``, any torch optimizer) works unchanged.
+"""
+import ctypes
+import random
+
+import torch
+
+from . import _lib
+from ._lib import check
+from .cnn_encoder import cnn14_feat_len
+
+# dropout site codes (low 16 bits of the seed; oracle/train_path.py restates them)
+OP_CNN_BLOCK = 1
+OP_GRU_LAYER = 10
+OP_MEM = 20
+OP_EMB_A, OP_EMB_B = 21, 22
+OP_LAYER = 30
+
+D = 256
+H = 256
+
+
+def _align(n, a=64):
+    return (n + a - 1) // a * a
+
+
+class FlatParams:
+    """The trainable parameters re-pointed into one flat fp32 buffer (``p.data`` become views) plus a flat gradient
+    buffer of the same layout.  GRU tensors are ordered so that the two directions of each kind are adjacent
+    ([W_ih fwd; W_ih rev] is one (2*3H, In) matrix)."""
+
+    def __init__(self, model):
+        rnn = model.encoder.rnn.network
+        names = []
+        for l in range(rnn.num_layers):
+            for kind in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                names += [f"encoder.rnn.network.{kind}_l{l}", f"encoder.rnn.network.{kind}_l{l}_reverse"]
+        named = dict(model.named_parameters())
+        for k, p in named.items():
+            if k.startswith("decoder.") and p.requires_grad:
+                names.append(k)
+        for k in names:
+            if not named[k].requires_grad:
+                raise NotImplementedError(f"TrainEngine: parameter {k} is frozen; partial freezing of the GRU/decoder "
+                                          "is not built")
+        for k, p in named.items():
+            if p.requires_grad and k not in names:
+                raise NotImplementedError(
+                    f"TrainEngine: {k} requires grad, but only the GRU and the decoder are trainable on the HIP path "
+                    "(the reference configs freeze the Cnn14: freeze_cnn / freeze_cnn_bn, cnn14rnn_trm.yaml:11-13)")
+        self.names = names
+        self.params = [named[k] for k in names]
+        dev = self.params[0].device
+        self.offsets, off = [], 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += _align(p.numel())
+        self.total = off
+        self.flat = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.grad_views = []
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                v = self.flat[o:o + p.numel()].view(p.shape)
+                v.copy_(p.data)
+                p.data = v
+                self.grad_views.append(self.grad[o:o + p.numel()].view(p.shape))
+        self.index = {k: i for i, k in enumerate(names)}
+
+    def intact(self):
+        base = self.flat.data_ptr()
+        return all(p.data_ptr() == base + 4 * o for p, o in zip(self.params, self.offsets))
+
+    def p(self, name):
+        return self.flat.data_ptr() + 4 * self.offsets[self.index[name]]
+
+    def g(self, name):
+        return self.grad.data_ptr() + 4 * self.offsets[self.index[name]]
+
+    def attach_grads(self):
+        """Fast path: make the views of the flat buffer the parameters' ``.grad`` (no copies)."""
+        for p, v in zip(self.params, self.grad_views):
+            p.grad = v
+
+
+class _Ws:
+    """Named device buffers of one (N, T, Tm, ...) shape, allocated once."""
+
+    def __init__(self, device):
+        self.device = device
+        self.t = {}
+
+    def f(self, name, *shape):
+        n = 1
+        for s in shape:
+            n *= int(s)
+        b = self.t.get(name)
+        if b is None or b.numel() < n:
+            b = torch.empty(max(n, 1), device=self.device, dtype=torch.float32)
+            self.t[name] = b
+        return b.data_ptr()
+
+    def i(self, name, n):
+        b = self.t.get(name)
+        if b is None or b.numel() < n:
+            b = torch.empty(max(n, 1), device=self.device, dtype=torch.int32)
+            self.t[name] = b
+        return b.data_ptr()
+
+    def tensor(self, name):
+        return self.t[name]
+
+
+class TrainEngine:
+
+    def __init__(self, model, seed=0):
+        from .crnn_trm_encoder import CrnnEncoder
+        if not isinstance(model.encoder, CrnnEncoder) or not model.encoder.freeze_cnn_bn:
+            raise NotImplementedError(
+                "TrainEngine: built for the reference's training recipe, CrnnEncoder(freeze_cnn=True, "
+                "freeze_cnn_bn=True) (cnn14rnn_trm.yaml:9-13); the backward through the Cnn14 is not built")
+        dec = model.decoder
+        if dec.d_model != D or dec.nhead * 64 != D or model.encoder.rnn.hidden_size != H:
+            raise NotImplementedError("TrainEngine: d_model 256 / head_dim 64 / GRU hidden 256 only")
+        self.model = model
+        self.lib = _lib.load()
+        self.flat = None
+        self._ws = {}
+        self.seed = int(seed)          # bumped after every forward (fresh dropout masks per step)
+        self._seed_dev = None
+        self._saved = None
+
+    # ---- small launch helpers (raw addresses; s = stream handle) ------------------------------------------
+    def _gemm(self, s, A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, bias=None, relu=0, beta=0.0, splitk=1, drop_p=0.0,
+              seed=0, row0=0):
+        check(self.lib.ac_gemm(A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, bias, relu, beta, splitk, drop_p, seed,
+                               self._seed_ptr, row0, s), "ac_gemm")
+
+    def _lin(self, s, x, W, b, y, M, N, K, ldx=None, ldy=None, relu=0, drop_p=0.0, seed=0, row0=0):
+        """y[M][N] = x[M][K] W[N][K]^T + b"""
+        self._gemm(s, x, ldx or K, 1, W, 1, K, y, ldy or N, M, N, K, b, relu, 0.0, 1, drop_p, seed, row0)
+
+    def _lin_dx(self, s, dy, W, dx, M, N, K, beta=0.0, lddy=None, lddx=None):
+        """dx[M][K] (+)= dy[M][N] W[N][K]"""
+        self._gemm(s, dy, lddy or N, 1, W, K, 1, dx, lddx or K, M, K, N, None, 0, beta)
+
+    @staticmethod
+    def _splitk(M, N, K):
+        blocks = ((M + 63) // 64) * ((N + 63) // 64)
+        sk = max(1, min(512 // max(blocks, 1), K // 128))
+        return sk
+
+    def _lin_dw(self, s, dy, lddy, x, ldx, dW, rows, N, K):
+        """dW[N][K] += dy[rows][N]^T x[rows][K]"""
+        sk = self._splitk(N, K, rows)
+        self._gemm(s, dy, 1, lddy, x, ldx, 1, dW, K, N, K, rows, None, 0, 1.0, sk)
+
+    def _colsum(self, s, x, ld, out, M, N):
+        check(self.lib.ac_colsum(x, ld, out, M, N, s), "ac_colsum")
+
+    # ---------------------------------------------------------------------------------------------------
+    def _ensure(self, device):
+        if self.flat is None or not self.flat.intact() or self.flat.flat.device != device:
+            self.flat = FlatParams(self.model)
+            _lib.bump_param_generation()
+        if self._seed_dev is None or self._seed_dev.device != device:
+            self._seed_dev = torch.zeros(1, device=device, dtype=torch.int64)
+            self._seed_host = torch.zeros(1, dtype=torch.int64).pin_memory()
+        self._seed_ptr = self._seed_dev.data_ptr()
+
+    def _layout(self, ws, N, T, Tm, lens_host, teacher_forcing, device):
+        """Static index tables of the row space (cached per shape)."""
+        key = (N, T, Tm, tuple(int(v) for v in lens_host), teacher_forcing)
+        if ws.t.get("_layout_key") == key:
+            return ws.t["_layout"]
+        if teacher_forcing:
+            passes = [(T, 0)]
+        else:
+            passes, off = [], 0
+            for t in range(T):
+                passes.append((t + 1, off))
+                off += N * (t + 1)
+        R = sum(N * L for L, _ in passes)
+        S = len(passes) * N
+        pos = torch.empty(R, dtype=torch.int32)
+        qrow0 = torch.empty(S, dtype=torch.int32)
+        qlen = torch.empty(S, dtype=torch.int32)
+        cls_rows = torch.empty(N * T, dtype=torch.int32)
+        for t, (L, off) in enumerate(passes):
+            pos[off:off + N * L] = torch.arange(L, dtype=torch.int32).repeat(N)
+            for n in range(N):
+                qrow0[t * N + n] = off + n * L
+                qlen[t * N + n] = L
+                if teacher_forcing:
+                    cls_rows[n * T:(n + 1) * T] = torch.arange(off + n * L, off + (n + 1) * L, dtype=torch.int32)
+                else:
+                    cls_rows[n * T + t] = off + n * L + t
+        mrow0 = torch.arange(S, dtype=torch.int32) * Tm
+        mklen = torch.full((S,), Tm, dtype=torch.int32)
+        mvalid = torch.as_tensor(lens_host, dtype=torch.int32).repeat(len(passes))
+        lay = {"passes": passes, "R": R, "S": S}
+        for k, v in (("pos", pos), ("qrow0", qrow0), ("qlen", qlen), ("cls_rows", cls_rows), ("mrow0", mrow0),
+                     ("mklen", mklen), ("mvalid", mvalid)):
+            lay[k] = v.to(device)
+        ws.t["_layout_key"], ws.t["_layout"] = key, lay
+        return lay
+
+    # ---- forward ------------------------------------------------------------------------------------------
+    def forward(self, input_dict):
+        """The reference's ``model(input_dict)`` for mode "train": returns ``logit`` (N, T, V) [+ ``seq``] as plain
+        device tensors and keeps what the backward needs."""
+        model, lib = self.model, self.lib
+        enc, dec = model.encoder, model.decoder
+        if not model.training:
+            raise RuntimeError("TrainEngine.forward needs model.train() (run.py:79)")
+        if input_dict.get("specaug", False):
+            raise NotImplementedError("TrainEngine: SpecAugment is not built (the reference config disables it, "
+                                      "cnn14rnn_trm.yaml:38)")
+        wav = input_dict["wav"]
+        dev = wav.device
+        if not wav.is_cuda:
+            raise _lib.HipLibraryError("the training step needs tensors on a ROCm device; there is no CPU fallback")
+        self._ensure(dev)
+        fp = self.flat
+        s = _lib.stream()
+        cap = input_dict["cap"].to(device=dev, dtype=torch.int64).contiguous()
+        N, Tc = cap.shape
+        T = Tc - 1
+        ss_ratio = input_dict["ss_ratio"]
+        teacher_forcing = ss_ratio == 1
+        # one draw per step, exactly the reference's call pattern (transformer_model.py:44)
+        use_cap = [1] * T if teacher_forcing else [int(random.random() < ss_ratio) for _ in range(T)]
+        use_cap = input_dict.get("_use_cap", use_cap)
+        p_dec = float(dec.in_dropout.p)
+        p_rnn = float(enc.rnn.network.dropout)
+        p_cnn = 0.2 if enc.cnn.training else 0.0
+        base_seed = int(input_dict.get("dropout_seed", self.seed))
+        self.seed = base_seed + 1
+        self._seed_host[0] = base_seed
+        self._seed_dev.copy_(self._seed_host, non_blocking=True)
+
+        # ---- frozen Cnn14 (train mode: dropout after every block) and feature lengths -------------------
+        if "_cnn_attn" in input_dict:   # parity-test hook: start downstream of the (un-pinned) mel front-end
+            cnn_attn = input_dict["_cnn_attn"].to(device=dev, dtype=torch.float32).contiguous()
+        else:
+            cnn_attn = enc.cnn.encode(wav, dropout=(p_cnn, OP_CNN_BLOCK, self._seed_ptr) if p_cnn > 0 else None)
+        lens = cnn14_feat_len(input_dict["wav_len"], enc.cnn.hop_length, enc.cnn.downsample_ratio)
+        B, Tq, Cin = cnn_attn.shape
+        if B != N:
+            raise ValueError("cap and wav batch sizes differ")
+        if int(lens.min()) < 1 or int(lens.max()) > Tq:
+            raise ValueError("attn_len must lie in [1, attn.size(1)]")
+        Tm = int(lens.max())
+        key = (dev, N, T, Tq, Tm)
+        ws = self._ws.get(key)
+        if ws is None:
+            ws = self._ws[key] = _Ws(dev)
+        lens_dev = lens.to(device=dev, dtype=torch.int32)
+        ws.t["lens"] = lens_dev
+        lay = self._layout(ws, N, T, Tm, lens.tolist(), teacher_forcing, dev)
+        R, S, passes = lay["R"], lay["S"], lay["passes"]
+        NP = len(passes)
+        rows_g = B * Tq
+
+        # ---- GRU, saving the gates -------------------------------------------------------------------
+        nl = enc.rnn.num_layers
+        x_in = cnn_attn.data_ptr()
+        in_dim = Cin
+        gru = []
+        for l in range(nl):
+            pre = f"encoder.rnn.network."
+            w_ih, w_hh = fp.p(f"{pre}weight_ih_l{l}"), fp.p(f"{pre}weight_hh_l{l}")
+            b_ih, b_hh = fp.p(f"{pre}bias_ih_l{l}"), fp.p(f"{pre}bias_hh_l{l}")
+            gx = ws.f(f"gx{l}", rows_g, 6 * H)
+            self._lin(s, x_in, w_ih, b_ih, gx, rows_g, 6 * H, in_dim)
+            whhT = ws.f(f"whhT{l}", 2 * 3 * H * H)
+            check(lib.ac_transpose(w_hh, whhT, 2, 3 * H, H, s), "ac_transpose")
+            out = ws.f(f"gru_out{l}", rows_g, 2 * H)
+            save = ws.f(f"gru_save{l}", rows_g, 2 * 4 * H)
+            check(lib.ac_gru_layer_train(gx, whhT, b_hh, lens_dev.data_ptr(), out, save, B, Tq, H, s),
+                  "ac_gru_layer_train")
+            nxt = out
+            if l < nl - 1 and p_rnn > 0:
+                nxt = ws.f(f"gru_drop{l}", rows_g, 2 * H)
+                check(lib.ac_dropout(out, nxt, rows_g * 2 * H, p_rnn, OP_GRU_LAYER + l, self._seed_ptr, 0, s),
+                      "ac_dropout")
+            gru.append({"x": x_in, "in_dim": in_dim, "out": out})
+            x_in, in_dim = nxt, 2 * H
+        # attn_emb (B, Tm, 512): pad_packed_sequence truncates to the longest clip
+        if Tm < Tq:
+            attn_emb_t = ws.tensor(f"gru_out{nl - 1}")[:rows_g * 2 * H].view(B, Tq, 2 * H)[:, :Tm].contiguous()
+            ws.t["attn_emb_c"] = attn_emb_t
+            attn_emb = attn_emb_t.data_ptr()
+        else:
+            attn_emb = x_in
+        A = 2 * H
+
+        # ---- decoder: audio memory (shared by all passes up to its dropout mask) ---------------------
+        dp = "decoder."
+        nlay = dec.nlayers
+        V = dec.vocab_size
+        F = dec.dim_feedforward
+        rows_m = N * Tm
+        Rm = NP * rows_m
+        mem_a = ws.f("mem_a", rows_m, D)
+        self._lin(s, attn_emb, fp.p(dp + "attn_proj.0.weight"), fp.p(dp + "attn_proj.0.bias"), mem_a, rows_m, D, A, relu=1)
+        mem_pre, mem = ws.f("mem_pre", Rm, D), ws.f("mem", Rm, D)
+        check(lib.ac_dropadd_ln_fwd(mem_a, None, fp.p(dp + "attn_proj.3.weight"), fp.p(dp + "attn_proj.3.bias"), mem_pre,
+                                    mem, 0, Rm, rows_m, D, p_dec, OP_MEM, self._seed_ptr, 1e-5, s), "ac_dropadd_ln_fwd")
+        kv = []
+        for l in range(nlay):
+            lp = f"{dp}model.layers.{l}."
+            kvb = ws.f(f"kv{l}", Rm, 2 * D)
+            self._lin(s, mem, fp.p(lp + "multihead_attn.in_proj_weight") + 4 * D * D,
+                      fp.p(lp + "multihead_attn.in_proj_bias") + 4 * D, kvb, Rm, 2 * D, D)
+            kv.append(kvb)
+
+        # ---- the passes ------------------------------------------------------------------------------
+        word = ws.i("word", R)
+        seq = ws.i("seq", N * T)
+        ucap = ws.i("use_cap", max(T, 1))
+        ucap_host = torch.tensor(use_cap if len(use_cap) else [1], dtype=torch.int32)
+        ws.tensor("use_cap")[:len(ucap_host)].copy_(ucap_host)
+        logit_t = torch.empty(N, T, V, device=dev, dtype=torch.float32)
+        logit = logit_t.data_ptr()
+        pos, qrow0, qlen = lay["pos"].data_ptr(), lay["qrow0"].data_ptr(), lay["qlen"].data_ptr()
+        mrow0, mklen, mvalid = lay["mrow0"].data_ptr(), lay["mklen"].data_ptr(), lay["mvalid"].data_ptr()
+        emb, pe, cls = fp.p(dp + "word_embedding.weight"), dec.pos_encoder.pe.data_ptr(), fp.p(dp + "classifier.weight")
+        nh = dec.nhead
+        P1 = [ws.f(f"P1_{l}", S * nh * T * T) for l in range(nlay)]     # attention probabilities, kept per layer
+        P2 = [ws.f(f"P2_{l}", S * nh * T * Tm) for l in range(nlay)]
+        x0 = ws.f("x_l0", R, D)
+        acts = []
+        for l in range(nlay):
+            a = {k: ws.f(f"{k}{l}", R, w) for k, w in (("qkv", 3 * D), ("ctx1", D), ("sa", D), ("pre1", D), ("x1", D),
+                                                       ("q2", D), ("ctx2", D), ("ca", D), ("pre2", D), ("x2", D),
+                                                       ("hdn", F), ("ff", D), ("pre3", D))}
+            a["x3"] = ws.f(f"x_l{l + 1}", R, D)
+            acts.append(a)
+        cap_p = cap.data_ptr()
+        for t, (L, off) in enumerate(passes):
+            nr = N * L
+            o4 = 4 * off * D
+            check(lib.ac_build_prefix(cap_p, Tc, seq, T, ucap, 0 if teacher_forcing else t, model.start_idx, word, off, N,
+                                      L, s), "ac_build_prefix")
+            check(lib.ac_embed_fwd(emb, pe, word, pos, x0, off, nr, D, p_dec, OP_EMB_A, p_dec, OP_EMB_B, self._seed_ptr,
+                                   s), "ac_embed_fwd")
+            x = x0
+            for l in range(nlay):
+                lp = f"{dp}model.layers.{l}."
+                a = acts[l]
+                op = OP_LAYER + 10 * l
+                qkv = a["qkv"] + 4 * off * 3 * D
+                self._lin(s, x + o4, fp.p(lp + "self_attn.in_proj_weight"), fp.p(lp + "self_attn.in_proj_bias"), qkv, nr,
+                          3 * D, D)
+                check(lib.ac_attn_seq_fwd(a["qkv"], 3 * D, a["qkv"] + 4 * D, 3 * D, a["qkv"] + 8 * D, 3 * D, a["ctx1"], D,
+                                          P1[l], T, T, qrow0, qlen, qrow0, qlen, None, word, model.pad_idx, 1, t * N, N, nh,
+                                          64, L, L, p_dec, op + 0, self._seed_ptr, s), "ac_attn_seq_fwd")
+                self._lin(s, a["ctx1"] + o4, fp.p(lp + "self_attn.out_proj.weight"), fp.p(lp + "self_attn.out_proj.bias"),
+                          a["sa"] + o4, nr, D, D)
+                check(lib.ac_dropadd_ln_fwd(a["sa"], x, fp.p(lp + "norm1.weight"), fp.p(lp + "norm1.bias"), a["pre1"],
+                                            a["x1"], off, nr, 0, D, p_dec, op + 1, self._seed_ptr, 1e-5, s), "ln1")
+                self._lin(s, a["x1"] + o4, fp.p(lp + "multihead_attn.in_proj_weight"),
+                          fp.p(lp + "multihead_attn.in_proj_bias"), a["q2"] + o4, nr, D, D)
+                check(lib.ac_attn_seq_fwd(a["q2"], D, kv[l], 2 * D, kv[l] + 4 * D, 2 * D, a["ctx2"], D, P2[l], T, Tm, qrow0,
+                                          qlen, mrow0, mklen, mvalid, None, 0, 0, t * N, N, nh, 64, L, Tm, p_dec, op + 2,
+                                          self._seed_ptr, s), "ac_attn_seq_fwd(cross)")
+                self._lin(s, a["ctx2"] + o4, fp.p(lp + "multihead_attn.out_proj.weight"),
+                          fp.p(lp + "multihead_attn.out_proj.bias"), a["ca"] + o4, nr, D, D)
+                check(lib.ac_dropadd_ln_fwd(a["ca"], a["x1"], fp.p(lp + "norm2.weight"), fp.p(lp + "norm2.bias"),
+                                            a["pre2"], a["x2"], off, nr, 0, D, p_dec, op + 3, self._seed_ptr, 1e-5, s),
+                      "ln2")
+                self._lin(s, a["x2"] + o4, fp.p(lp + "linear1.weight"), fp.p(lp + "linear1.bias"),
+                          a["hdn"] + 4 * off * F, nr, F, D, relu=1, drop_p=p_dec, seed=op + 4, row0=off)
+                self._lin(s, a["hdn"] + 4 * off * F, fp.p(lp + "linear2.weight"), fp.p(lp + "linear2.bias"), a["ff"] + o4,
+                          nr, D, F)
+                check(lib.ac_dropadd_ln_fwd(a["ff"], a["x2"], fp.p(lp + "norm3.weight"), fp.p(lp + "norm3.bias"),
+                                            a["pre3"], a["x3"], off, nr, 0, D, p_dec, op + 5, self._seed_ptr, 1e-5, s),
+                      "ln3")
+                x = a["x3"]
+            if teacher_forcing:
+                self._lin(s, x, cls, None, logit, N * T, V, D)
+            else:
+                # classifier on the last position of every sequence of this pass -> logit[:, t]
+                self._lin(s, x + o4 + 4 * t * D, cls, None, logit + 4 * t * V, N, V, D, ldx=L * D, ldy=T * V)
+                check(lib.ac_argmax_rows(logit + 4 * t * V, T * V, N, V, seq + 4 * t, T, s), "ac_argmax_rows")
+        self._saved = dict(ws=ws, lay=lay, N=N, T=T, Tm=Tm, Tq=Tq, B=B, V=V, F=F, p_dec=p_dec, p_rnn=p_rnn, gru=gru,
+                           kv=kv, acts=acts, x0=x0, word=word, P1=P1, P2=P2, mem=mem, mem_pre=mem_pre, mem_a=mem_a,
+                           attn_emb=attn_emb, logit=logit_t, cnn_attn=cnn_attn, cap=cap, teacher_forcing=teacher_forcing)
+        out = {"logit": logit_t, "attn_emb_len": lens}
+        if not teacher_forcing:
+            out["seq"] = ws.tensor("seq")[:N * T].view(N, T).to(torch.int64)
+        return out
+
+    # ---- backward -----------------------------------------------------------------------------------------
+    def backward(self, dlogit):
+        """d(loss)/d(parameters) of the last forward into the (zeroed) flat gradient buffer, given d(loss)/d(logit)
+        (N, T, V).  The kernels accumulate (split-K atomics, bias column sums), so the buffer is cleared first."""
+        sv = self._saved
+        if sv is None:
+            raise RuntimeError("TrainEngine.backward without a forward")
+        self._saved = None
+        model, lib, fp = self.model, self.lib, self.flat
+        enc, dec = model.encoder, model.decoder
+        s = _lib.stream()
+        ws, lay = sv["ws"], sv["lay"]
+        N, T, Tm, Tq, B, V, F = sv["N"], sv["T"], sv["Tm"], sv["Tq"], sv["B"], sv["V"], sv["F"]
+        p_dec, p_rnn = sv["p_dec"], sv["p_rnn"]
+        R, S = lay["R"], lay["S"]
+        NP = len(lay["passes"])
+        rows_m = N * Tm
+        Rm = NP * rows_m
+        nh = dec.nhead
+        nlay = dec.nlayers
+        dp = "decoder."
+        dlogit = dlogit.contiguous()
+        if dlogit.dtype != torch.float32:
+            dlogit = dlogit.float()
+        dl = dlogit.data_ptr()
+        fp.grad.zero_()
+        qrow0, qlen = lay["qrow0"].data_ptr(), lay["qlen"].data_ptr()
+        mrow0, mklen = lay["mrow0"].data_ptr(), lay["mklen"].data_ptr()
+        cls_rows = lay["cls_rows"].data_ptr()
+        NT = N * T
+
+        # ---- classifier --------------------------------------------------------------------------------
+        xtop = sv["acts"][-1]["x3"]
+        xlast = ws.f("xlast", NT, D)
+        check(lib.ac_gather_rows(xtop, cls_rows, xlast, NT, D, s), "ac_gather_rows")
+        self._lin_dw(s, dl, V, xlast, D, fp.g(dp + "classifier.weight"), NT, V, D)
+        dxlast = ws.f("dxlast", NT, D)
+        self._lin_dx(s, dl, fp.p(dp + "classifier.weight"), dxlast, NT, V, D)
+        dx = ws.f("dx_a", R, D)
+        dres = ws.f("dx_b", R, D)
+        ws.tensor("dx_a")[:R * D].zero_()
+        check(lib.ac_scatter_add_rows(dxlast, cls_rows, dx, NT, D, s), "ac_scatter_add_rows")
+        dsub = ws.f("dsub", R, D)
+        dhdn = ws.f("dhdn", R, F)
+        dctx = ws.f("dctx", R, D)
+        dq2 = ws.f("dq2", R, D)
+        dqkv = ws.f("dqkv", R, 3 * D)
+        dmem = ws.f("dmem", Rm, D)
+        dkv = ws.f("dkv", Rm, 2 * D)
+        scale = 1.0 / (1.0 - p_dec) if p_dec > 0 else 1.0
+        for l in reversed(range(nlay)):
+            lp = f"{dp}model.layers.{l}."
+            a = sv["acts"][l]
+            op = OP_LAYER + 10 * l
+            x_in = sv["x0"] if l == 0 else sv["acts"][l - 1]["x3"]
+            # norm3 / feed-forward
+            check(lib.ac_dropadd_ln_bwd(dx, a["pre3"], fp.p(lp + "norm3.weight"), dsub, dres, 0, None, 0,
+                                        fp.g(lp + "norm3.weight"), fp.g(lp + "norm3.bias"), R, D, p_dec, op + 5,
+                                        self._seed_ptr, 1e-5, s), "ln3 bwd")
+            self._lin_dw(s, dsub, D, a["hdn"], F, fp.g(lp + "linear2.weight"), R, D, F)
+            self._colsum(s, dsub, D, fp.g(lp + "linear2.bias"), R, D)
+            self._lin_dx(s, dsub, fp.p(lp + "linear2.weight"), dhdn, R, D, F)
+            check(lib.ac_mask_pos_scale(dhdn, a["hdn"], R * F, scale, s), "ac_mask_pos_scale")
+            self._lin_dw(s, dhdn, F, a["x2"], D, fp.g(lp + "linear1.weight"), R, F, D)
+            self._colsum(s, dhdn, F, fp.g(lp + "linear1.bias"), R, F)
+            self._lin_dx(s, dhdn, fp.p(lp + "linear1.weight"), dres, R, F, D, beta=1.0)
+            dx, dres = dres, dx                                   # dx = d(x2)
+            # norm2 / cross attention
+            check(lib.ac_dropadd_ln_bwd(dx, a["pre2"], fp.p(lp + "norm2.weight"), dsub, dres, 0, None, 0,
+                                        fp.g(lp + "norm2.weight"), fp.g(lp + "norm2.bias"), R, D, p_dec, op + 3,
+                                        self._seed_ptr, 1e-5, s), "ln2 bwd")
+            self._lin_dw(s, dsub, D, a["ctx2"], D, fp.g(lp + "multihead_attn.out_proj.weight"), R, D, D)
+            self._colsum(s, dsub, D, fp.g(lp + "multihead_attn.out_proj.bias"), R, D)
+            self._lin_dx(s, dsub, fp.p(lp + "multihead_attn.out_proj.weight"), dctx, R, D, D)
+            kvl = sv["kv"][l]
+            check(lib.ac_attn_seq_bwd(a["q2"], D, kvl, 2 * D, kvl + 4 * D, 2 * D, sv["P2"][l], T, Tm, dctx, D, dq2, D, dkv,
+                                      2 * D, dkv + 4 * D, 2 * D, qrow0, qlen, mrow0, mklen, 0, S, nh, 64, T, Tm, p_dec,
+                                      op + 2, self._seed_ptr, s), "ac_attn_seq_bwd(cross)")
+            w_in, g_in = fp.p(lp + "multihead_attn.in_proj_weight"), fp.g(lp + "multihead_attn.in_proj_weight")
+            b_in_g = fp.g(lp + "multihead_attn.in_proj_bias")
+            self._lin_dw(s, dq2, D, a["x1"], D, g_in, R, D, D)
+            self._colsum(s, dq2, D, b_in_g, R, D)
+            self._lin_dx(s, dq2, w_in, dres, R, D, D, beta=1.0)
+            self._lin_dw(s, dkv, 2 * D, sv["mem"], D, g_in + 4 * D * D, Rm, 2 * D, D)
+            self._colsum(s, dkv, 2 * D, b_in_g + 4 * D, Rm, 2 * D)
+            self._lin_dx(s, dkv, w_in + 4 * D * D, dmem, Rm, 2 * D, D, beta=0.0 if l == nlay - 1 else 1.0)
+            dx, dres = dres, dx                                   # dx = d(x1)
+            # norm1 / self attention
+            check(lib.ac_dropadd_ln_bwd(dx, a["pre1"], fp.p(lp + "norm1.weight"), dsub, dres, 0, None, 0,
+                                        fp.g(lp + "norm1.weight"), fp.g(lp + "norm1.bias"), R, D, p_dec, op + 1,
+                                        self._seed_ptr, 1e-5, s), "ln1 bwd")
+            self._lin_dw(s, dsub, D, a["ctx1"], D, fp.g(lp + "self_attn.out_proj.weight"), R, D, D)
+            self._colsum(s, dsub, D, fp.g(lp + "self_attn.out_proj.bias"), R, D)
+            self._lin_dx(s, dsub, fp.p(lp + "self_attn.out_proj.weight"), dctx, R, D, D)
+            check(lib.ac_attn_seq_bwd(a["qkv"], 3 * D, a["qkv"] + 4 * D, 3 * D, a["qkv"] + 8 * D, 3 * D, sv["P1"][l], T, T,
+                                      dctx, D, dqkv, 3 * D, dqkv + 4 * D, 3 * D, dqkv + 8 * D, 3 * D, qrow0, qlen, qrow0,
+                                      qlen, 0, S, nh, 64, T, T, p_dec, op + 0, self._seed_ptr, s), "ac_attn_seq_bwd")
+            self._lin_dw(s, dqkv, 3 * D, x_in, D, fp.g(lp + "self_attn.in_proj_weight"), R, 3 * D, D)
+            self._colsum(s, dqkv, 3 * D, fp.g(lp + "self_attn.in_proj_bias"), R, 3 * D)
+            self._lin_dx(s, dqkv, fp.p(lp + "self_attn.in_proj_weight"), dres, R, 3 * D, D, beta=1.0)
+            dx, dres = dres, dx                                   # dx = d(layer input)
+        check(lib.ac_embed_bwd(dx, sv["word"], fp.g(dp + "word_embedding.weight"), R, D, p_dec, OP_EMB_A, p_dec, OP_EMB_B,
+                               self._seed_ptr, s), "ac_embed_bwd")
+
+        # ---- audio memory -> attn_proj -> GRU output ---------------------------------------------------
+        da_rep = ws.f("da_rep", Rm, D)
+        check(lib.ac_dropadd_ln_bwd(dmem, sv["mem_pre"], fp.p(dp + "attn_proj.3.weight"), da_rep, None, 0, sv["mem_a"],
+                                    rows_m, fp.g(dp + "attn_proj.3.weight"), fp.g(dp + "attn_proj.3.bias"), Rm, D, p_dec,
+                                    OP_MEM, self._seed_ptr, 1e-5, s), "mem ln bwd")
+        da = ws.f("da", rows_m, D)
+        check(lib.ac_sum_replicas(da_rep, da, rows_m * D, NP, s), "ac_sum_replicas")
+        A = 2 * H
+        self._lin_dw(s, da, D, sv["attn_emb"], A, fp.g(dp + "attn_proj.0.weight"), rows_m, D, A)
+        self._colsum(s, da, D, fp.g(dp + "attn_proj.0.bias"), rows_m, D)
+        rows_g = B * Tq
+        dout = ws.f("gru_dout", rows_g, A)
+        if Tm < Tq:
+            dtmp = ws.f("gru_dout_c", rows_m, A)
+            self._lin_dx(s, da, fp.p(dp + "attn_proj.0.weight"), dtmp, rows_m, D, A)
+            full = ws.tensor("gru_dout")[:rows_g * A].view(B, Tq, A)
+            full.zero_()
+            full[:, :Tm].copy_(ws.tensor("gru_dout_c")[:rows_m * A].view(B, Tm, A))
+        else:
+            self._lin_dx(s, da, fp.p(dp + "attn_proj.0.weight"), dout, rows_m, D, A)
+        lens_p = ws.tensor("lens").data_ptr()
+        nl = enc.rnn.num_layers
+        dgx, dgh, hprev = ws.f("dgx", rows_g, 6 * H), ws.f("dgh", rows_g, 6 * H), ws.f("hprev", rows_g, 2 * H)
+        for l in reversed(range(nl)):
+            pre = "encoder.rnn.network."
+            g = sv["gru"][l]
+            if l < nl - 1 and p_rnn > 0:
+                check(lib.ac_dropout(dout, dout, rows_g * A, p_rnn, OP_GRU_LAYER + l, self._seed_ptr, 0, s), "ac_dropout")
+            check(lib.ac_gru_layer_bwd(dout, g["out"], ws.f(f"gru_save{l}", rows_g, 8 * H), fp.p(f"{pre}weight_hh_l{l}"),
+                                       lens_p, dgx, dgh, hprev, B, Tq, H, s), "ac_gru_layer_bwd")
+            self._lin_dw(s, dgx, 6 * H, g["x"], g["in_dim"], fp.g(f"{pre}weight_ih_l{l}"), rows_g, 6 * H, g["in_dim"])
+            self._colsum(s, dgx, 6 * H, fp.g(f"{pre}bias_ih_l{l}"), rows_g, 6 * H)
+            self._colsum(s, dgh, 6 * H, fp.g(f"{pre}bias_hh_l{l}"), rows_g, 6 * H)
+            for d_ in range(2):
+                # dW_hh[dir] (3H, H) += dgh[:, dir]^T hprev[:, dir]
+                sk = self._splitk(3 * H, H, rows_g)
+                self._gemm(s, dgh + 4 * d_ * 3 * H, 1, 6 * H, hprev + 4 * d_ * H, 2 * H, 1,
+                           fp.g(f"{pre}weight_hh_l{l}") + 4 * d_ * 3 * H * H, H, 3 * H, H, rows_g, None, 0, 1.0, sk)
+            if l > 0:
+                self._lin_dx(s, dgx, fp.p(f"{pre}weight_ih_l{l}"), dout, rows_g, 6 * H, g["in_dim"])
+
+
+    # ---- fast path: forward + loss + backward (+ gradient all-reduce) + clip + Adam -----------------------
+    def step(self, input_dict, optimizer, smoothing=0.1, max_grad_norm=1.0, process_group=None):
+        """One training iteration (run.py:106-126) without leaving the HIP path: returns the loss as a device scalar.
+        Gradients go straight into the flat buffer (= the parameters' ``.grad``); with ``torch.distributed``
+        initialised they are summed over the ranks in ONE all-reduce and the division by the world size is folded
+        into the clip coefficient."""
+        from .loss import _launch
+        from .optim import FusedAdam, clip_grad_norm_
+        import torch.distributed as dist
+        out = self.forward(input_dict)
+        sv = self._saved
+        logit = out["logit"]
+        N, T, _ = logit.shape
+        cap = sv["cap"]
+        tgt = cap[:, 1:]
+        tgt_len = torch.as_tensor(input_dict["cap_len"]).cpu().long() - 1
+        count = float(torch.clamp(tgt_len, max=T).sum())
+        tgt_len_dev = tgt_len.to(device=logit.device, dtype=torch.int32)
+        dlogit = torch.empty_like(logit)
+        loss, _ = _launch(logit, tgt, tgt_len_dev, smoothing, 1.0 / count, dlogit, 1.0 / count, None)
+        self.backward(dlogit)
+        self.flat.attach_grads()
+        world = 1
+        if dist.is_available() and dist.is_initialized():
+            world = dist.get_world_size(process_group)
+            if world > 1:
+                dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=process_group)
+        clip = clip_grad_norm_(self.flat.params, max_grad_norm, grad_div=float(world), scale_now=False)
+        if isinstance(optimizer, FusedAdam):
+            optimizer.step(clip=clip)
+        else:
+            check(self.lib.ac_scale_by_coef(self.flat.grad.data_ptr(), self.flat.total, clip.state.data_ptr(),
+                                            _lib.stream()), "ac_scale_by_coef")
+            optimizer.step()
+            _lib.bump_param_generation()
+        return {"loss": loss[0], "total_norm": clip.total_norm, "logit": logit, "seq": out.get("seq")}
+
+
+class _TrainBridge(torch.autograd.Function):
+    """One autograd node for the whole HIP training forward: ``logit`` depends on every trainable parameter; its
+    backward runs TrainEngine.backward and hands autograd the views of the flat gradient buffer, so ``.grad``
+    accumulation, optimizers and torch's DistributedDataParallel hooks behave as with the reference model."""
+
+    @staticmethod
+    def forward(ctx, engine, logit, *params):
+        ctx.engine = engine
+        return logit.view_as(logit)
+
+    @staticmethod
+    def backward(ctx, dlogit):
+        ctx.engine.backward(dlogit)
+        return (None, None) + tuple(ctx.engine.flat.grad_views)
+
+
+def train_forward(model, input_dict):
+    """``TransformerModel.forward`` for ``mode == "train"`` (base.py:73-112 -> train_forward)."""
+    engine = getattr(model, "_train_engine", None)
+    if engine is None:
+        engine = model._train_engine = TrainEngine(model)
+    out = engine.forward(input_dict)
+    if torch.is_grad_enabled():
+        out["logit"] = _TrainBridge.apply(engine, out["logit"], *engine.flat.params)
+    return out

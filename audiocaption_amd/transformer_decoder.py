@@ -94,7 +94,7 @@ class TransformerDecoder(BaseDecoder):
 
     # ------------------------------------------------------------------------------------------
     def _weights_key(self):
-        return tuple((t.data_ptr(), t._version, t.dtype) for t in self.parameters())
+        return tuple((t.data_ptr(), t._version, t.dtype) for t in self.parameters()) + (_lib.param_generation(),)
 
     def weights(self):
         """ac_trm_weights struct of device pointers (rebuilt when a parameter changes)."""
@@ -162,7 +162,9 @@ class TransformerDecoder(BaseDecoder):
 
     def forward(self, input_dict):
         if self.training:
-            raise NotImplementedError("TransformerDecoder (HIP path): the training forward/backward is not built yet")
+            raise NotImplementedError(
+                "TransformerDecoder (HIP path): in train mode the decoder only runs inside the whole-model training "
+                "step (audiocaption_amd.train.TrainEngine / TransformerModel.forward with mode='train')")
         lib = _lib.load()
         attn_emb = input_dict["attn_emb"]
         dev = attn_emb.device

@@ -54,15 +54,18 @@ class CaptionModel(nn.Module, CaptionMetaMixin):
             f"please use decoder in {names} "
 
     def forward(self, input_dict):
+        if input_dict["mode"] == "train":
+            # the whole training forward (frozen Cnn14 with dropout, GRU, scheduled-sampling decoder) is one engine
+            # call; ``logit`` comes back attached to autograd by a single bridge node (audiocaption_amd/train.py)
+            from .train import train_forward
+            return train_forward(self, input_dict)
         encoder_output_dict = self.encoder(input_dict)
         output = self.forward_decoder(input_dict, encoder_output_dict)
         return output
 
     def forward_decoder(self, input_dict, encoder_output_dict):
         if input_dict["mode"] == "train":
-            raise NotImplementedError(
-                "CaptionModel (HIP path): mode='train' (teacher forcing / scheduled sampling with backward) "
-                "is not built yet; only mode='inference' exists")
+            raise NotImplementedError("mode='train' is handled by CaptionModel.forward as one fused step")
         elif input_dict["mode"] == "inference":
             forward_dict = {"mode": "inference"}
             default_args = {"sample_method": "greedy", "max_length": self.max_length, "temp": 1.0}

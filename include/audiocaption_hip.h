@@ -246,10 +246,11 @@ int ac_colsum(const float* x, long ld, float* out, long M, int N, void* stream);
 /* out[r*out_ld] = argmax_v logit[r*ld + v], first index on ties (sample_next_word "greedy", base.py:206-209). */
 int ac_argmax_rows(const float* logit, long ld, int rows, int V, int* out, long out_ld, void* stream);
 /* LabelSmoothingLoss (loss.py:51-74): logit [N][T][V], tgt int64 [N][tgt_ld], tgt_len int32 [N]; row_loss [N*T];
- * loss[0] = inv_count * sum(row_loss); dlogit (optional) = gscale * (softmax - q) on valid rows, 0 elsewhere. */
+ * loss[0] = inv_count * sum(row_loss); dlogit (optional) = gscale [* gscale_dev[0]] * (softmax - q) on valid rows,
+ * 0 elsewhere (gscale_dev: the upstream gradient of the loss when it lives on the device). */
 int ac_label_smoothing_loss(const float* logit, const long long* tgt, long tgt_ld, const int* tgt_len, int N, int T, int V,
                             float smoothing, float inv_count, float* row_loss, float* loss, float* dlogit, float gscale,
-                            void* stream);
+                            const float* gscale_dev, void* stream);
 /* ac_gru_layer that also keeps (r, z, n, W_hn h + b_hn) per (clip, step, direction): save [B][T][2][4H]. */
 int ac_gru_layer_train(const float* gx, const float* whhT, const float* bhh, const int* lens, float* out, float* save,
                        int B, int T, int hidden, void* stream);

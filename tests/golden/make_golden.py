@@ -277,7 +277,7 @@ def main():
         g8[f"{tag}_logit_top_val"] = out["logit"].detach().topk(8, dim=-1).values.numpy()
         g8[f"{tag}_logit_top_idx"] = out["logit"].detach().topk(8, dim=-1).indices.numpy()
         for k, p_ in trainable:
-            g8[f"{tag}_gnorm/{k}"] = np.array(float(raw[k].norm()))
+            g8[f"{tag}_gnorm/{k}"] = np.array(float(raw[k].double().norm()))  # f32 CPU norms lose 2e-4 on 1.3M elements
             g8[f"{tag}_gsum/{k}"] = np.array(float(raw[k].double().sum()))
             g8[f"{tag}_gsample/{k}"] = raw[k].reshape(-1)[sample_idx[k]].numpy()
             g8[f"{tag}_delta/{k}"] = (p_.detach() - before[k]).reshape(-1)[sample_idx[k]].numpy()

@@ -119,8 +119,9 @@ def test_no_cpu_fallback():
     with pytest.raises(Exception):
         model({"mode": "bogus", "wav": torch.zeros(1, 32000), "wav_len": [32000], "specaug": False})
     model.train()
-    with pytest.raises(NotImplementedError):
-        model({"mode": "train", "wav": torch.zeros(1, 32000), "wav_len": [32000], "specaug": False})
+    with pytest.raises(_lib.HipLibraryError):
+        model({"mode": "train", "wav": torch.zeros(1, 32000), "wav_len": [32000], "specaug": False,
+               "cap": torch.ones(1, 5, dtype=torch.long), "cap_len": [5], "ss_ratio": 1.0})
 
 
 def test_feat_len_and_geometry():
