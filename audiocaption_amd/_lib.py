@@ -100,6 +100,11 @@ def param_generation():
     return PARAM_GENERATION
 
 
+def param_generation_flat(engine):
+    """Identity of the flat parameter storage a captured training graph was recorded against."""
+    return engine.flat.flat.data_ptr()
+
+
 class HipLibraryError(RuntimeError):
     pass
 

@@ -59,6 +59,10 @@ __device__ __forceinline__ float wave_max(float v) {
   return fmaxf(fmaxf(lane_read(v, 0), lane_read(v, 16)), fmaxf(lane_read(v, 32), lane_read(v, 48)));
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter
+// (s_waitcnt vmcnt(0)), which would force every global prefetch in flight to land at each barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 static inline int ac_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? AC_OK : AC_ERR_LAUNCH;

@@ -64,7 +64,9 @@ struct GemmP {
   long row0;
 };
 
-constexpr int GT = 64, GK = 16, GLD = GT + 4;
+constexpr int GT = 64, GK = 16, GLD = GT + 1;  // odd pitch: k-fast global loads scatter over all 32 LDS banks when stored k-major
+constexpr int GPF = 6;   // K chunks in flight per thread: most of these GEMMs are short (K = 256) and alone on the chip,
+                         // so what bounds them is the ~2 us global-load latency per dependent round, not bandwidth
 
 __global__ __launch_bounds__(256) void gemm_general_kernel(GemmP p) {
   __shared__ float As[2][GK][GLD];
@@ -81,48 +83,64 @@ __global__ __launch_bounds__(256) void gemm_general_kernel(GemmP p) {
   }
   // element -> (row, k) assignment follows whichever stride is 1 so that global loads coalesce
   const bool a_kfast = (p.sak == 1), b_nfast = (p.sbn == 1);
-  float ar[4], br[4];
-  auto load = [&](int k0) {
+  int am[4], ak[4], bn[4], bk[4];
+  const float* ap[4];
+  const float* bp[4];
+  bool aok[4], bok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int e = tid + i * 256;
+    am[i] = a_kfast ? (e >> 4) : (e & 63);
+    ak[i] = a_kfast ? (e & 15) : (e >> 6);
+    bn[i] = b_nfast ? (e & 63) : (e >> 4);
+    bk[i] = b_nfast ? (e >> 6) : (e & 15);
+    aok[i] = m0 + am[i] < p.M;
+    bok[i] = n0 + bn[i] < p.N;
+    // out-of-range rows / columns / k are loaded from a clamped (valid) address and zeroed afterwards: the loads stay
+    // unconditional, so all of them are in flight at once (a predicated load costs a branch region each)
+    ap[i] = p.A + (long)min(m0 + am[i], p.M - 1) * p.sam;
+    bp[i] = p.B + (long)min(n0 + bn[i], p.N - 1) * p.sbn;
+  }
+  float ar[GPF][4], br[GPF][4];
+  const int nchunks = (kend - kbeg + GK - 1) / GK;
+  auto load = [&](int c, float (&a)[4], float (&b)[4]) {
+    const int k0 = kbeg + c * GK;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int e = tid + i * 256;
-      const int am = a_kfast ? (e >> 4) : (e & 63), ak = a_kfast ? (e & 15) : (e >> 6);
-      const int gm = m0 + am, gk = k0 + ak;
-      ar[i] = (gm < p.M && gk < kend) ? p.A[(long)gm * p.sam + (long)gk * p.sak] : 0.f;
-      const int bn = b_nfast ? (e & 63) : (e >> 4), bk = b_nfast ? (e >> 6) : (e & 15);
-      const int gn = n0 + bn, gk2 = k0 + bk;
-      br[i] = (gn < p.N && gk2 < kend) ? p.B[(long)gk2 * p.sbk + (long)gn * p.sbn] : 0.f;
-    }
-  };
-  auto store = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int e = tid + i * 256;
-      const int am = a_kfast ? (e >> 4) : (e & 63), ak = a_kfast ? (e & 15) : (e >> 6);
-      As[buf][ak][am] = ar[i];
-      const int bn = b_nfast ? (e & 63) : (e >> 4), bk = b_nfast ? (e >> 6) : (e & 15);
-      Bs[buf][bk][bn] = br[i];
+      const int ka = k0 + ak[i], kb = k0 + bk[i];
+      const float va = ap[i][(long)min(ka, kend - 1) * p.sak];
+      const float vb = bp[i][(long)min(kb, kend - 1) * p.sbk];
+      a[i] = (aok[i] && ka < kend) ? va : 0.f;
+      b[i] = (bok[i] && kb < kend) ? vb : 0.f;
     }
   };
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  load(kbeg);
-  store(0);
-  __syncthreads();
-  int buf = 0;
-  for (int k0 = kbeg; k0 < kend; k0 += GK) {
-    const bool more = k0 + GK < kend;
-    if (more) load(k0 + GK);
 #pragma unroll
-    for (int kk = 0; kk < GK; kk += 2) {
-      const float a = As[buf][kk + (lane >> 5)][wm + (lane & 31)];
-      const float b = Bs[buf][kk + (lane >> 5)][wn + (lane & 31)];
-      acc = mfma32(a, b, acc);
+  for (int u = 0; u < GPF; ++u)
+    if (u < nchunks) load(u, ar[u], br[u]);
+  for (int c0 = 0; c0 < nchunks; c0 += GPF) {
+#pragma unroll
+    for (int u = 0; u < GPF; ++u) {
+      const int c = c0 + u;
+      if (c < nchunks) {
+        const int buf = u & 1;   // GPF is even, so the parity of c is the parity of u
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          As[buf][ak[i]][am[i]] = ar[u][i];
+          Bs[buf][bk[i]][bn[i]] = br[u][i];
+        }
+        if (c + GPF < nchunks) load(c + GPF, ar[u], br[u]);
+        lds_barrier();
+#pragma unroll
+        for (int kk = 0; kk < GK; kk += 2) {
+          const float a = As[buf][kk + (lane >> 5)][wm + (lane & 31)];
+          const float b = Bs[buf][kk + (lane >> 5)][wn + (lane & 31)];
+          acc = mfma32(a, b, acc);
+        }
+      }
     }
-    if (more) store(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
   }
   const int n = n0 + wn + (lane & 31);
   if (n >= p.N) return;
@@ -141,6 +159,76 @@ __global__ __launch_bounds__(256) void gemm_general_kernel(GemmP p) {
       if (p.beta != 0.f) v += p.beta * *c;
       *c = v;
     }
+  }
+}
+
+// x W^T flavour for launches too small to fill the chip (the forward GEMMs of one decoder pass are <= 44 64x64 tiles
+// on 256 CUs, and a CU needs >= 3.7 us of f32 MFMA for one 64x64x256 tile): 32x32 tiles, one per workgroup, so 4x
+// more CUs work; the 4 waves of a workgroup take one K-quarter each and are reduced through LDS.  Both operands are
+// contiguous along k, so there is no LDS staging: lane l reads 4 consecutive k of row (l & 31) at k offset
+// 4 * (l >> 5) inside every 8-k group - one 16-byte load feeds 4 MFMAs - with one exposed load latency and no barrier
+// in the K loop.  Needs K % 32 == 0 and 16-byte aligned rows.
+constexpr int GS = 4, KT = 32;
+__global__ __launch_bounds__(256) void gemm_kk_kernel(GemmP p) {
+  __shared__ float red[GS - 1][KT][KT + 1];
+  const int lane = threadIdx.x & 63, kq = threadIdx.x >> 6;
+  const int m0 = blockIdx.y * KT, n0 = blockIdx.x * KT;
+  const int kper = p.K / GS;                 // multiple of 8
+  const int kb = kq * kper;
+  const float* a = p.A + (long)min(m0 + (lane & 31), p.M - 1) * p.sam + kb + 4 * (lane >> 5);
+  const float* b = p.B + (long)min(n0 + (lane & 31), p.N - 1) * p.sbn + kb + 4 * (lane >> 5);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  constexpr int ST = 8;                      // 8-k groups per stage (64 k)
+  f32x4 va[2][ST], vb[2][ST];
+  const int ngroups = kper / 8;
+  auto load = [&](int g0, f32x4 (&xa)[ST], f32x4 (&xb)[ST]) {
+#pragma unroll
+    for (int g = 0; g < ST; ++g) {
+      const int gg = min(g0 + g, ngroups - 1);   // clamped (valid) address; unused groups are skipped below
+      xa[g] = *(const f32x4*)(a + 8 * gg);
+      xb[g] = *(const f32x4*)(b + 8 * gg);
+    }
+  };
+  load(0, va[0], vb[0]);
+  for (int g0 = 0; g0 < ngroups; g0 += 2 * ST) {
+    if (g0 + ST < ngroups) load(g0 + ST, va[1], vb[1]);
+#pragma unroll
+    for (int g = 0; g < ST; ++g)
+      if (g0 + g < ngroups) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = mfma32(va[0][g][j], vb[0][g][j], acc);
+      }
+    if (g0 + 2 * ST < ngroups) load(g0 + 2 * ST, va[0], vb[0]);
+#pragma unroll
+    for (int g = 0; g < ST; ++g)
+      if (g0 + ST + g < ngroups) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = mfma32(va[1][g][j], vb[1][g][j], acc);
+      }
+  }
+  const int col = lane & 31;
+  if (kq > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[kq - 1][(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][col] = acc[r];
+  }
+  __syncthreads();
+  if (kq != 0) return;
+  const int n = n0 + col;
+  if (n >= p.N) return;
+  const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int m = m0 + row;
+    if (m >= p.M) continue;
+    float v = ((acc[r] + red[0][row][col]) + (red[1][row][col] + red[2][row][col])) + bias;
+    if (p.relu) v = fmaxf(v, 0.f);
+    v *= p.drop.mask((uint64_t)(p.row0 + m) * (uint64_t)p.N + (uint64_t)n);
+    float* c = p.C + (long)m * p.ldc + n;
+    if (p.beta != 0.f) v += p.beta * *c;
+    *c = v;
   }
 }
 
@@ -531,9 +619,14 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* logit, lo
 __global__ __launch_bounds__(256) void xent_kernel(const float* logit, const long long* tgt, long tgt_ld,
                                                    const int* tgt_len, int T, int V, float smoothing,
                                                    float* row_loss, float* dlogit, float gscale,
-                                                   const float* gscale_dev) {
+                                                   const float* gscale_dev, int N) {
   __shared__ float red[4];
   const int row = blockIdx.x, n = row / T, t = row % T;
+  if (gscale <= 0.f) {  // "mean" with the count taken from tgt_len on the device (graph-replayable)
+    int cnt = 0;
+    for (int i = 0; i < N; ++i) cnt += min(tgt_len[i], T);
+    gscale = 1.0f / (float)cnt;
+  }
   const float* z = logit + (long)row * V;
   const bool valid = t < tgt_len[n];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -580,8 +673,13 @@ __global__ __launch_bounds__(256) void xent_kernel(const float* logit, const lon
     }
   }
 }
-__global__ void sum_scale_kernel(const float* x, long n, float scale, float* out) {
+__global__ void sum_scale_kernel(const float* x, long n, float scale, float* out, const int* tgt_len, int N, int T) {
   __shared__ float red[4];
+  if (scale <= 0.f) {
+    int cnt = 0;
+    for (int i = 0; i < N; ++i) cnt += min(tgt_len[i], T);
+    scale = 1.0f / (float)cnt;
+  }
   float a = 0.f;
   for (long i = threadIdx.x; i < n; i += 256) a += x[i];
   a = wave_sum(a);
@@ -764,7 +862,12 @@ int ac_gemm(const float* A, long sam, long sak, const float* B, long sbk, long s
   p.drop = make_drop(drop_p, drop_seed, seed_dev);
   p.row0 = row0;
   dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT, p.splitk);
-  hipLaunchKernelGGL(gemm_general_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+  const bool small = p.splitk == 1 && grid.x * grid.y <= 256 && K >= 128;
+  if (small && sak == 1 && sbk == 1 && K % 32 == 0 && sam % 4 == 0 && sbn % 4 == 0 &&
+      ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0)
+    hipLaunchKernelGGL(gemm_kk_kernel, dim3((N + KT - 1) / KT, (M + KT - 1) / KT), dim3(256), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(gemm_general_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
   return ac_check_launch();
 }
 
@@ -940,8 +1043,9 @@ int ac_label_smoothing_loss(const float* logit, const long long* tgt, long tgt_l
                             const float* gscale_dev, void* stream) {
   if (!logit || !tgt || !tgt_len || !row_loss || !loss || N <= 0 || T <= 0 || V <= 1) return AC_ERR_ARG;
   hipLaunchKernelGGL(xent_kernel, dim3(N * T), dim3(256), 0, (hipStream_t)stream, logit, tgt, tgt_ld, tgt_len, T, V,
-                     smoothing, row_loss, dlogit, gscale, gscale_dev);
-  hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, row_loss, (long)N * T, inv_count, loss);
+                     smoothing, row_loss, dlogit, gscale, gscale_dev, N);
+  hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, row_loss, (long)N * T, inv_count, loss,
+                     tgt_len, N, T);
   return ac_check_launch();
 }
 

@@ -146,8 +146,9 @@ class TrainEngine:
         self.flat = None
         self._ws = {}
         self.seed = int(seed)          # bumped after every forward (fresh dropout masks per step)
-        self._seed_dev = None
+        self._seed_ptr = None
         self._saved = None
+        self._states = {}
 
     # ---- small launch helpers (raw addresses; s = stream handle) ------------------------------------------
     def _gemm(self, s, A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, bias=None, relu=0, beta=0.0, splitk=1, drop_p=0.0,
@@ -181,17 +182,12 @@ class TrainEngine:
     def _ensure(self, device):
         if self.flat is None or not self.flat.intact() or self.flat.flat.device != device:
             self.flat = FlatParams(self.model)
+            self._states = {}
             _lib.bump_param_generation()
-        if self._seed_dev is None or self._seed_dev.device != device:
-            self._seed_dev = torch.zeros(1, device=device, dtype=torch.int64)
-            self._seed_host = torch.zeros(1, dtype=torch.int64).pin_memory()
-        self._seed_ptr = self._seed_dev.data_ptr()
 
-    def _layout(self, ws, N, T, Tm, lens_host, teacher_forcing, device):
-        """Static index tables of the row space (cached per shape)."""
-        key = (N, T, Tm, tuple(int(v) for v in lens_host), teacher_forcing)
-        if ws.t.get("_layout_key") == key:
-            return ws.t["_layout"]
+    @staticmethod
+    def _layout(N, T, Tm, teacher_forcing, device):
+        """Static index tables of the row space."""
         if teacher_forcing:
             passes = [(T, 0)]
         else:
@@ -207,31 +203,24 @@ class TrainEngine:
         cls_rows = torch.empty(N * T, dtype=torch.int32)
         for t, (L, off) in enumerate(passes):
             pos[off:off + N * L] = torch.arange(L, dtype=torch.int32).repeat(N)
-            for n in range(N):
-                qrow0[t * N + n] = off + n * L
-                qlen[t * N + n] = L
-                if teacher_forcing:
-                    cls_rows[n * T:(n + 1) * T] = torch.arange(off + n * L, off + (n + 1) * L, dtype=torch.int32)
-                else:
-                    cls_rows[n * T + t] = off + n * L + t
-        mrow0 = torch.arange(S, dtype=torch.int32) * Tm
-        mklen = torch.full((S,), Tm, dtype=torch.int32)
-        mvalid = torch.as_tensor(lens_host, dtype=torch.int32).repeat(len(passes))
+            qrow0[t * N:(t + 1) * N] = off + torch.arange(N, dtype=torch.int32) * L
+            qlen[t * N:(t + 1) * N] = L
+            if teacher_forcing:
+                cls_rows[:] = torch.arange(N * T, dtype=torch.int32)
+            else:
+                cls_rows[t::T] = off + torch.arange(N, dtype=torch.int32) * L + t
         lay = {"passes": passes, "R": R, "S": S}
-        for k, v in (("pos", pos), ("qrow0", qrow0), ("qlen", qlen), ("cls_rows", cls_rows), ("mrow0", mrow0),
-                     ("mklen", mklen), ("mvalid", mvalid)):
+        for k, v in (("pos", pos), ("qrow0", qrow0), ("qlen", qlen), ("cls_rows", cls_rows),
+                     ("mrow0", torch.arange(S, dtype=torch.int32) * Tm), ("mklen", torch.full((S,), Tm, dtype=torch.int32))):
             lay[k] = v.to(device)
-        ws.t["_layout_key"], ws.t["_layout"] = key, lay
         return lay
 
-    # ---- forward ------------------------------------------------------------------------------------------
-    def forward(self, input_dict):
-        """The reference's ``model(input_dict)`` for mode "train": returns ``logit`` (N, T, V) [+ ``seq``] as plain
-        device tensors and keeps what the backward needs."""
-        model, lib = self.model, self.lib
+    # ---- host side of one iteration: shapes, static input buffers, scheduled-sampling draws, seed -------------
+    def _prepare(self, input_dict):
+        model = self.model
         enc, dec = model.encoder, model.decoder
         if not model.training:
-            raise RuntimeError("TrainEngine.forward needs model.train() (run.py:79)")
+            raise RuntimeError("TrainEngine needs model.train() (run.py:79)")
         if input_dict.get("specaug", False):
             raise NotImplementedError("TrainEngine: SpecAugment is not built (the reference config disables it, "
                                       "cnn14rnn_trm.yaml:38)")
@@ -240,54 +229,98 @@ class TrainEngine:
         if not wav.is_cuda:
             raise _lib.HipLibraryError("the training step needs tensors on a ROCm device; there is no CPU fallback")
         self._ensure(dev)
-        fp = self.flat
-        s = _lib.stream()
-        cap = input_dict["cap"].to(device=dev, dtype=torch.int64).contiguous()
+        cap = input_dict["cap"]
         N, Tc = cap.shape
         T = Tc - 1
         ss_ratio = input_dict["ss_ratio"]
         teacher_forcing = ss_ratio == 1
-        # one draw per step, exactly the reference's call pattern (transformer_model.py:44)
-        use_cap = [1] * T if teacher_forcing else [int(random.random() < ss_ratio) for _ in range(T)]
-        use_cap = input_dict.get("_use_cap", use_cap)
+        hook = input_dict.get("_cnn_attn")    # parity-test hook: start downstream of the (un-pinned) mel front-end
+        if hook is None:
+            Tq = enc.cnn.geometry(wav.shape[1])[1][5]
+        else:
+            Tq = hook.shape[1]
         p_dec = float(dec.in_dropout.p)
         p_rnn = float(enc.rnn.network.dropout)
         p_cnn = 0.2 if enc.cnn.training else 0.0
-        base_seed = int(input_dict.get("dropout_seed", self.seed))
-        self.seed = base_seed + 1
-        self._seed_host[0] = base_seed
-        self._seed_dev.copy_(self._seed_host, non_blocking=True)
-
-        # ---- frozen Cnn14 (train mode: dropout after every block) and feature lengths -------------------
-        if "_cnn_attn" in input_dict:   # parity-test hook: start downstream of the (un-pinned) mel front-end
-            cnn_attn = input_dict["_cnn_attn"].to(device=dev, dtype=torch.float32).contiguous()
-        else:
-            cnn_attn = enc.cnn.encode(wav, dropout=(p_cnn, OP_CNN_BLOCK, self._seed_ptr) if p_cnn > 0 else None)
-        lens = cnn14_feat_len(input_dict["wav_len"], enc.cnn.hop_length, enc.cnn.downsample_ratio)
-        B, Tq, Cin = cnn_attn.shape
-        if B != N:
+        key = (dev, N, Tc, tuple(wav.shape) if hook is None else ("hook", Tq), teacher_forcing, p_dec, p_rnn, p_cnn,
+               model.start_idx, model.pad_idx)
+        st = self._states.get(key)
+        if st is None:
+            lay = self._layout(N, T, Tq, teacher_forcing, dev)
+            S = lay["S"]
+            st = {"key": key, "ws": _Ws(dev), "lay": lay, "N": N, "T": T, "Tc": Tc, "Tq": Tq, "teacher_forcing": teacher_forcing,
+                  "p_dec": p_dec, "p_rnn": p_rnn, "p_cnn": p_cnn, "graph": None, "steps": 0,
+                  "wav": torch.empty_like(wav, dtype=torch.float32) if hook is None else None,
+                  "cnn_attn_in": torch.empty(N, Tq, 2048, device=dev) if hook is not None else None,
+                  "cap": torch.empty(N, Tc, device=dev, dtype=torch.int64),
+                  # one pinned staging block -> one device block (int32 words):
+                  #   seed (int64) | lens [N] | tgt_len [N] | use_cap [T] | mvalid [S]
+                  # a ring of staging blocks, each guarded by an event, because the host runs ahead of the device
+                  "ring": [(torch.zeros(2 + 2 * N + max(T, 1) + S, dtype=torch.int32).pin_memory(), torch.cuda.Event())
+                           for _ in range(4)],
+                  "small": torch.zeros(2 + 2 * N + max(T, 1) + S, device=dev, dtype=torch.int32)}
+            self._states[key] = st
+        if wav.shape[0] != N:
             raise ValueError("cap and wav batch sizes differ")
+        lens = cnn14_feat_len(input_dict["wav_len"], enc.cnn.hop_length, enc.cnn.downsample_ratio)
         if int(lens.min()) < 1 or int(lens.max()) > Tq:
             raise ValueError("attn_len must lie in [1, attn.size(1)]")
-        Tm = int(lens.max())
-        key = (dev, N, T, Tq, Tm)
-        ws = self._ws.get(key)
-        if ws is None:
-            ws = self._ws[key] = _Ws(dev)
-        lens_dev = lens.to(device=dev, dtype=torch.int32)
-        ws.t["lens"] = lens_dev
-        lay = self._layout(ws, N, T, Tm, lens.tolist(), teacher_forcing, dev)
+        # one draw per step, exactly the reference's call pattern (transformer_model.py:44)
+        use_cap = [1] * T if teacher_forcing else [int(random.random() < ss_ratio) for _ in range(T)]
+        use_cap = input_dict.get("_use_cap", use_cap)
+        S = st["lay"]["S"]
+        base_seed = int(input_dict.get("dropout_seed", self.seed))
+        self.seed = base_seed + 1
+        h, ev = st["ring"][st["steps"] % len(st["ring"])]
+        ev.synchronize()                       # the copy that last used this staging block has completed
+        h[:2].view(torch.int64)[0] = base_seed
+        h[2:2 + N] = lens.to(torch.int32)
+        if "cap_len" in input_dict:
+            h[2 + N:2 + 2 * N] = (torch.as_tensor(input_dict["cap_len"]).to(torch.int32) - 1).clamp(max=T)
+        h[2 + 2 * N:2 + 2 * N + T] = torch.as_tensor(use_cap, dtype=torch.int32)
+        h[2 + 2 * N + max(T, 1):] = lens.to(torch.int32).repeat(S // N)
+        st["small"].copy_(h, non_blocking=True)
+        ev.record()
+        if hook is None:
+            st["wav"].copy_(wav, non_blocking=True)
+        else:
+            st["cnn_attn_in"].copy_(hook, non_blocking=True)
+        st["cap"].copy_(cap, non_blocking=True)
+        st["lens_host"] = lens
+        return st
+
+    # ---- forward launches (no host synchronisation, capturable) ---------------------------------------------------
+    def _launch_forward(self, st):
+        model, lib, fp = self.model, self.lib, self.flat
+        enc, dec = model.encoder, model.decoder
+        s = _lib.stream()
+        ws, lay = st["ws"], st["lay"]
+        N, T, Tc, Tq = st["N"], st["T"], st["Tc"], st["Tq"]
+        p_dec, p_rnn, p_cnn = st["p_dec"], st["p_rnn"], st["p_cnn"]
+        teacher_forcing = st["teacher_forcing"]
+        small = st["small"].data_ptr()
+        self._seed_ptr = small
+        lens_p, ucap, mvalid = small + 8, small + 4 * (2 + 2 * N), small + 4 * (2 + 2 * N + max(T, 1))
         R, S, passes = lay["R"], lay["S"], lay["passes"]
         NP = len(passes)
+        Tm = Tq
+        B = N
         rows_g = B * Tq
+        # frozen Cnn14 (train mode: dropout after every block)
+        if st["cnn_attn_in"] is not None:
+            cnn_attn = st["cnn_attn_in"]
+        else:
+            cnn_attn = enc.cnn.encode(st["wav"], dropout=(p_cnn, OP_CNN_BLOCK, self._seed_ptr) if p_cnn > 0 else None)
+        st["cnn_attn"] = cnn_attn
+        Cin = cnn_attn.shape[2]
 
         # ---- GRU, saving the gates -------------------------------------------------------------------
         nl = enc.rnn.num_layers
         x_in = cnn_attn.data_ptr()
         in_dim = Cin
         gru = []
+        pre = "encoder.rnn.network."
         for l in range(nl):
-            pre = f"encoder.rnn.network."
             w_ih, w_hh = fp.p(f"{pre}weight_ih_l{l}"), fp.p(f"{pre}weight_hh_l{l}")
             b_ih, b_hh = fp.p(f"{pre}bias_ih_l{l}"), fp.p(f"{pre}bias_hh_l{l}")
             gx = ws.f(f"gx{l}", rows_g, 6 * H)
@@ -296,8 +329,7 @@ class TrainEngine:
             check(lib.ac_transpose(w_hh, whhT, 2, 3 * H, H, s), "ac_transpose")
             out = ws.f(f"gru_out{l}", rows_g, 2 * H)
             save = ws.f(f"gru_save{l}", rows_g, 2 * 4 * H)
-            check(lib.ac_gru_layer_train(gx, whhT, b_hh, lens_dev.data_ptr(), out, save, B, Tq, H, s),
-                  "ac_gru_layer_train")
+            check(lib.ac_gru_layer_train(gx, whhT, b_hh, lens_p, out, save, B, Tq, H, s), "ac_gru_layer_train")
             nxt = out
             if l < nl - 1 and p_rnn > 0:
                 nxt = ws.f(f"gru_drop{l}", rows_g, 2 * H)
@@ -305,13 +337,10 @@ class TrainEngine:
                       "ac_dropout")
             gru.append({"x": x_in, "in_dim": in_dim, "out": out})
             x_in, in_dim = nxt, 2 * H
-        # attn_emb (B, Tm, 512): pad_packed_sequence truncates to the longest clip
-        if Tm < Tq:
-            attn_emb_t = ws.tensor(f"gru_out{nl - 1}")[:rows_g * 2 * H].view(B, Tq, 2 * H)[:, :Tm].contiguous()
-            ws.t["attn_emb_c"] = attn_emb_t
-            attn_emb = attn_emb_t.data_ptr()
-        else:
-            attn_emb = x_in
+        # attn_emb (B, Tq, 512).  The reference truncates it to the longest clip (pad_packed_sequence); the frames
+        # beyond a clip's length are zero and masked as keys, so keeping all Tq frames changes no result and keeps
+        # the shapes static.
+        attn_emb = x_in
         A = 2 * H
 
         # ---- decoder: audio memory (shared by all passes up to its dropout mask) ---------------------
@@ -337,13 +366,9 @@ class TrainEngine:
         # ---- the passes ------------------------------------------------------------------------------
         word = ws.i("word", R)
         seq = ws.i("seq", N * T)
-        ucap = ws.i("use_cap", max(T, 1))
-        ucap_host = torch.tensor(use_cap if len(use_cap) else [1], dtype=torch.int32)
-        ws.tensor("use_cap")[:len(ucap_host)].copy_(ucap_host)
-        logit_t = torch.empty(N, T, V, device=dev, dtype=torch.float32)
-        logit = logit_t.data_ptr()
+        logit = ws.f("logit", N * T, V)
         pos, qrow0, qlen = lay["pos"].data_ptr(), lay["qrow0"].data_ptr(), lay["qlen"].data_ptr()
-        mrow0, mklen, mvalid = lay["mrow0"].data_ptr(), lay["mklen"].data_ptr(), lay["mvalid"].data_ptr()
+        mrow0, mklen = lay["mrow0"].data_ptr(), lay["mklen"].data_ptr()
         emb, pe, cls = fp.p(dp + "word_embedding.weight"), dec.pos_encoder.pe.data_ptr(), fp.p(dp + "classifier.weight")
         nh = dec.nhead
         P1 = [ws.f(f"P1_{l}", S * nh * T * T) for l in range(nlay)]     # attention probabilities, kept per layer
@@ -356,7 +381,7 @@ class TrainEngine:
                                                        ("hdn", F), ("ff", D), ("pre3", D))}
             a["x3"] = ws.f(f"x_l{l + 1}", R, D)
             acts.append(a)
-        cap_p = cap.data_ptr()
+        cap_p = st["cap"].data_ptr()
         for t, (L, off) in enumerate(passes):
             nr = N * L
             o4 = 4 * off * D
@@ -403,12 +428,26 @@ class TrainEngine:
                 # classifier on the last position of every sequence of this pass -> logit[:, t]
                 self._lin(s, x + o4 + 4 * t * D, cls, None, logit + 4 * t * V, N, V, D, ldx=L * D, ldy=T * V)
                 check(lib.ac_argmax_rows(logit + 4 * t * V, T * V, N, V, seq + 4 * t, T, s), "ac_argmax_rows")
-        self._saved = dict(ws=ws, lay=lay, N=N, T=T, Tm=Tm, Tq=Tq, B=B, V=V, F=F, p_dec=p_dec, p_rnn=p_rnn, gru=gru,
-                           kv=kv, acts=acts, x0=x0, word=word, P1=P1, P2=P2, mem=mem, mem_pre=mem_pre, mem_a=mem_a,
-                           attn_emb=attn_emb, logit=logit_t, cnn_attn=cnn_attn, cap=cap, teacher_forcing=teacher_forcing)
-        out = {"logit": logit_t, "attn_emb_len": lens}
-        if not teacher_forcing:
-            out["seq"] = ws.tensor("seq")[:N * T].view(N, T).to(torch.int64)
+        st.update(V=V, F=F, gru=gru, kv=kv, acts=acts, x0=x0, word=word, P1=P1, P2=P2, mem=mem, mem_pre=mem_pre,
+                  mem_a=mem_a, attn_emb=attn_emb)
+
+    def _outputs(self, st):
+        N, T, V = st["N"], st["T"], st["V"]
+        out = {"logit": st["ws"].tensor("logit")[:N * T * V].view(N, T, V), "attn_emb_len": st["lens_host"]}
+        if not st["teacher_forcing"]:
+            out["seq"] = st["ws"].tensor("seq")[:N * T].view(N, T)
+        return out
+
+    def forward(self, input_dict):
+        """The reference's ``model(input_dict)`` for mode "train": returns ``logit`` (N, T, V) [+ ``seq``] as fresh
+        device tensors and keeps what the backward needs."""
+        st = self._prepare(input_dict)
+        self._launch_forward(st)
+        self._saved = st
+        out = self._outputs(st)
+        out["logit"] = out["logit"].clone()
+        if "seq" in out:
+            out["seq"] = out["seq"].to(torch.int64)
         return out
 
     # ---- backward -----------------------------------------------------------------------------------------
@@ -419,11 +458,18 @@ class TrainEngine:
         if sv is None:
             raise RuntimeError("TrainEngine.backward without a forward")
         self._saved = None
+        dlogit = dlogit.contiguous()
+        if dlogit.dtype != torch.float32:
+            dlogit = dlogit.float()
+        self._launch_backward(sv, dlogit.data_ptr())
+
+    def _launch_backward(self, sv, dl):
         model, lib, fp = self.model, self.lib, self.flat
         enc, dec = model.encoder, model.decoder
         s = _lib.stream()
         ws, lay = sv["ws"], sv["lay"]
-        N, T, Tm, Tq, B, V, F = sv["N"], sv["T"], sv["Tm"], sv["Tq"], sv["B"], sv["V"], sv["F"]
+        N, T, Tq, V, F = sv["N"], sv["T"], sv["Tq"], sv["V"], sv["F"]
+        B, Tm = N, Tq
         p_dec, p_rnn = sv["p_dec"], sv["p_rnn"]
         R, S = lay["R"], lay["S"]
         NP = len(lay["passes"])
@@ -432,11 +478,8 @@ class TrainEngine:
         nh = dec.nhead
         nlay = dec.nlayers
         dp = "decoder."
-        dlogit = dlogit.contiguous()
-        if dlogit.dtype != torch.float32:
-            dlogit = dlogit.float()
-        dl = dlogit.data_ptr()
         fp.grad.zero_()
+        self._seed_ptr = sv["small"].data_ptr()
         qrow0, qlen = lay["qrow0"].data_ptr(), lay["qlen"].data_ptr()
         mrow0, mklen = lay["mrow0"].data_ptr(), lay["mklen"].data_ptr()
         cls_rows = lay["cls_rows"].data_ptr()
@@ -527,19 +570,12 @@ class TrainEngine:
         self._colsum(s, da, D, fp.g(dp + "attn_proj.0.bias"), rows_m, D)
         rows_g = B * Tq
         dout = ws.f("gru_dout", rows_g, A)
-        if Tm < Tq:
-            dtmp = ws.f("gru_dout_c", rows_m, A)
-            self._lin_dx(s, da, fp.p(dp + "attn_proj.0.weight"), dtmp, rows_m, D, A)
-            full = ws.tensor("gru_dout")[:rows_g * A].view(B, Tq, A)
-            full.zero_()
-            full[:, :Tm].copy_(ws.tensor("gru_dout_c")[:rows_m * A].view(B, Tm, A))
-        else:
-            self._lin_dx(s, da, fp.p(dp + "attn_proj.0.weight"), dout, rows_m, D, A)
-        lens_p = ws.tensor("lens").data_ptr()
+        self._lin_dx(s, da, fp.p(dp + "attn_proj.0.weight"), dout, rows_m, D, A)
+        lens_p = sv["small"].data_ptr() + 8
         nl = enc.rnn.num_layers
         dgx, dgh, hprev = ws.f("dgx", rows_g, 6 * H), ws.f("dgh", rows_g, 6 * H), ws.f("hprev", rows_g, 2 * H)
+        pre = "encoder.rnn.network."
         for l in reversed(range(nl)):
-            pre = "encoder.rnn.network."
             g = sv["gru"][l]
             if l < nl - 1 and p_rnn > 0:
                 check(lib.ac_dropout(dout, dout, rows_g * A, p_rnn, OP_GRU_LAYER + l, self._seed_ptr, 0, s), "ac_dropout")
@@ -556,28 +592,48 @@ class TrainEngine:
             if l > 0:
                 self._lin_dx(s, dgx, fp.p(f"{pre}weight_ih_l{l}"), dout, rows_g, 6 * H, g["in_dim"])
 
-
     # ---- fast path: forward + loss + backward (+ gradient all-reduce) + clip + Adam -----------------------
-    def step(self, input_dict, optimizer, smoothing=0.1, max_grad_norm=1.0, process_group=None):
-        """One training iteration (run.py:106-126) without leaving the HIP path: returns the loss as a device scalar.
-        Gradients go straight into the flat buffer (= the parameters' ``.grad``); with ``torch.distributed``
-        initialised they are summed over the ranks in ONE all-reduce and the division by the world size is folded
-        into the clip coefficient."""
-        from .loss import _launch
+    def _launch_step_body(self, st, smoothing):
+        """forward, label-smoothing loss (mean over the valid target tokens, counted on the device) and backward."""
+        self._launch_forward(st)
+        N, T, Tc, V = st["N"], st["T"], st["Tc"], st["V"]
+        ws = st["ws"]
+        logit = ws.f("logit", N * T, V)
+        dlogit = ws.f("dlogit", N * T, V)
+        row_loss, loss = ws.f("row_loss", N * T), ws.f("loss", 1)
+        tgt_len = st["small"].data_ptr() + 4 * (2 + N)
+        check(self.lib.ac_label_smoothing_loss(logit, st["cap"].data_ptr() + 8, Tc, tgt_len, N, T, V, float(smoothing), 0.0,
+                                               row_loss, loss, dlogit, 0.0, None, _lib.stream()),
+              "ac_label_smoothing_loss")
+        self._launch_backward(st, dlogit)
+
+    def step(self, input_dict, optimizer, smoothing=0.1, max_grad_norm=1.0, process_group=None, use_graph=True):
+        """One training iteration (run.py:106-126) without leaving the HIP path; returns the loss as a device scalar.
+
+        The ~700 launches of forward + loss + backward are latency-bound at the reference's batch sizes, so for each
+        batch shape they are captured ONCE into a HIP graph over static buffers (second iteration of that shape) and
+        replayed; the per-iteration data - audio, captions, lengths, the scheduled-sampling draws and the dropout
+        seed - are copied into those buffers first.  Gradients land in the flat buffer (= the parameters' ``.grad``);
+        with ``torch.distributed`` initialised they are summed over the ranks in ONE all-reduce and the division by
+        the world size is folded into the clip coefficient; clip + Adam are three launches on the flat buffers."""
         from .optim import FusedAdam, clip_grad_norm_
         import torch.distributed as dist
-        out = self.forward(input_dict)
-        sv = self._saved
-        logit = out["logit"]
-        N, T, _ = logit.shape
-        cap = sv["cap"]
-        tgt = cap[:, 1:]
-        tgt_len = torch.as_tensor(input_dict["cap_len"]).cpu().long() - 1
-        count = float(torch.clamp(tgt_len, max=T).sum())
-        tgt_len_dev = tgt_len.to(device=logit.device, dtype=torch.int32)
-        dlogit = torch.empty_like(logit)
-        loss, _ = _launch(logit, tgt, tgt_len_dev, smoothing, 1.0 / count, dlogit, 1.0 / count, None)
-        self.backward(dlogit)
+        if "cap_len" not in input_dict:
+            raise KeyError("cap_len")
+        st = self._prepare(input_dict)
+        st["steps"] += 1
+        if not use_graph:
+            self._launch_step_body(st, smoothing)
+        elif st["graph"] is None and st["steps"] < 2:
+            self._launch_step_body(st, smoothing)          # first iteration of this shape: eager (also the warm-up)
+        else:
+            if st["graph"] is None or st["graph_key"] != (smoothing, _lib.param_generation_flat(self)):
+                torch.cuda.synchronize(st["cap"].device)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self._launch_step_body(st, smoothing)
+                st["graph"], st["graph_key"] = graph, (smoothing, _lib.param_generation_flat(self))
+            st["graph"].replay()
         self.flat.attach_grads()
         world = 1
         if dist.is_available() and dist.is_initialized():
@@ -592,7 +648,9 @@ class TrainEngine:
                                             _lib.stream()), "ac_scale_by_coef")
             optimizer.step()
             _lib.bump_param_generation()
-        return {"loss": loss[0], "total_norm": clip.total_norm, "logit": logit, "seq": out.get("seq")}
+        out = self._outputs(st)
+        return {"loss": st["ws"].tensor("loss")[0], "total_norm": clip.total_norm, "logit": out["logit"],
+                "seq": out.get("seq")}
 
 
 class _TrainBridge(torch.autograd.Function):

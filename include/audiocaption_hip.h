@@ -247,7 +247,8 @@ int ac_colsum(const float* x, long ld, float* out, long M, int N, void* stream);
 int ac_argmax_rows(const float* logit, long ld, int rows, int V, int* out, long out_ld, void* stream);
 /* LabelSmoothingLoss (loss.py:51-74): logit [N][T][V], tgt int64 [N][tgt_ld], tgt_len int32 [N]; row_loss [N*T];
  * loss[0] = inv_count * sum(row_loss); dlogit (optional) = gscale [* gscale_dev[0]] * (softmax - q) on valid rows,
- * 0 elsewhere (gscale_dev: the upstream gradient of the loss when it lives on the device). */
+ * 0 elsewhere (gscale_dev: the upstream gradient of the loss when it lives on the device).  inv_count <= 0 /
+ * gscale <= 0 mean "1 / sum_n min(tgt_len[n], T)", computed on the device (reduction "mean" inside a HIP graph). */
 int ac_label_smoothing_loss(const float* logit, const long long* tgt, long tgt_ld, const int* tgt_len, int N, int T, int V,
                             float smoothing, float inv_count, float* row_loss, float* loss, float* dlogit, float gscale,
                             const float* gscale_dev, void* stream);

@@ -99,8 +99,10 @@ def gru_train_forward(state, attn, attn_len, base_seed, p=0.5, prefix="encoder.r
         x = torch.cat(outs, dim=-1)
         if l < num_layers - 1 and p > 0:
             x = x * _mask_t(op_seed(base_seed, OP_GRU_LAYER + l), 0, (B, T, x.shape[-1]), p)
-    t_out = int(lens.max())
-    return x[:, :t_out]
+    # The reference truncates to the longest clip (pad_packed_sequence); frames beyond a clip's length are zero
+    # and masked as attention keys, so all T frames are kept here, like the HIP path does (static shapes; the
+    # dropout mask of the audio memory is indexed over T frames per clip).
+    return x
 
 
 # ---------------------------------------------------------------------------------------------------------
