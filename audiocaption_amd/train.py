@@ -102,6 +102,19 @@ class FlatParams:
             p.grad = v
 
 
+def allreduce_flat_gradients(flat_grad, process_group=None):
+    """Sum the flat gradient buffer over the ranks (ONE collective for all 10.7 M gradients, the reference's DDP
+    all-reduce run_ddp.py:98-108) and return the world size; the division by it is folded into the clip coefficient
+    (``clip_grad_norm_(..., grad_div=world)``).  No-op without an initialised process group."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    world = dist.get_world_size(process_group)
+    if world > 1:
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=process_group)
+    return world
+
+
 class _Ws:
     """Named device buffers of one (N, T, Tm, ...) shape, allocated once."""
 
@@ -617,7 +630,6 @@ class TrainEngine:
         with ``torch.distributed`` initialised they are summed over the ranks in ONE all-reduce and the division by
         the world size is folded into the clip coefficient; clip + Adam are three launches on the flat buffers."""
         from .optim import FusedAdam, clip_grad_norm_
-        import torch.distributed as dist
         if "cap_len" not in input_dict:
             raise KeyError("cap_len")
         st = self._prepare(input_dict)
@@ -635,11 +647,7 @@ class TrainEngine:
                 st["graph"], st["graph_key"] = graph, (smoothing, _lib.param_generation_flat(self))
             st["graph"].replay()
         self.flat.attach_grads()
-        world = 1
-        if dist.is_available() and dist.is_initialized():
-            world = dist.get_world_size(process_group)
-            if world > 1:
-                dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=process_group)
+        world = allreduce_flat_gradients(self.flat.grad, process_group)
         clip = clip_grad_norm_(self.flat.params, max_grad_norm, grad_div=float(world), scale_now=False)
         if isinstance(optimizer, FusedAdam):
             optimizer.step(clip=clip)

@@ -27,6 +27,74 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
 
 
+def bench_train(args, world, rank, dev, dist, steps, warmup):
+    """Training iterations of the reference's recipe (run.py:77-148; cnn14rnn_trm.yaml): frozen Cnn14 with dropout,
+    bi-GRU, scheduled-sampling decoder (ss_ratio 0.85), LabelSmoothingLoss(0.1), backward, gradient all-reduce
+    (one RCCL call on the flat gradient buffer), clip_grad_norm_(1.0), Adam(5e-4, weight_decay 1e-6) - everything
+    inside the timed region, synthetic AudioCaps-shape batches resident in HBM."""
+    import random
+    import numpy as np
+    import audiocaption_amd as A
+    from audiocaption_amd import build, procedural as P
+    from audiocaption_amd.optim import FusedAdam
+    from audiocaption_amd.train import TrainEngine
+    build.build()
+    vocab, cap_len = 4981, 22   # AudioCaps vocabulary (cnn14rnn_trm.yaml:31); <bos> + 20 words + <eos>
+    model = A.init_model_from_config(A.cnn14rnn_trm_config(vocab), print_fn=lambda s: None)
+    model.load_state_dict(P.to_torch(P.cnn14rnn_trm_state(vocab)), strict=True)
+    model = model.to(dev).train()
+    B, L = args.train_batch, int(args.seconds * 32000)
+    wav = torch.from_numpy(P.synthetic_wav(B, L, seed=P.BASE_SEED + 100 + rank)).to(dev)
+    g = torch.Generator().manual_seed(1000 + rank)
+    cap = torch.randint(4, vocab, (B, cap_len), generator=g)
+    lens = torch.randint(8, cap_len + 1, (B,), generator=g)
+    lens[0] = cap_len
+    cap[:, 0] = 1
+    for i, n in enumerate(lens.tolist()):
+        cap[i, n - 1] = 2
+        cap[i, n:] = 0
+    batch = {"mode": "train", "wav": wav, "wav_len": [L] * B, "specaug": False, "cap": cap.to(dev),
+             "cap_len": np.asarray(lens), "ss_ratio": 0.85}
+    engine = TrainEngine(model, seed=rank * 1000003)
+    opt = FusedAdam([p for p in model.parameters() if p.requires_grad], lr=5e-4, weight_decay=1e-6)
+    random.seed(rank)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    r = None
+    for _ in range(warmup):
+        r = engine.step(batch, opt, smoothing=0.1, max_grad_norm=1.0)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r = engine.step(batch, opt, smoothing=0.1, max_grad_norm=1.0)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    loss = float(r["loss"])
+    n_param = engine.flat.total
+    return {
+        "metric": "clips/sec trained (forward+backward+Adam), Cnn14_Rnn-Trm, AudioCaps-shape batches",
+        "value": world * B * steps / elapsed, "unit": "clips/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16x3 frozen convolutions, f32 everything trained", "data": "synthetic",
+        "config": {"workload": f"training step, batch {B} per GPU ({world * B} global), {args.seconds:g} s @ 32 kHz clips, "
+                               f"captions of {cap_len} tokens, vocab {vocab}, scheduled sampling 0.85, dropout on "
+                               "(BASELINE configs[3]; the reference's own recipe is global batch 32)",
+                   "trainable_parameters": int(sum(p.numel() for p in engine.flat.params)),
+                   "gradient_sync": ("one all-reduce of the flat %.1f MB gradient buffer per step (RCCL)" % (n_param * 4e-6))
+                   if world > 1 else "single GPU: none",
+                   "last_loss": loss},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -40,6 +108,11 @@ def main():
     ap.add_argument("--sync-steps", action="store_true", help="blocking model(input_dict) per step (no overlap)")
     ap.add_argument("--cpu-clips", type=int, default=4, help="clips per CPU-baseline pass")
     ap.add_argument("--cpu-reps", type=int, default=3)
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+                    help="train: the JSON line is the TRAINING step (BASELINE configs[3]: forward + backward + Adam, "
+                         "gradients all-reduced over RCCL when N > 1)")
+    ap.add_argument("--train-batch", type=int, default=32, help="clips per GPU per training step")
+    ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -59,6 +132,15 @@ def main():
     import audiocaption_amd as A
     from audiocaption_amd import build, kernels as K, procedural as P
     build.build()
+
+    if args.mode == "train":
+        res = bench_train(args, world, rank, dev, dist, args.steps, max(args.warmup, 3))
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     vocab = 4368  # Clotho v2 (eg_configs/clotho_v2/waveform/cnn14rnn_trm.yaml:31)
     state = P.to_torch(P.cnn14rnn_trm_state(vocab))
@@ -155,6 +237,11 @@ def main():
                              "ms_per_step": fdt / max(2, args.steps // 2) * 1e3,
                              "value": world * B * max(2, args.steps // 2) / fdt, "unit": "clips/s"}
         cnn.conv_algo, cnn._packed = algo, None
+    if world == 1 and not args.no_train:
+        # secondary: the training step (BASELINE configs[3]) on this GPU
+        del out
+        tr = bench_train(args, world, rank, dev, dist, max(3, args.steps // 2), 3)
+        extra["train_step"] = {k: tr[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config")}
     result = None
     if rank == 0:
         clips = world * B * args.steps
@@ -195,6 +282,8 @@ def main():
             "reference on the golden fixtures" if algo.startswith("bf16x3") else "f32 end to end")
         if "f32_path" in extra:
             result["f32_path"] = extra["f32_path"]
+        if "train_step" in extra:
+            result["train_step"] = extra["train_step"]
         if not args.no_cpu_baseline and world == 1:
             from oracle import cpu_path as O  # the CPU restatement, timed as a reported baseline only
             nc = args.cpu_clips

@@ -1,0 +1,111 @@
+"""CPU tests of the training-step oracle and host logic: the oracle against the gradients the REFERENCE produced
+(tests/golden/g8_train.npz), the LR schedule, the dropout hash, and the flat-gradient all-reduce on gloo (world 2)."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+@pytest.mark.parametrize("tag", ["ss", "tf"])
+def test_oracle_training_step_matches_reference_gradients(golden_dir, state4981, tag):
+    from audiocaption_amd import procedural as P
+    from oracle import cpu_path as O
+    from oracle import train_path as OT
+    g8 = dict(np.load(os.path.join(golden_dir, "g8_train.npz")))
+    lms = torch.from_numpy(P.synthetic_logmel(4, 1001))
+    cnn_attn = O.cnn14_from_logmel(state4981, lms)
+    cap, cap_len = torch.from_numpy(g8["cap"]), g8["cap_len"]
+    use_cap = g8[f"{tag}_use_cap"].tolist()
+    o = OT.train_step_grads(state4981, cnn_attn, O.cnn14_feat_len(g8["wav_len"].tolist()), cap, cap_len, use_cap,
+                            p_dec=0.0, p_rnn=0.0, teacher_forcing=(tag == "tf"))
+    assert abs(float(o["loss"]) - float(g8[f"{tag}_loss"])) < 2e-5 * float(g8[f"{tag}_loss"])
+    top = o["logit"].topk(8, dim=-1)
+    assert np.abs(top.values.numpy() - g8[f"{tag}_logit_top_val"]).max() < 5e-5
+    if tag == "ss":
+        assert np.array_equal(o["seq"].numpy(), g8["ss_seq"])
+    for key, grad in o["grads"].items():
+        gn = float(g8[f"{tag}_gnorm/{key}"])
+        assert abs(float(grad.double().norm()) - gn) < 1e-4 * gn + 1e-12, key
+        sample = grad.reshape(-1)[torch.from_numpy(g8[f"sample_idx/{key}"])].numpy()
+        assert np.abs(sample - g8[f"{tag}_gsample/{key}"]).max() < 1e-4 * float(grad.abs().max()) + 1e-12, key
+    # clip + Adam: the total norm and the update on solid gradients
+    keys = list(o["grads"])
+    params = {k: state4981[k].clone() for k in keys}
+    m1 = {k: torch.zeros_like(v) for k, v in params.items()}
+    m2 = {k: torch.zeros_like(v) for k, v in params.items()}
+    norm = OT.clip_and_adam(params, o["grads"], m1, m2, 1)
+    assert abs(float(norm) - float(g8[f"{tag}_total_norm"])) < 1e-4 * float(norm)
+    for k in keys:
+        idx = torch.from_numpy(g8[f"sample_idx/{k}"])
+        delta = (params[k] - state4981[k]).reshape(-1)[idx].numpy()
+        gs = np.abs(g8[f"{tag}_gsample/{k}"])
+        solid = gs > 1e-5 * (gs.max() + 1e-30) + 1e-7
+        assert np.abs(delta - g8[f"{tag}_delta/{k}"])[solid].max(initial=0.0) < 5e-6, k
+
+
+def test_dropout_hash_properties():
+    from oracle import train_path as OT
+    a = OT.drop_mask(OT.op_seed(5, 31), 0, 200000, 0.2)
+    b = OT.drop_mask(OT.op_seed(5, 31), 1000, 1000, 0.2)
+    assert np.array_equal(a[1000:2000], b)                       # pure function of (seed, index)
+    assert set(np.unique(a)) == {np.float32(0.0), np.float32(1.25)}
+    assert abs((a > 0).mean() - 0.8) < 0.005
+    c = OT.drop_mask(OT.op_seed(6, 31), 0, 200000, 0.2)
+    assert 0.6 < (a == c).mean() < 0.76                          # independent streams agree on 0.8^2 + 0.2^2 = 0.68
+    assert np.all(OT.drop_mask(1, 0, 100, 0.0) == 1.0)
+
+
+def test_exponential_decay_scheduler_matches_the_reference_formula():
+    from audiocaption_amd.lr_scheduler import ExponentialDecayScheduler
+    from oracle import train_path as OT
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=5e-4)
+    total, warm = 200, 40          # run.py:249-251: warm-up = iterations // 5
+    sched = ExponentialDecayScheduler(opt, total_iters=total, final_lrs=5e-7, warmup_iters=warm)
+    lrs = []
+    for it in range(total):
+        sched.step()               # stepped before the optimiser, once per iteration (run.py:104-105)
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+    # closed form of lr_scheduler.py:22-42 (the constructor's implicit first step makes _step_count start at 1)
+    want = [OT.exponential_decay_lr(it + 2, 5e-4, 5e-7, total, warm) for it in range(total)]
+    np.testing.assert_allclose(lrs, want, rtol=1e-12)
+    assert lrs[warm - 2] == pytest.approx(5e-4) and lrs[0] == pytest.approx(5e-4 * 2 / warm)
+    assert lrs[-1] < 6e-7 * 1.2
+
+
+def _allreduce_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from audiocaption_amd.train import allreduce_flat_gradients
+        flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+        w = allreduce_flat_gradients(flat)
+        # the division by the world size is folded into the clip coefficient (csrc/train.hip clip_coef_kernel)
+        norm = float((flat / w).norm())
+        coef = min(1.0, 1.0 / (norm + 1e-6)) / w
+        out.put((rank, w, flat.clone(), coef))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_gradient_allreduce_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + random.randint(0, 400)
+    procs = [ctx.Process(target=_allreduce_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = torch.arange(1000, dtype=torch.float32) * 3
+    for rank, w, flat, coef in res:
+        assert w == 2 and torch.equal(flat, want)
+        avg = want / 2
+        assert coef * 2 == pytest.approx(min(1.0, 1.0 / (float(avg.norm()) + 1e-6)))
