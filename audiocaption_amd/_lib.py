@@ -56,7 +56,7 @@ SIGNATURES = {
     "ac_trm_beam_step": (_I, [_WP, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P]),
     "ac_trm_beam_reorder": (_I, [_WP, _I, _I, _I, _P, _P, _P]),
     # training step (csrc/train.hip)
-    "ac_gemm": (_I, [_P, _L, _L, _P, _L, _L, _P, _L, _I, _I, _I, _P, _I, _F, _I, _F, _U64, _P, _L, _P]),
+    "ac_gemm": (_I, [_P, _L, _L, _P, _L, _L, _P, _L, _I, _I, _I, _P, _I, _F, _I, _F, _U64, _P, _L, _P, _I, _P]),
     "ac_dropout": (_I, [_P, _P, _L, _F, _U64, _P, _L, _P]),
     "ac_mask_pos_scale": (_I, [_P, _P, _L, _F, _P]),
     "ac_build_prefix": (_I, [_P, _I, _P, _I, _P, _I, _I, _P, _L, _I, _I, _P]),
@@ -82,6 +82,11 @@ SIGNATURES = {
     "ac_clip_coef": (_I, [_P, _F, _F, _P]),
     "ac_scale_by_coef": (_I, [_P, _L, _P, _P]),
     "ac_adam_step": (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _I, _P]),
+    # EfficientNet-B2 encoder (csrc/effnet.hip)
+    "ac_top_db_clamp": (_I, [_P, _L, _F, _P, _I, _P]),
+    "ac_effnet_stem": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "ac_effnet_depthwise": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ac_effnet_se_gate": (_I, [_P, _F, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
 }
 
 _lib = None

@@ -18,6 +18,9 @@ ALIASES = {
     "captioning.models.crnn_trm_encoder.Cnn14RnnEncoder": "audiocaption_amd.crnn_trm_encoder.Cnn14RnnEncoder",
     "captioning.models.transformer_decoder.TransformerDecoder": "audiocaption_amd.transformer_decoder.TransformerDecoder",
     "captioning.models.transformer_model.TransformerModel": "audiocaption_amd.transformer_model.TransformerModel",
+    "captioning.models.cnn_encoder.EfficientNetB2": "audiocaption_amd.effnet_encoder.EfficientNetB2",
+    "captioning.losses.loss.LabelSmoothingLoss": "audiocaption_amd.loss.LabelSmoothingLoss",
+    "captioning.utils.lr_scheduler.ExponentialDecayScheduler": "audiocaption_amd.lr_scheduler.ExponentialDecayScheduler",
 }
 
 
@@ -85,6 +88,19 @@ def cnn14rnn_trm_config(vocab_size=4368, encoder_name="CrnnEncoder"):
         "decoder": {"type": "captioning.models.transformer_decoder.TransformerDecoder",
                     "args": {"vocab_size": vocab_size, "emb_dim": 256, "fc_emb_dim": 512, "attn_emb_dim": 512,
                              "nlayers": 2, "dropout": 0.2}},
+        "type": "captioning.models.transformer_model.TransformerModel",
+        "args": {},
+    }
+
+
+def effb2_trm_config(vocab_size=4981):
+    """The model ``Effb2TrmCaptioningModel`` builds from ``Effb2TrmConfig`` defaults (hf_wrapper.py:1115-1160):
+    EfficientNetB2 encoder (16 kHz), 2-layer decoder with the word embedding tied to the classifier."""
+    return {
+        "encoder": {"type": "captioning.models.cnn_encoder.EfficientNetB2", "args": {}},
+        "decoder": {"type": "captioning.models.transformer_decoder.TransformerDecoder",
+                    "args": {"vocab_size": vocab_size, "emb_dim": 256, "fc_emb_dim": 1408, "attn_emb_dim": 1408,
+                             "nlayers": 2, "dropout": 0.2, "tie_weights": True}},
         "type": "captioning.models.transformer_model.TransformerModel",
         "args": {},
     }

@@ -1,0 +1,203 @@
+// EfficientNet-B2 audio encoder pieces on gfx950: everything of an MBConv block that
+// is not a 1x1 convolution (those are ac_gemm with BatchNorm folded into the weights and the swish / squeeze-excite
+// gate / residual in its prologue and epilogue).
+//
+// The arithmetic being replaced is efficientnet_pytorch==0.7.1's EfficientNet.extract_features (un-vendored; call
+// sites hf_wrapper.py:229-241, cnn_encoder.py:798-805), whose construction the reference restates in
+// eff_latent_encoder.py:74-186.  Activations are channels-last [clip][time][mel][channel] fp32 (time is the
+// reference's W axis, mel its H axis): every kernel here is HBM-bound, so threads walk channels fastest (float4) and
+// each activation is read once; the squeeze-excite mean is accumulated by the depthwise kernel that produces the
+// tensor (LDS atomics per workgroup, one global atomic per channel per workgroup).
+#include "ac_common.h"
+
+namespace {
+
+__device__ __forceinline__ float swishf(float v) { return v / (1.0f + expf(-v)); }
+
+// ---- AmplitudeToDB(top_db): clamp at (max over the whole batch) - top_db (torchaudio packs the batch axis) ----------
+__global__ __launch_bounds__(256) void block_max_kernel(const float* x, long n, float* partial) {
+  __shared__ float red[4];
+  float m = -INFINITY;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) m = fmaxf(m, x[i]);
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__global__ __launch_bounds__(256) void clamp_top_db_kernel(float* x, long n, const float* partial, int nparts, float top_db) {
+  __shared__ float red[4];
+  float m = -INFINITY;
+  for (int i = threadIdx.x; i < nparts; i += 256) m = fmaxf(m, partial[i]);
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  const float lo = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) - top_db;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) x[i] = fmaxf(x[i], lo);
+}
+
+// ---- stem: 3x3 stride-2 convolution of the 1-channel log-mel + BN + swish ------------------------------------------
+// x [B][T][F], w [C][3 (mel)][3 (time)], y [B][To][Fo][C]; static "same" padding (pb before, pa after) on both axes.
+__global__ void stem_kernel(const float* x, const float* w, const float* scale, const float* shift, float* y, int B,
+                            int T, int F, int To, int Fo, int C, int pb) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  const long n = (long)B * To * Fo * C;
+  if (i >= n) return;
+  const int c = (int)(i % C);
+  long r = i / C;
+  const int fo = (int)(r % Fo);
+  r /= Fo;
+  const int to = (int)(r % To);
+  const int b = (int)(r / To);
+  const float* xb = x + (long)b * T * F;
+  float acc = 0.f;
+#pragma unroll
+  for (int kf = 0; kf < 3; ++kf) {
+    const int f = fo * 2 - pb + kf;
+    if (f < 0 || f >= F) continue;
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) {
+      const int t = to * 2 - pb + kt;
+      if (t < 0 || t >= T) continue;
+      acc = fmaf(xb[(long)t * F + f], w[c * 9 + kf * 3 + kt], acc);
+    }
+  }
+  y[i] = swishf(acc * scale[c] + shift[c]);
+}
+
+// ---- depthwise k x k convolution (stride s) + BN + swish, and the squeeze-excite channel sums ---------------------
+// x [B][T][F][C] -> y [B][To][Fo][C]; w [k (time)][k (mel)][C]; pool [B][C] += sum over positions of y.
+struct DwP {
+  const float* x; const float* w; const float* scale; const float* shift;
+  float* y; float* pool;
+  int T, F, To, Fo, C, k, s, pb, pos_per_block;
+};
+
+template <int K>
+__global__ __launch_bounds__(256) void depthwise_kernel(DwP p) {
+  extern __shared__ float spool[];   // [C]
+  const int b = blockIdx.y;
+  const int C4 = p.C >> 2;
+  for (int c = threadIdx.x; c < p.C; c += 256) spool[c] = 0.f;
+  __syncthreads();
+  const int npos = p.To * p.Fo;
+  const int pos0 = blockIdx.x * p.pos_per_block;
+  const int pos1 = min(npos, pos0 + p.pos_per_block);
+  const float* xb = p.x + (long)b * p.T * p.F * p.C;
+  float* yb = p.y + (long)b * npos * p.C;
+  const int items = (pos1 - pos0) * C4;
+  for (int it = threadIdx.x; it < items; it += 256) {
+    const int pos = pos0 + it / C4, c = (it % C4) * 4;
+    const int to = pos / p.Fo, fo = pos % p.Fo;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < K; ++kt) {
+      const int t = to * p.s - p.pb + kt;
+      if (t < 0 || t >= p.T) continue;
+#pragma unroll
+      for (int kf = 0; kf < K; ++kf) {
+        const int f = fo * p.s - p.pb + kf;
+        if (f < 0 || f >= p.F) continue;
+        const f32x4 xv = *(const f32x4*)(xb + ((long)t * p.F + f) * p.C + c);
+        const f32x4 wv = *(const f32x4*)(p.w + (long)(kt * K + kf) * p.C + c);
+        acc += xv * wv;
+      }
+    }
+    const f32x4 sc = *(const f32x4*)(p.scale + c), sh = *(const f32x4*)(p.shift + c);
+    f32x4 v = acc * sc + sh;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[j] = swishf(v[j]);
+      atomicAdd(&spool[c + j], v[j]);
+    }
+    *(f32x4*)(yb + (long)pos * p.C + c) = v;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < p.C; c += 256) atomicAdd(p.pool + (long)b * p.C + c, spool[c]);
+}
+
+// ---- squeeze-excite gate: g[b][c] = sigmoid(W2 swish(W1 mean[b] + b1) + b2) -----------------------------------------
+// pool [B][C] sums, w1 [S][C], w2 [C][S]; one workgroup per clip.
+__global__ __launch_bounds__(256) void se_gate_kernel(const float* pool, float inv_count, const float* w1, const float* b1,
+                                                      const float* w2, const float* b2, float* gate, int C, int S) {
+  extern __shared__ float sm[];   // mean [C] | squeezed [S]
+  float* mean = sm;
+  float* sq = sm + C;
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += 256) mean[c] = pool[(long)b * C + c] * inv_count;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int s = wave; s < S; s += 4) {
+    float a = 0.f;
+    for (int c = lane; c < C; c += 64) a = fmaf(w1[(long)s * C + c], mean[c], a);
+    a = wave_sum(a);
+    if (lane == 0) sq[s] = swishf(a + b1[s]);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = b2[c];
+    for (int s = 0; s < S; ++s) a = fmaf(w2[(long)c * S + s], sq[s], a);
+    gate[(long)b * C + c] = 1.0f / (1.0f + expf(-a));
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ac_top_db_clamp(float* x, long n, float top_db, float* scratch, int scratch_floats, void* stream) {
+  if (!x || !scratch || n <= 0 || scratch_floats < 1) return AC_ERR_ARG;
+  int nparts = (int)((n + 255) / 256);
+  if (nparts > scratch_floats) nparts = scratch_floats;
+  if (nparts > 1024) nparts = 1024;
+  hipLaunchKernelGGL(block_max_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, x, n, scratch);
+  long g = (n + 255) / 256;
+  if (g > 65535) g = 65535;
+  hipLaunchKernelGGL(clamp_top_db_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, n, scratch, nparts, top_db);
+  return ac_check_launch();
+}
+
+int ac_effnet_stem(const float* x, const float* w, const float* scale, const float* shift, float* y, int B, int T, int F,
+                   int C, int pad_before, int pad_after, void* stream) {
+  if (!x || !w || !scale || !shift || !y || B <= 0 || T <= 0 || F <= 0 || C <= 0) return AC_ERR_ARG;
+  const int To = (T + pad_before + pad_after - 3) / 2 + 1, Fo = (F + pad_before + pad_after - 3) / 2 + 1;
+  if (To <= 0 || Fo <= 0) return AC_ERR_ARG;
+  const long n = (long)B * To * Fo * C;
+  hipLaunchKernelGGL(stem_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, w, scale, shift,
+                     y, B, T, F, To, Fo, C, pad_before);
+  return ac_check_launch();
+}
+
+int ac_effnet_depthwise(const float* x, const float* w, const float* scale, const float* shift, float* y, float* pool,
+                        int B, int T, int F, int C, int k, int stride, int pad_before, int pad_after, void* stream) {
+  if (!x || !w || !scale || !shift || !y || !pool || B <= 0 || T <= 0 || F <= 0 || C <= 0 || (C & 3) ||
+      (k != 3 && k != 5) || (stride != 1 && stride != 2) || C > 8192)
+    return AC_ERR_ARG;
+  DwP p;
+  p.x = x; p.w = w; p.scale = scale; p.shift = shift; p.y = y; p.pool = pool;
+  p.T = T; p.F = F; p.C = C; p.k = k; p.s = stride; p.pb = pad_before;
+  p.To = (T + pad_before + pad_after - k) / stride + 1;
+  p.Fo = (F + pad_before + pad_after - k) / stride + 1;
+  if (p.To <= 0 || p.Fo <= 0) return AC_ERR_ARG;
+  // ~8 float4 items per thread per block
+  int ppb = (256 * 8) / (C / 4);
+  if (ppb < 1) ppb = 1;
+  p.pos_per_block = ppb;
+  const int npos = p.To * p.Fo;
+  dim3 grid((npos + ppb - 1) / ppb, B);
+  const size_t lds = (size_t)C * sizeof(float);
+  if (k == 3)
+    hipLaunchKernelGGL(depthwise_kernel<3>, grid, dim3(256), lds, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(depthwise_kernel<5>, grid, dim3(256), lds, (hipStream_t)stream, p);
+  return ac_check_launch();
+}
+
+int ac_effnet_se_gate(const float* pool, float inv_count, const float* w1, const float* b1, const float* w2,
+                      const float* b2, float* gate, int B, int C, int S, void* stream) {
+  if (!pool || !w1 || !b1 || !w2 || !b2 || !gate || B <= 0 || C <= 0 || S <= 0 || C + S > 12000) return AC_ERR_ARG;
+  hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(256), (size_t)(C + S) * sizeof(float), (hipStream_t)stream, pool,
+                     inv_count, w1, b1, w2, b2, gate, C, S);
+  return ac_check_launch();
+}
+
+}  // extern "C"

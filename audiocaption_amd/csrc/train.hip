@@ -57,7 +57,8 @@ struct GemmP {
   float* C; long ldc;
   int M, N, K;
   const float* bias;
-  int relu;
+  int relu;       // activation: 0 none, 1 ReLU, 2 swish (x * sigmoid(x))
+  const float* a_scale; int a_rows;   // optional per-(row group, k) multiplier on A: A(m,k) *= a_scale[(m / a_rows) * K + k]
   float beta;
   int splitk;     // > 1: K is cut into gridDim.z slices, results atomically added to C (beta must be 1)
   Drop drop;      // dropout on the output, element index = (row0 + m) * N + n
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256) void gemm_general_kernel(GemmP p) {
   __shared__ float As[2][GK][GLD];
   __shared__ float Bs[2][GK][GLD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+  const int m0 = blockIdx.x * GT, n0 = blockIdx.y * GT;   // M tiles on x: row counts reach millions (grid y <= 65535)
   const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
   int kbeg = 0, kend = p.K;
   if (p.splitk > 1) {
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void gemm_general_kernel(GemmP p) {
   }
   // element -> (row, k) assignment follows whichever stride is 1 so that global loads coalesce
   const bool a_kfast = (p.sak == 1), b_nfast = (p.sbn == 1);
-  int am[4], ak[4], bn[4], bk[4];
+  int am[4], ak[4], bn[4], bk[4], agrp[4];
   const float* ap[4];
   const float* bp[4];
   bool aok[4], bok[4];
@@ -91,6 +92,7 @@ __global__ __launch_bounds__(256) void gemm_general_kernel(GemmP p) {
   for (int i = 0; i < 4; ++i) {
     const int e = tid + i * 256;
     am[i] = a_kfast ? (e >> 4) : (e & 63);
+    agrp[i] = p.a_scale ? min(m0 + am[i], p.M - 1) / p.a_rows : 0;
     ak[i] = a_kfast ? (e & 15) : (e >> 6);
     bn[i] = b_nfast ? (e & 63) : (e >> 4);
     bk[i] = b_nfast ? (e >> 6) : (e & 15);
@@ -108,8 +110,9 @@ __global__ __launch_bounds__(256) void gemm_general_kernel(GemmP p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int ka = k0 + ak[i], kb = k0 + bk[i];
-      const float va = ap[i][(long)min(ka, kend - 1) * p.sak];
+      float va = ap[i][(long)min(ka, kend - 1) * p.sak];
       const float vb = bp[i][(long)min(kb, kend - 1) * p.sbk];
+      if (p.a_scale) va *= p.a_scale[(long)agrp[i] * p.K + min(ka, kend - 1)];
       a[i] = (aok[i] && ka < kend) ? va : 0.f;
       b[i] = (bok[i] && kb < kend) ? vb : 0.f;
     }
@@ -154,7 +157,8 @@ __global__ __launch_bounds__(256) void gemm_general_kernel(GemmP p) {
       atomicAdd(c, acc[r]);
     } else {
       float v = acc[r] + bias;
-      if (p.relu) v = fmaxf(v, 0.f);
+      if (p.relu == 1) v = fmaxf(v, 0.f);
+      else if (p.relu == 2) v = v / (1.0f + expf(-v));
       v *= p.drop.mask((uint64_t)(p.row0 + m) * (uint64_t)p.N + (uint64_t)n);
       if (p.beta != 0.f) v += p.beta * *c;
       *c = v;
@@ -172,7 +176,7 @@ constexpr int GS = 4, KT = 32;
 __global__ __launch_bounds__(256) void gemm_kk_kernel(GemmP p) {
   __shared__ float red[GS - 1][KT][KT + 1];
   const int lane = threadIdx.x & 63, kq = threadIdx.x >> 6;
-  const int m0 = blockIdx.y * KT, n0 = blockIdx.x * KT;
+  const int m0 = blockIdx.x * KT, n0 = blockIdx.y * KT;
   const int kper = p.K / GS;                 // multiple of 8
   const int kb = kq * kper;
   const float* a = p.A + (long)min(m0 + (lane & 31), p.M - 1) * p.sam + kb + 4 * (lane >> 5);
@@ -224,7 +228,8 @@ __global__ __launch_bounds__(256) void gemm_kk_kernel(GemmP p) {
     const int m = m0 + row;
     if (m >= p.M) continue;
     float v = ((acc[r] + red[0][row][col]) + (red[1][row][col] + red[2][row][col])) + bias;
-    if (p.relu) v = fmaxf(v, 0.f);
+    if (p.relu == 1) v = fmaxf(v, 0.f);
+    else if (p.relu == 2) v = v / (1.0f + expf(-v));
     v *= p.drop.mask((uint64_t)(p.row0 + m) * (uint64_t)p.N + (uint64_t)n);
     float* c = p.C + (long)m * p.ldc + n;
     if (p.beta != 0.f) v += p.beta * *c;
@@ -852,20 +857,22 @@ extern "C" {
 
 int ac_gemm(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc, int M, int N,
             int K, const float* bias, int relu, float beta, int splitk, float drop_p, unsigned long long drop_seed,
-            const unsigned long long* seed_dev, long row0, void* stream) {
-  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return AC_ERR_ARG;
+            const unsigned long long* seed_dev, long row0, const float* a_scale, int a_rows, void* stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || relu < 0 || relu > 2 || (a_scale && a_rows <= 0)) return AC_ERR_ARG;
   if (splitk > 1 && (bias || relu || drop_p > 0.f || beta != 1.0f)) return AC_ERR_ARG;
   GemmP p;
   p.A = A; p.sam = sam; p.sak = sak; p.B = B; p.sbk = sbk; p.sbn = sbn; p.C = C; p.ldc = ldc;
   p.M = M; p.N = N; p.K = K; p.bias = bias; p.relu = relu; p.beta = beta;
+  p.a_scale = a_scale; p.a_rows = a_rows;
   p.splitk = splitk < 1 ? 1 : splitk;
   p.drop = make_drop(drop_p, drop_seed, seed_dev);
   p.row0 = row0;
-  dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT, p.splitk);
+  dim3 grid((M + GT - 1) / GT, (N + GT - 1) / GT, p.splitk);
+  if (grid.y > 65535) return AC_ERR_ARG;
   const bool small = p.splitk == 1 && grid.x * grid.y <= 256 && K >= 128;
-  if (small && sak == 1 && sbk == 1 && K % 32 == 0 && sam % 4 == 0 && sbn % 4 == 0 &&
+  if (small && !a_scale && sak == 1 && sbk == 1 && K % 32 == 0 && sam % 4 == 0 && sbn % 4 == 0 &&
       ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0)
-    hipLaunchKernelGGL(gemm_kk_kernel, dim3((N + KT - 1) / KT, (M + KT - 1) / KT), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(gemm_kk_kernel, dim3((M + KT - 1) / KT, (N + KT - 1) / KT), dim3(256), 0, (hipStream_t)stream, p);
   else
     hipLaunchKernelGGL(gemm_general_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
   return ac_check_launch();

@@ -1,0 +1,259 @@
+"""EfficientNet-B2 audio encoder, MI355X path.  Plugin-compatible with the reference class ``EfficientNetB2``
+(``captioning.models.cnn_encoder.EfficientNetB2`` cnn_encoder.py:770-839 == hf_wrapper.py:262-315): same constructor
+keywords, ``forward(input_dict) -> {"fc_emb", "attn_emb", "attn_emb_len"}``, ``fc_emb_size`` 1408, and the
+``state_dict()`` keys of ``backbone.eff_net.*`` exactly as ``efficientnet_pytorch`` names them
+(eff_latent_encoder.py:263-290), so the published checkpoint loads.
+
+The nn modules below only OWN the parameters.  The forward pass is csrc/logmel.hip (HTK mel, top_db clamp),
+csrc/effnet.hip (stem, depthwise + squeeze sums, squeeze-excite gate) and ``ac_gemm`` for the 1x1 convolutions
+(BatchNorm folded into the weight rows; swish, the squeeze-excite gate and the residual in the GEMM's prologue /
+epilogue), channels-last ``[clip][time][mel][C]``.  PARITY UNPINNED: the backbone's arithmetic lives in the un-vendored
+``efficientnet_pytorch==0.7.1``; ``oracle/effb2_path.py`` restates its published algorithm and is what the tests
+compare against.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from . import kernels as K
+from ._lib import check, ptr, stream
+from .cnn_encoder import cnn14_feat_len
+from .mel import MelTables
+
+# (repeats, kernel, stride, expand, in, out) of EfficientNet-B0; B2: width x1.1, depth x1.2, resolution 260
+_B0 = [(1, 3, 1, 1, 32, 16), (2, 3, 2, 6, 16, 24), (2, 5, 2, 6, 24, 40), (3, 3, 2, 6, 40, 80), (3, 5, 1, 6, 80, 112),
+       (4, 5, 2, 6, 112, 192), (1, 3, 1, 6, 192, 320)]
+BN_EPS, BN_MOM = 1e-3, 0.01
+
+
+def round_filters(filters, width=1.1, divisor=8):
+    filters *= width
+    new = max(divisor, int(filters + divisor / 2) // divisor * divisor)
+    if new < 0.9 * filters:
+        new += divisor
+    return int(new)
+
+
+def same_pad(image, k, s):
+    """Static "same" padding of efficientnet_pytorch's Conv2dStaticSamePadding for a construction-time size."""
+    out = math.ceil(image / s)
+    pad = max((out - 1) * s + (k - 1) + 1 - image, 0)
+    return pad // 2, pad - pad // 2
+
+
+class _Conv(nn.Module):
+    """Weight (and optional bias) holder with Conv2d's parameter names."""
+
+    def __init__(self, cin, cout, k, groups=1, bias=False):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin // groups, k, k))
+        nn.init.kaiming_normal_(self.weight, mode="fan_out")
+        self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
+
+
+class MBConvBlock(nn.Module):
+
+    def __init__(self, cin, cout, expand, k, stride, image):
+        super().__init__()
+        mid = cin * expand
+        self.cin, self.cout, self.mid, self.expand, self.k, self.stride = cin, cout, mid, expand, k, stride
+        self.pad = same_pad(image, k, stride)
+        self.skip = stride == 1 and cin == cout
+        if expand != 1:
+            self._expand_conv = _Conv(cin, mid, 1)
+            self._bn0 = nn.BatchNorm2d(mid, momentum=BN_MOM, eps=BN_EPS)
+        self._depthwise_conv = _Conv(mid, mid, k, groups=mid)
+        self._bn1 = nn.BatchNorm2d(mid, momentum=BN_MOM, eps=BN_EPS)
+        se = max(1, int(cin * 0.25))
+        self._se_reduce = _Conv(mid, se, 1, bias=True)
+        self._se_expand = _Conv(se, mid, 1, bias=True)
+        self._project_conv = _Conv(mid, cout, 1)
+        self._bn2 = nn.BatchNorm2d(cout, momentum=BN_MOM, eps=BN_EPS)
+
+
+class EfficientNet(nn.Module):
+    """Parameter layout of ``efficientnet_pytorch.EfficientNet`` (B2, 1 input channel, include_top False)."""
+
+    def __init__(self):
+        super().__init__()
+        image = 260
+        self._conv_stem = _Conv(1, round_filters(32), 3)
+        self.stem_pad = same_pad(image, 3, 2)
+        self._bn0 = nn.BatchNorm2d(round_filters(32), momentum=BN_MOM, eps=BN_EPS)
+        image = math.ceil(image / 2)
+        blocks = []
+        for (r, k, s, e, i, o) in _B0:
+            cin, cout = round_filters(i), round_filters(o)
+            for j in range(int(math.ceil(1.2 * r))):
+                stride = s if j == 0 else 1
+                blocks.append(MBConvBlock(cin if j == 0 else cout, cout, e, k, stride, image))
+                image = math.ceil(image / stride)
+        self._blocks = nn.ModuleList(blocks)
+        self._conv_head = _Conv(blocks[-1].cout, round_filters(1280), 1)
+        self._bn1 = nn.BatchNorm2d(round_filters(1280), momentum=BN_MOM, eps=BN_EPS)
+
+
+class _EffiNet(nn.Module):
+
+    def __init__(self):
+        super().__init__()
+        self.eff_net = EfficientNet()
+
+
+def _fold(bn):
+    scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+    return scale, bn.bias.detach().float() - bn.running_mean.detach().float() * scale
+
+
+class EfficientNetB2(nn.Module):
+
+    def __init__(self, n_mels=64, win_length=32, hop_length=10, f_min=0, freeze=False):
+        super().__init__()
+        if n_mels != 64 or win_length != 32 or hop_length != 10:
+            raise NotImplementedError("EfficientNetB2 (HIP path): n_mels 64, 32 ms windows, 10 ms hop only "
+                                      "(the configuration every reference config uses)")
+        self.sample_rate = 16000
+        self.n_fft = win_length * self.sample_rate // 1000
+        self.hop_length = 10 * self.sample_rate // 1000
+        self.f_min = float(f_min)
+        self.top_db = 120.0
+        self.backbone = _EffiNet()
+        self.fc_emb_size = self.backbone.eff_net._conv_head.weight.shape[0]
+        self.downsample_ratio = 32
+        if freeze:
+            for p in self.parameters():
+                p.requires_grad = False
+        self._packed, self._packed_key, self._tables, self._bufs = None, None, None, {}
+
+    # ---- weight packing (cached) ---------------------------------------------------------------------------
+    def _pack(self):
+        net = self.backbone.eff_net
+        key = tuple((t.data_ptr(), t._version) for t in list(net.parameters()) + list(net.buffers())) + \
+            (_lib.param_generation(),)
+        if self._packed is not None and key == self._packed_key:
+            return self._packed
+
+        def pointwise(conv, bn):
+            sc, sh = _fold(bn)
+            w = conv.weight.detach().float().reshape(conv.weight.shape[0], -1) * sc[:, None]   # BN folded into rows
+            return w.contiguous(), sh.contiguous()
+
+        with torch.no_grad():
+            sc, sh = _fold(net._bn0)
+            pk = {"stem": (net._conv_stem.weight.detach().float().reshape(-1, 9).contiguous(), sc.contiguous(),
+                           sh.contiguous()), "blocks": []}
+            for blk in net._blocks:
+                d = {}
+                if blk.expand != 1:
+                    d["expand"] = pointwise(blk._expand_conv, blk._bn0)
+                sc, sh = _fold(blk._bn1)
+                # [C][1][k mel][k time] -> [k time][k mel][C]
+                d["dw"] = (blk._depthwise_conv.weight.detach().float()[:, 0].permute(2, 1, 0).contiguous(),
+                           sc.contiguous(), sh.contiguous())
+                d["se"] = (blk._se_reduce.weight.detach().float().reshape(blk._se_reduce.weight.shape[0], -1).contiguous(),
+                           blk._se_reduce.bias.detach().float().contiguous(),
+                           blk._se_expand.weight.detach().float().reshape(blk.mid, -1).contiguous(),
+                           blk._se_expand.bias.detach().float().contiguous())
+                d["project"] = pointwise(blk._project_conv, blk._bn2)
+                pk["blocks"].append(d)
+            pk["head"] = pointwise(net._conv_head, net._bn1)
+        self._packed, self._packed_key = pk, key
+        return pk
+
+    def _buf(self, name, numel, device):
+        b = self._bufs.get(name)
+        if b is None or b.numel() < numel or b.device != device:
+            b = torch.empty(numel, device=device, dtype=torch.float32)
+            self._bufs[name] = b
+        return b
+
+    @staticmethod
+    def _gemm(x, w, bias, y, M, N, Kd, act=0, beta=0.0, a_scale=None, a_rows=0):
+        lib = _lib.load()
+        check(lib.ac_gemm(ptr(x), Kd, 1, ptr(w), 1, Kd, ptr(y), N, M, N, Kd, ptr(bias), act, beta, 1, 0.0, 0, None, 0,
+                          ptr(a_scale), a_rows, stream()), "ac_gemm")
+
+    def logmel(self, wav):
+        """wav (B, L) -> log-mel dB [B][T][64] (time-major), clamped at (batch max - 120 dB) like AmplitudeToDB."""
+        dev = wav.device
+        if self._tables is None or self._tables.window.device != dev:
+            self._tables = MelTables(self.sample_rate, self.n_fft, self.hop_length, self.f_min, self.sample_rate // 2, 64,
+                                     None, "htk", dev)
+        x = K.logmel(wav, self._tables, channels_last=True)      # (B*T, 64)
+        scratch = self._buf("maxscratch", 1024, dev)
+        check(_lib.load().ac_top_db_clamp(ptr(x), x.numel(), self.top_db, ptr(scratch), 1024, stream()),
+              "ac_top_db_clamp")
+        return x
+
+    def features(self, x, B, T, F=64):
+        """x: log-mel [B][T][F] -> attn_emb (B, T', 1408)."""
+        lib = _lib.load()
+        dev = x.device
+        pk = self._pack()
+        net = self.backbone.eff_net
+        s = stream()
+        w, sc, sh = pk["stem"]
+        pb, pa = net.stem_pad
+        To, Fo = (T + pb + pa - 3) // 2 + 1, (F + pb + pa - 3) // 2 + 1
+        C = w.shape[0]
+        # three rotating activation buffers sized for the largest tensor of the chain (block 2's expanded input)
+        big = B * To * Fo * max(blk.mid for blk in net._blocks[:3])
+        cur = self._buf("act_a", big, dev)
+        check(lib.ac_effnet_stem(ptr(x), ptr(w), ptr(sc), ptr(sh), ptr(cur), B, T, F, C, pb, pa, s), "ac_effnet_stem")
+        T, F = To, Fo
+        mid_buf, dw_buf = self._buf("act_b", big, dev), self._buf("act_c", big, dev)
+        nxt = self._buf("act_d", big, dev)
+        pool = self._buf("se_pool", B * 2112, dev)
+        gate = self._buf("se_gate", B * 2112, dev)
+        for blk, d in zip(net._blocks, pk["blocks"]):
+            rows = B * T * F
+            xin = cur
+            if blk.expand != 1:
+                w, b = d["expand"]
+                self._gemm(xin, w, b, mid_buf, rows, blk.mid, blk.cin, act=2)
+                xmid = mid_buf
+            else:
+                xmid = xin
+            wd, sc, sh = d["dw"]
+            pb, pa = blk.pad
+            To, Fo = (T + pb + pa - blk.k) // blk.stride + 1, (F + pb + pa - blk.k) // blk.stride + 1
+            pool[:B * blk.mid].zero_()
+            check(lib.ac_effnet_depthwise(ptr(xmid), ptr(wd), ptr(sc), ptr(sh), ptr(dw_buf), ptr(pool), B, T, F, blk.mid,
+                                          blk.k, blk.stride, pb, pa, s), "ac_effnet_depthwise")
+            w1, b1, w2, b2 = d["se"]
+            check(lib.ac_effnet_se_gate(ptr(pool), 1.0 / (To * Fo), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(gate), B,
+                                        blk.mid, w1.shape[0], s), "ac_effnet_se_gate")
+            w, b = d["project"]
+            rows_o = B * To * Fo
+            if blk.skip:
+                # x <- x + project(gate * dw): accumulate in place on the block input
+                self._gemm(dw_buf, w, b, xin, rows_o, blk.cout, blk.mid, beta=1.0, a_scale=gate, a_rows=To * Fo)
+            else:
+                self._gemm(dw_buf, w, b, nxt, rows_o, blk.cout, blk.mid, a_scale=gate, a_rows=To * Fo)
+                cur, nxt = nxt, cur
+            T, F = To, Fo
+        w, b = pk["head"]
+        rows = B * T * F
+        Ch = w.shape[0]
+        self._gemm(cur, w, b, mid_buf, rows, Ch, w.shape[1], act=2)
+        attn = torch.empty(B, T, Ch, device=dev, dtype=torch.float32)
+        K.rows_mean_w(mid_buf, attn, B, T, T, F, Ch)            # mean over mel: 'b c f t -> b t c'
+        return attn
+
+    def forward(self, input_dict):
+        if self.training:
+            raise NotImplementedError("EfficientNetB2 (HIP path): inference only; training this encoder "
+                                      "(BatchNorm statistics, drop-connect, backward) is not built")
+        wav = input_dict["wav"]
+        if not wav.is_cuda:
+            raise _lib.HipLibraryError("the HIP path needs tensors on a ROCm device; there is no CPU fallback")
+        wav = K.f32c(wav)
+        B, L = wav.shape
+        x = self.logmel(wav)
+        attn_emb = self.features(x, B, L // self.hop_length + 1)
+        feat_length = cnn14_feat_len(input_dict["wav_len"], self.hop_length, self.downsample_ratio)
+        lens = feat_length.to(device=wav.device, dtype=torch.int32)
+        fc_emb = K.mean_with_lens(attn_emb, lens)
+        return {"fc_emb": fc_emb, "attn_emb": attn_emb, "attn_emb_len": feat_length}

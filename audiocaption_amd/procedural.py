@@ -154,6 +154,71 @@ def cnn14rnn_trm_state(vocab_size=4368, seed=BASE_SEED):
     return out
 
 
+# (repeats, kernel, stride, expand, in, out) of EfficientNet-B0 (Tan & Le 2019, table 1); B2 scales width by 1.1 and
+# depth by 1.2.  The reference spells the same construction out in eff_latent_encoder.py:74-186.
+_EFFNET_B0 = [(1, 3, 1, 1, 32, 16), (2, 3, 2, 6, 16, 24), (2, 5, 2, 6, 24, 40), (3, 3, 2, 6, 40, 80),
+              (3, 5, 1, 6, 80, 112), (4, 5, 2, 6, 112, 192), (1, 3, 1, 6, 192, 320)]
+
+
+def effb2_round_filters(filters, width=1.1, divisor=8):
+    filters *= width
+    new = max(divisor, int(filters + divisor / 2) // divisor * divisor)
+    if new < 0.9 * filters:
+        new += divisor
+    return int(new)
+
+
+def effb2_blocks():
+    """[(cin, cout, expand, kernel, stride, se_channels)] for the 23 MBConv blocks of EfficientNet-B2."""
+    out = []
+    for (r, k, s, e, i, o) in _EFFNET_B0:
+        cin, cout = effb2_round_filters(i), effb2_round_filters(o)
+        for j in range(int(math.ceil(1.2 * r))):
+            bi = cin if j == 0 else cout
+            out.append((bi, cout, e, k, s if j == 0 else 1, max(1, int(bi * 0.25))))
+    return out
+
+
+def effb2_state(prefix="encoder.backbone.eff_net.", seed=BASE_SEED):
+    """EfficientNet-B2 tensors with 1 input channel and no classifier top (hf_wrapper.py:235-241), keys as
+    efficientnet_pytorch names them (eff_latent_encoder.py:263-290)."""
+    out = {}
+
+    def conv(key, shape, fan_in, gain=2.0):
+        out[key] = _normal(key, shape, math.sqrt(gain / fan_in), seed)
+
+    # the stem sees raw dB values (~ -60..0): a small stem keeps the activations O(1) like a trained one would
+    k = prefix + "_conv_stem.weight"
+    out[k] = _normal(k, (32, 1, 3, 3), math.sqrt(2.0 / 9) / 20.0, seed)
+    _bn(prefix + "_bn0", 32, out, seed)
+    for i, (cin, cout, e, ks, s, se) in enumerate(effb2_blocks()):
+        p = f"{prefix}_blocks.{i}."
+        mid = cin * e
+        if e != 1:
+            conv(p + "_expand_conv.weight", (mid, cin, 1, 1), cin)
+            _bn(p + "_bn0", mid, out, seed)
+        conv(p + "_depthwise_conv.weight", (mid, 1, ks, ks), ks * ks)
+        _bn(p + "_bn1", mid, out, seed)
+        conv(p + "_se_reduce.weight", (se, mid, 1, 1), mid, 1.0)
+        out[p + "_se_reduce.bias"] = _uniform(p + "_se_reduce.bias", (se,), -0.1, 0.1, seed)
+        conv(p + "_se_expand.weight", (mid, se, 1, 1), se, 1.0)
+        out[p + "_se_expand.bias"] = _uniform(p + "_se_expand.bias", (mid,), -0.1, 0.1, seed)
+        conv(p + "_project_conv.weight", (cout, mid, 1, 1), mid, 1.0)
+        _bn(p + "_bn2", cout, out, seed)
+    conv(prefix + "_conv_head.weight", (effb2_round_filters(1280), effb2_blocks()[-1][1], 1, 1), effb2_blocks()[-1][1])
+    _bn(prefix + "_bn1", effb2_round_filters(1280), out, seed)
+    return out
+
+
+def effb2_trm_state(vocab_size=4981, seed=BASE_SEED):
+    """State dict of the EffB2-Transformer captioner (``Effb2TrmConfig`` defaults, hf_wrapper.py:1115-1141: d_model
+    256, 2 layers, tied word embedding / classifier, attn_emb_dim 1408)."""
+    out = {}
+    out.update(effb2_state("encoder.backbone.eff_net.", seed))
+    out.update(decoder_state("decoder.", vocab_size, 256, 1408, 2, 1024, seed, tie_weights=True))
+    return out
+
+
 def synthetic_wav(batch, n_samples, seed=BASE_SEED, varied=False, sample_rate=32000):
     """wav = clip(0.1*N(0,1), -1, 1), fp32, shape (B, L).
 

@@ -167,7 +167,7 @@ class TrainEngine:
     def _gemm(self, s, A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, bias=None, relu=0, beta=0.0, splitk=1, drop_p=0.0,
               seed=0, row0=0):
         check(self.lib.ac_gemm(A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, bias, relu, beta, splitk, drop_p, seed,
-                               self._seed_ptr, row0, s), "ac_gemm")
+                               self._seed_ptr, row0, None, 0, s), "ac_gemm")
 
     def _lin(self, s, x, W, b, y, M, N, K, ldx=None, ldy=None, relu=0, drop_p=0.0, seed=0, row0=0):
         """y[M][N] = x[M][K] W[N][K]^T + b"""

@@ -180,11 +180,14 @@ int ac_trm_beam_reorder(const ac_trm_weights* w, int R, int max_len, int t, cons
 
 /* C[M][N] (row pitch ldc) = epi( sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] ): X W^T / dY W / dY^T X with one kernel
  * (replaces F.linear and its autograd, e.g. transformer_decoder.py:86-101, rnn_encoder.py:41).
- * epi: + bias[n], ReLU, dropout(drop_p, drop_seed, index (row0+m)*N+n), + beta*C.  splitk > 1: K is cut into splitk
- * slices whose partial sums are atomically ADDED to C (weight gradients; needs beta == 1, no bias/relu/dropout). */
+ * epi: + bias[n], activation (relu = 1: ReLU, 2: swish x*sigmoid(x)), dropout(drop_p, drop_seed, index (row0+m)*N+n),
+ * + beta*C.  splitk > 1: K is cut into splitk slices whose partial sums are atomically ADDED to C (weight gradients;
+ * needs beta == 1, no bias/activation/dropout).  a_scale (optional): A(m,k) is multiplied by
+ * a_scale[(m / a_rows)*K + k] on the way in - the squeeze-excite gate of an MBConv block applied inside its 1x1
+ * projection (efficientnet_pytorch MBConvBlock.forward; call site hf_wrapper.py:231). */
 int ac_gemm(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc, int M, int N,
             int K, const float* bias, int relu, float beta, int splitk, float drop_p, unsigned long long drop_seed,
-            const unsigned long long* seed_dev, long row0, void* stream);
+            const unsigned long long* seed_dev, long row0, const float* a_scale, int a_rows, void* stream);
 /* y[i] = x[i] * mask(seed, idx0 + i): F.dropout (cnn_encoder.py:432-442, nn.GRU inter-layer dropout); applying it to
  * a gradient with the same seed is its backward. */
 int ac_dropout(const float* x, float* y, long n, float p, unsigned long long seed, const unsigned long long* seed_dev,
@@ -269,6 +272,29 @@ int ac_clip_coef(float* norm_state, float max_norm, float grad_div, void* stream
 int ac_scale_by_coef(float* x, long n, const float* norm_state, void* stream);
 int ac_adam_step(float* p, const float* g, float* m, float* v, long n, const float* norm_state, float lr, float beta1,
                  float beta2, float eps, float weight_decay, int step, void* stream);
+
+/* ============================ EfficientNet-B2 encoder ============================
+ * Replaces efficientnet_pytorch==0.7.1 EfficientNet.extract_features as the reference calls it (hf_wrapper.py:229-241,
+ * cnn_encoder.py:798-839; construction restated in eff_latent_encoder.py:74-186).  PARITY UNPINNED: that package is
+ * not vendored, the kernels follow its published algorithm.  Activations are channels-last [clip][time][mel][C] fp32
+ * (time = the reference's W axis, mel = its H axis).  The 1x1 convolutions are ac_gemm (BatchNorm folded into the
+ * weight rows, swish in the epilogue, the squeeze-excite gate as a_scale, the residual as beta = 1).               */
+
+/* AmplitudeToDB(top_db) on a (batch, mel, time) tensor: x = max(x, max(x over the WHOLE buffer) - top_db)
+ * (hf_wrapper.py:279; torchaudio packs the batch axis as channels).  scratch: >= 1 float (<= 1024 used). */
+int ac_top_db_clamp(float* x, long n, float top_db, float* scratch, int scratch_floats, void* stream);
+/* Stem: 3x3 stride-2 conv of the 1-channel log-mel x [B][T][F] with w [C][3 mel][3 time], static "same" padding
+ * (pad_before / pad_after zeros on both axes), BN scale/shift, swish -> y [B][To][Fo][C]. */
+int ac_effnet_stem(const float* x, const float* w, const float* scale, const float* shift, float* y, int B, int T, int F,
+                   int C, int pad_before, int pad_after, void* stream);
+/* Depthwise k x k conv (k = 3 / 5, stride 1 / 2) + BN + swish: x [B][T][F][C], w [k time][k mel][C] ->
+ * y [B][To][Fo][C], To = (T + pad_before + pad_after - k) / stride + 1; pool [B][C] += sum of y over positions
+ * (the squeeze of the squeeze-excite layer; zero it first). */
+int ac_effnet_depthwise(const float* x, const float* w, const float* scale, const float* shift, float* y, float* pool,
+                        int B, int T, int F, int C, int k, int stride, int pad_before, int pad_after, void* stream);
+/* gate[b][c] = sigmoid(w2 swish(w1 (pool[b] * inv_count) + b1) + b2), w1 [S][C], w2 [C][S]. */
+int ac_effnet_se_gate(const float* pool, float inv_count, const float* w1, const float* b1, const float* w2,
+                      const float* b2, float* gate, int B, int C, int S, void* stream);
 
 #ifdef __cplusplus
 }

@@ -27,6 +27,13 @@ def state4981():
 
 
 @pytest.fixture(scope="session")
+def state_effb2():
+    """Procedural weights of the EffB2-Transformer captioner."""
+    from audiocaption_amd import procedural as P
+    return P.to_torch(P.effb2_trm_state(4981))
+
+
+@pytest.fixture(scope="session")
 def hip_model(state4981):
     """The product model on cuda:0 with procedural weights (GPU tests only)."""
     import torch

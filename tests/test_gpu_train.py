@@ -46,13 +46,13 @@ def test_general_gemm_all_layouts(lib):
     xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
     # y = relu(x w^T + b)
     y = torch.empty(M, N, device="cuda")
-    assert lib.ac_gemm(P(xd), K, 1, P(wd), 1, K, P(y), N, M, N, K, P(bd), 1, 0.0, 1, 0.0, 0, None, 0, S()) == 0
+    assert lib.ac_gemm(P(xd), K, 1, P(wd), 1, K, P(y), N, M, N, K, P(bd), 1, 0.0, 1, 0.0, 0, None, 0, None, 0, S()) == 0
     assert rel("x w^T + b, relu", y, torch.relu(x.double() @ w.double().t() + b.double())) < 1e-5
     # dx = dy w, accumulated on top of an existing tensor (beta = 1)
     dy = torch.randn(M, N, generator=g)
     dx0 = torch.randn(M, K, generator=g)
     dx = dx0.cuda()
-    assert lib.ac_gemm(P(dy.cuda()), N, 1, P(wd), K, 1, P(dx), K, M, K, N, None, 0, 1.0, 1, 0.0, 0, None, 0, S()) == 0
+    assert lib.ac_gemm(P(dy.cuda()), N, 1, P(wd), K, 1, P(dx), K, M, K, N, None, 0, 1.0, 1, 0.0, 0, None, 0, None, 0, S()) == 0
     assert rel("dy w + dx0", dx, dy.double() @ w.double() + dx0.double()) < 1e-5
     # dw += dy^T x, split-K with atomics, strided views (ld > width)
     dyp = torch.randn(M, N + 24, generator=g)
@@ -62,11 +62,11 @@ def test_general_gemm_all_layouts(lib):
         dw = dw0.cuda()
         dyd, xdp = dyp.cuda(), xp.cuda()
         assert lib.ac_gemm(P(dyd), 1, N + 24, P(xdp), K + 8, 1, P(dw), K, N, K, M, None, 0, 1.0, splitk, 0.0, 0, None, 0,
-                           S()) == 0
+                           None, 0, S()) == 0
         want = dyp[:, :N].double().t() @ xp[:, :K].double() + dw0.double()
         assert rel(f"dy^T x split-K {splitk}", dw, want) < 1e-5
     # rejected combinations
-    assert lib.ac_gemm(P(xd), K, 1, P(wd), 1, K, P(y), N, M, N, K, P(bd), 0, 1.0, 4, 0.0, 0, None, 0, S()) == -1
+    assert lib.ac_gemm(P(xd), K, 1, P(wd), 1, K, P(y), N, M, N, K, P(bd), 0, 1.0, 4, 0.0, 0, None, 0, None, 0, S()) == -1
 
 
 def test_dropout_hash_is_the_oracles(lib):

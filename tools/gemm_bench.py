@@ -11,11 +11,11 @@ def run(M, N, K, mode="fwd", splitk=1, reps=50):
     y = torch.zeros(M, N, device="cuda")
     def call():
         if mode == "fwd":
-            return lib.ac_gemm(P(x), K, 1, P(w), 1, K, P(y), N, M, N, K, P(b), 0, 0.0, 1, 0.0, 0, None, 0, S())
+            return lib.ac_gemm(P(x), K, 1, P(w), 1, K, P(y), N, M, N, K, P(b), 0, 0.0, 1, 0.0, 0, None, 0, None, 0, S())
         if mode == "dx":   # y[M][N] = dy[M][K] W[K][N]
-            return lib.ac_gemm(P(x), K, 1, P(w), N, 1, P(y), N, M, N, K, None, 0, 0.0, 1, 0.0, 0, None, 0, S())
+            return lib.ac_gemm(P(x), K, 1, P(w), N, 1, P(y), N, M, N, K, None, 0, 0.0, 1, 0.0, 0, None, 0, None, 0, S())
         if mode == "dw":   # y[M][N] += A^T B with rows = K
-            return lib.ac_gemm(P(x), 1, M, P(w), N, 1, P(y), N, M, N, K, None, 0, 1.0, splitk, 0.0, 0, None, 0, S())
+            return lib.ac_gemm(P(x), 1, M, P(w), N, 1, P(y), N, M, N, K, None, 0, 1.0, splitk, 0.0, 0, None, 0, None, 0, S())
     if mode == "dx":
         w = torch.randn(K, N, device="cuda")
     if mode == "dw":
