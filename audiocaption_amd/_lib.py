@@ -83,6 +83,7 @@ SIGNATURES = {
     "ac_scale_by_coef": (_I, [_P, _L, _P, _P]),
     "ac_adam_step": (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _I, _P]),
     # EfficientNet-B2 encoder (csrc/effnet.hip)
+    "ac_pointwise_conv": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _F, _P, _I, _P]),
     "ac_top_db_clamp": (_I, [_P, _L, _F, _P, _I, _P]),
     "ac_effnet_stem": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ac_effnet_depthwise": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

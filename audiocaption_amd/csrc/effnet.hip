@@ -140,9 +140,90 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* pool, float i
   }
 }
 
+// ---- 1x1 convolution = thin GEMM y[M][N] = act((x .* gate) W^T + b) (+ y), M = clips * positions in the millions,
+// K, N <= 2112.  HBM-bound: every wave owns 32 rows and reads its A fragments straight from global memory exactly
+// once per pass (lane l: 4 consecutive k of row l & 31 at k offset 4 * (l >> 5) of every 8-k group - one 16-byte load
+// feeds 4 MFMAs per output tile), the weights (<= 3 MB, L2-resident) the same way; up to 4 output tiles of 32 columns
+// are kept in accumulators per pass.  No LDS, no barriers; the squeeze-excite gate multiplies A on the way in.
+struct PwP {
+  const float* x; const float* w; const float* bias; float* y;
+  const float* gate; int gate_rows;
+  long M; int N, K, act;
+  float beta;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void pointwise_kernel(PwP p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long m0 = ((long)blockIdx.x * 4 + wave) * 32;
+  if (m0 >= p.M) return;
+  const long row = min(m0 + (lane & 31), p.M - 1);
+  const int koff = 4 * (lane >> 5);
+  const float* a = p.x + row * p.K + koff;
+  const float* g = p.gate ? p.gate + (row / p.gate_rows) * p.K + koff : nullptr;
+  const int ngroups = p.K >> 3;
+  for (int n0 = 0; n0 < p.N; n0 += 32 * NT) {
+    f32x16 acc[NT];
+    const float* b[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+      b[t] = p.w + (long)min(n0 + t * 32 + (lane & 31), p.N - 1) * p.K + koff;
+    }
+#pragma unroll 2
+    for (int gq = 0; gq < ngroups; ++gq) {
+      f32x4 va = *(const f32x4*)(a + 8 * gq);
+      if (g) va *= *(const f32x4*)(g + 8 * gq);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const f32x4 vb = *(const f32x4*)(b[t] + 8 * gq);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t] = mfma32(va[j], vb[j], acc[t]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int n = n0 + t * 32 + (lane & 31);
+      if (n >= p.N) continue;
+      const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long m = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m >= p.M) continue;
+        float v = acc[t][r] + bias;
+        if (p.act == 2) v = swishf(v);
+        else if (p.act == 1) v = fmaxf(v, 0.f);
+        float* c = p.y + m * p.N + n;
+        if (p.beta != 0.f) v += p.beta * *c;
+        *c = v;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int ac_pointwise_conv(const float* x, const float* w, const float* bias, float* y, long M, int N, int K, int act, float beta,
+                      const float* gate, int gate_rows, void* stream) {
+  if (!x || !w || !y || M <= 0 || N <= 0 || K <= 0 || (K & 7) || act < 0 || act > 2 || (gate && gate_rows <= 0) ||
+      ((uintptr_t)x & 15) || ((uintptr_t)w & 15))
+    return AC_ERR_ARG;
+  PwP p;
+  p.x = x; p.w = w; p.bias = bias; p.y = y; p.gate = gate; p.gate_rows = gate_rows;
+  p.M = M; p.N = N; p.K = K; p.act = act; p.beta = beta;
+  const long blocks = (M + 127) / 128;
+  if (blocks > 2147483647L) return AC_ERR_ARG;
+  dim3 grid((unsigned)blocks);
+  hipStream_t s = (hipStream_t)stream;
+  if (N <= 32) hipLaunchKernelGGL(pointwise_kernel<1>, grid, dim3(256), 0, s, p);
+  else if (N <= 64) hipLaunchKernelGGL(pointwise_kernel<2>, grid, dim3(256), 0, s, p);
+  else if (N <= 96) hipLaunchKernelGGL(pointwise_kernel<3>, grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(pointwise_kernel<4>, grid, dim3(256), 0, s, p);
+  return ac_check_launch();
+}
 
 int ac_top_db_clamp(float* x, long n, float top_db, float* scratch, int scratch_floats, void* stream) {
   if (!x || !scratch || n <= 0 || scratch_floats < 1) return AC_ERR_ARG;

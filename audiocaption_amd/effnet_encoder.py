@@ -5,7 +5,7 @@ keywords, ``forward(input_dict) -> {"fc_emb", "attn_emb", "attn_emb_len"}``, ``f
 (eff_latent_encoder.py:263-290), so the published checkpoint loads.
 
 The nn modules below only OWN the parameters.  The forward pass is csrc/logmel.hip (HTK mel, top_db clamp),
-csrc/effnet.hip (stem, depthwise + squeeze sums, squeeze-excite gate) and ``ac_gemm`` for the 1x1 convolutions
+csrc/effnet.hip (stem, depthwise + squeeze sums, squeeze-excite gate, ``ac_pointwise_conv`` for the 1x1 convolutions
 (BatchNorm folded into the weight rows; swish, the squeeze-excite gate and the residual in the GEMM's prologue /
 epilogue), channels-last ``[clip][time][mel][C]``.  PARITY UNPINNED: the backbone's arithmetic lives in the un-vendored
 ``efficientnet_pytorch==0.7.1``; ``oracle/effb2_path.py`` restates its published algorithm and is what the tests
@@ -172,8 +172,15 @@ class EfficientNetB2(nn.Module):
     @staticmethod
     def _gemm(x, w, bias, y, M, N, Kd, act=0, beta=0.0, a_scale=None, a_rows=0):
         lib = _lib.load()
-        check(lib.ac_gemm(ptr(x), Kd, 1, ptr(w), 1, Kd, ptr(y), N, M, N, Kd, ptr(bias), act, beta, 1, 0.0, 0, None, 0,
-                          ptr(a_scale), a_rows, stream()), "ac_gemm")
+        # two kernels for the same contract (tools/pointwise_bench.py): millions of rows against a small weight matrix
+        # are HBM-bound -> the streaming kernel that reads each activation once; the late stages (<= 32 k rows against
+        # up to 3 MB of weights) -> the LDS-tiled GEMM that shares the weight tile between 64 rows
+        if (N <= 128 and M >= 30000) or N * Kd <= 16384:
+            check(lib.ac_pointwise_conv(ptr(x), ptr(w), ptr(bias), ptr(y), M, N, Kd, act, beta, ptr(a_scale), a_rows,
+                                        stream()), "ac_pointwise_conv")
+        else:
+            check(lib.ac_gemm(ptr(x), Kd, 1, ptr(w), 1, Kd, ptr(y), N, M, N, Kd, ptr(bias), act, beta, 1, 0.0, 0, None, 0,
+                              ptr(a_scale), a_rows, stream()), "ac_gemm")
 
     def logmel(self, wav):
         """wav (B, L) -> log-mel dB [B][T][64] (time-major), clamped at (batch max - 120 dB) like AmplitudeToDB."""

@@ -197,8 +197,9 @@ class TransformerModel(CaptionModel):
         tokens[:, 0] = self.start_idx
         cum = np.zeros((B, beam), dtype=np.float32)
         done = [[] for _ in range(B)]
-        active = [True] * B
-        src_row = np.arange(R, dtype=np.int32)
+        active = np.ones(B, dtype=bool)
+        base = (np.arange(B, dtype=np.int64) * beam)[:, None]
+        identity = np.arange(R, dtype=np.int32)
         for t in range(max_length):
             tok_dev = torch.from_numpy(tokens).to(dev)
             mask_dev = torch.from_numpy((tokens == self.pad_idx).astype(np.uint8)).to(dev)
@@ -206,32 +207,26 @@ class TransformerModel(CaptionModel):
             top_val, top_idx = dec.beam_step(memkv, mem_len, B, beam, Tm, max_length, t, temp, tok_dev, mask_dev,
                                              cum_dev, ws)
             top_val = top_val.cpu().numpy()
-            top_idx = top_idx.cpu().numpy()
-            new_tokens = tokens.copy()
-            for i in range(B):
-                if not active[i]:
-                    src_row[i * beam:(i + 1) * beam] = np.arange(i * beam, (i + 1) * beam)
-                    continue
-                prev_beam = top_idx[i] // V
-                word = top_idx[i] % V
-                rows = i * beam + prev_beam
-                new_tokens[i * beam:(i + 1) * beam, :t + 1] = tokens[rows, :t + 1]
-                new_tokens[i * beam:(i + 1) * beam, t + 1] = word
-                src_row[i * beam:(i + 1) * beam] = rows
-                is_end = word == self.end_idx
-                if t == max_length - 1:
-                    is_end[:] = True
-                for k in range(beam):
-                    if is_end[k]:
-                        done[i].append({"seq": new_tokens[i * beam + k, 1:t + 2].copy(),
-                                        "score": float(top_val[i, k]) / (t + 1)})
-                cum[i] = top_val[i] - np.where(is_end, np.float32(1000.0), np.float32(0.0))
+            top_idx = top_idx.cpu().numpy().astype(np.int64)
+            # per-clip bookkeeping of base.py:290-323, vectorised over the clips (only beams that END are visited
+            # one by one, in beam order, to keep the reference's append order and its '==' stop rule)
+            act = active[:, None]
+            prev_beam, word = top_idx // V, top_idx % V
+            src_row = np.where(act, base + prev_beam, identity.reshape(B, beam)).astype(np.int32).reshape(-1)
+            new_tokens = tokens[src_row]
+            new_tokens[:, t + 1] = np.where(act, word, new_tokens[:, t + 1].reshape(B, beam)).reshape(-1)
+            is_end = (word == self.end_idx) | (t == max_length - 1)
+            is_end &= act
+            for i, k in zip(*np.nonzero(is_end)):
+                done[i].append({"seq": new_tokens[i * beam + k, 1:t + 2].copy(), "score": float(top_val[i, k]) / (t + 1)})
+            cum = np.where(act, top_val - np.where(is_end, np.float32(1000.0), np.float32(0.0)), cum).astype(np.float32)
+            for i in np.nonzero(is_end.any(axis=1))[0]:
                 if len(done[i]) == beam:  # '==' as in base.py:321
                     active[i] = False
             tokens = new_tokens
-            if not any(active):
+            if not active.any():
                 break
-            dec.beam_reorder(R, max_length, t, torch.from_numpy(src_row.copy()).to(dev), ws)
+            dec.beam_reorder(R, max_length, t, torch.from_numpy(src_row).to(dev), ws)
 
         if n_best:
             seq = torch.full((B, n_best_size, max_length), self.end_idx, dtype=torch.long)

@@ -280,6 +280,11 @@ int ac_adam_step(float* p, const float* g, float* m, float* v, long n, const flo
  * (time = the reference's W axis, mel = its H axis).  The 1x1 convolutions are ac_gemm (BatchNorm folded into the
  * weight rows, swish in the epilogue, the squeeze-excite gate as a_scale, the residual as beta = 1).               */
 
+/* 1x1 convolution over channels-last rows: y[M][N] = act((x[M][K] .* gate[m / gate_rows][K]) w[N][K]^T + bias) + beta*y
+ * (_expand_conv / _project_conv / _conv_head of efficientnet_pytorch with BatchNorm folded into w and bias; act 0 none,
+ * 1 ReLU, 2 swish; gate = the squeeze-excite gate or NULL; beta = 1 adds the block input in place).  K % 8 == 0. */
+int ac_pointwise_conv(const float* x, const float* w, const float* bias, float* y, long M, int N, int K, int act, float beta,
+                      const float* gate, int gate_rows, void* stream);
 /* AmplitudeToDB(top_db) on a (batch, mel, time) tensor: x = max(x, max(x over the WHOLE buffer) - top_db)
  * (hf_wrapper.py:279; torchaudio packs the batch axis as channels).  scratch: >= 1 float (<= 1024 used). */
 int ac_top_db_clamp(float* x, long n, float top_db, float* scratch, int scratch_floats, void* stream);

@@ -101,6 +101,17 @@ def test_se_gate_and_gated_projection(lib):
     assert lib.ac_gemm(P(x.cuda()), C, 1, P(w.cuda()), 1, C, P(y), Co, B * HW, Co, C, P(b.cuda()), 0, 1.0, 1, 0.0, 0, None,
                        0, P(gate), HW, S()) == 0
     assert rel("gated projection + residual", y, ref) < 1e-5
+    y = res.clone().cuda()
+    assert lib.ac_pointwise_conv(P(x.cuda()), P(w.cuda()), P(b.cuda()), P(y), B * HW, Co, C, 0, 1.0, P(gate), HW, S()) == 0
+    assert rel("pointwise kernel: gated projection + residual", y, ref) < 1e-5
+    for n_out in (16, 48, 88, 200):   # 1..4 accumulator tiles per pass, ragged last tile, several passes
+        wn, bn = torch.randn(n_out, 88, generator=g) * 0.1, torch.randn(n_out, generator=g)
+        r3 = F.linear(x[:, :88], wn, bn)
+        r3 = r3 * torch.sigmoid(r3)
+        y3 = torch.empty(B * HW, n_out, device="cuda")
+        assert lib.ac_pointwise_conv(P(x[:, :88].contiguous().cuda()), P(wn.cuda()), P(bn.cuda()), P(y3), B * HW, n_out, 88,
+                                     2, 0.0, None, 0, S()) == 0
+        assert rel(f"pointwise kernel N={n_out} swish", y3, r3) < 1e-5
     # swish epilogue, K not a multiple of 16
     ref2 = F.linear(x[:, :88], w[:, :88].contiguous(), b)
     ref2 = ref2 * torch.sigmoid(ref2)
