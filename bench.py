@@ -95,6 +95,58 @@ def bench_train(args, world, rank, dev, dist, steps, warmup):
     }
 
 
+def bench_effb2(args, world, rank, dev, dist, steps, warmup):
+    """EffB2-Transformer captioner (``Effb2TrmCaptioningModel`` shape, hf_wrapper.py:1115-1181): 16 kHz waveforms ->
+    log-mel (HTK, top_db 120) -> EfficientNet-B2 -> 2-layer Transformer decoder, beam search (the wrapper's default,
+    beam 3) with token ids back on the host; clips sharded over the ranks, no data-path collective."""
+    import audiocaption_amd as A
+    from audiocaption_amd import build, procedural as P
+    build.build()
+    vocab = 4981
+    model = A.init_model_from_config(A.effb2_trm_config(vocab), print_fn=lambda s: None)
+    model.load_state_dict(P.to_torch(P.effb2_trm_state(vocab)), strict=True)
+    model = model.eval().to(dev)
+    B, L = args.effb2_batch, int(args.seconds * 16000)
+    wav = torch.from_numpy(P.synthetic_wav(B, L, seed=P.BASE_SEED + 200 + rank, sample_rate=16000)).to(dev)
+    inp = {"mode": "inference", "wav": wav, "wav_len": [L] * B, "specaug": False, "max_length": args.max_length}
+    if args.beam > 0:
+        inp.update(sample_method="beam", beam_size=args.beam)
+    else:
+        inp.update(sample_method="greedy")
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        model(dict(inp))
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = model(dict(inp))
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    assert tuple(out["seq"].shape) == (B, args.max_length)
+    return {
+        "metric": "clips/sec encode+decode, EffB2-Transformer", "value": world * B * steps / elapsed, "unit": "clips/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"EffB2-Trm, batch {B} per GPU, {args.seconds:g} s @ 16 kHz synthetic clips, "
+                               + (f"beam search (beam {args.beam})" if args.beam > 0 else "greedy")
+                               + f", max_length {args.max_length}, vocab {vocab} (BASELINE configs[2]; configs[4] with "
+                                 "--seconds 30 --beam 4 --gpus 8)",
+                   "global_batch": world * B, "parity": "unpinned (efficientnet_pytorch / torchaudio are not vendored by "
+                   "the reference): checked against oracle/effb2_path.py",
+                   "sharding": f"clips sharded over {world} rank(s), no data-path collective"},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,9 +160,13 @@ def main():
     ap.add_argument("--sync-steps", action="store_true", help="blocking model(input_dict) per step (no overlap)")
     ap.add_argument("--cpu-clips", type=int, default=4, help="clips per CPU-baseline pass")
     ap.add_argument("--cpu-reps", type=int, default=3)
-    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+    ap.add_argument("--mode", choices=["infer", "train", "effb2"], default="infer",
                     help="train: the JSON line is the TRAINING step (BASELINE configs[3]: forward + backward + Adam, "
-                         "gradients all-reduced over RCCL when N > 1)")
+                         "gradients all-reduced over RCCL when N > 1); effb2: EffB2-Transformer inference "
+                         "(BASELINE configs[2] / configs[4] with --seconds 30 --beam 4)")
+    ap.add_argument("--effb2-batch", type=int, default=128, help="clips per GPU per step in the EffB2 measurement")
+    ap.add_argument("--beam", type=int, default=3, help="beam size of the EffB2 measurement (0: greedy)")
+    ap.add_argument("--no-effb2", action="store_true", help="skip the secondary EffB2-Trm measurement")
     ap.add_argument("--train-batch", type=int, default=32, help="clips per GPU per training step")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement")
     args = ap.parse_args()
@@ -133,8 +189,11 @@ def main():
     from audiocaption_amd import build, kernels as K, procedural as P
     build.build()
 
-    if args.mode == "train":
-        res = bench_train(args, world, rank, dev, dist, args.steps, max(args.warmup, 3))
+    if args.mode in ("train", "effb2"):
+        if args.mode == "train":
+            res = bench_train(args, world, rank, dev, dist, args.steps, max(args.warmup, 3))
+        else:
+            res = bench_effb2(args, world, rank, dev, dist, args.steps, max(args.warmup, 1))
         if rank == 0:
             print(json.dumps(res), flush=True)
         if dist is not None:
@@ -242,6 +301,10 @@ def main():
         del out
         tr = bench_train(args, world, rank, dev, dist, max(3, args.steps // 2), 3)
         extra["train_step"] = {k: tr[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config")}
+    if world == 1 and not args.no_effb2:
+        # secondary: EffB2-Transformer inference (BASELINE configs[2])
+        eb = bench_effb2(args, world, rank, dev, dist, max(3, args.steps // 2), 2)
+        extra["effb2_trm"] = {k: eb[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config")}
     result = None
     if rank == 0:
         clips = world * B * args.steps
@@ -284,6 +347,8 @@ def main():
             result["f32_path"] = extra["f32_path"]
         if "train_step" in extra:
             result["train_step"] = extra["train_step"]
+        if "effb2_trm" in extra:
+            result["effb2_trm"] = extra["effb2_trm"]
         if not args.no_cpu_baseline and world == 1:
             from oracle import cpu_path as O  # the CPU restatement, timed as a reported baseline only
             nc = args.cpu_clips
