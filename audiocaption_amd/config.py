@@ -19,6 +19,8 @@ ALIASES = {
     "captioning.models.transformer_decoder.TransformerDecoder": "audiocaption_amd.transformer_decoder.TransformerDecoder",
     "captioning.models.transformer_model.TransformerModel": "audiocaption_amd.transformer_model.TransformerModel",
     "captioning.models.cnn_encoder.EfficientNetB2": "audiocaption_amd.effnet_encoder.EfficientNetB2",
+    "captioning.models.transformer_encoder.TransformerEncoder": "audiocaption_amd.transformer_encoder.TransformerEncoder",
+    "captioning.models.crnn_trm_encoder.Cnn14TransformerEncoder": "audiocaption_amd.crnn_trm_encoder.Cnn14TransformerEncoder",
     "captioning.losses.loss.LabelSmoothingLoss": "audiocaption_amd.loss.LabelSmoothingLoss",
     "captioning.utils.lr_scheduler.ExponentialDecayScheduler": "audiocaption_amd.lr_scheduler.ExponentialDecayScheduler",
 }

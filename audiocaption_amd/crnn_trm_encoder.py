@@ -38,3 +38,32 @@ class CrnnEncoder(nn.Module):
 
 
 Cnn14RnnEncoder = CrnnEncoder
+
+
+class Cnn14TransformerEncoder(nn.Module):
+    """CNN -> Transformer composite encoder (reference crnn_trm_encoder.py:214-246)."""
+
+    def __init__(self, cnn, transformer, freeze_cnn=False, freeze_cnn_bn=False, **kwargs):
+        super().__init__()
+        self.cnn = cnn
+        self.trm = transformer
+        self.freeze_cnn_bn = False
+        if freeze_cnn:
+            for param in self.cnn.parameters():
+                param.requires_grad = False
+            self.freeze_cnn_bn = freeze_cnn_bn
+
+    def train(self, mode=True):
+        super().train(mode=mode)
+        if self.freeze_cnn_bn:
+            for module in self.cnn.modules():
+                if module.__class__.__name__.find("BatchNorm") != -1:
+                    module.eval()
+        return self
+
+    def forward(self, input_dict):
+        try:
+            out = self.cnn(input_dict, skip_fc=True)
+        except TypeError:
+            out = self.cnn(input_dict)
+        return self.trm({"attn": out["attn_emb"], "attn_len": out["attn_emb_len"]})

@@ -219,6 +219,32 @@ def effb2_trm_state(vocab_size=4981, seed=BASE_SEED):
     return out
 
 
+def trm_encoder_state(prefix="", attn_feat_dim=2048, d_model=256, nlayers=2, dim_ff=1024, seed=BASE_SEED):
+    """TransformerEncoder tensors (reference transformer_encoder.py:66-86)."""
+    out = {}
+    d = d_model
+    k = prefix + "attn_proj.0.weight"
+    out[k] = _normal(k, (d, attn_feat_dim), math.sqrt(2.0 / attn_feat_dim), seed)
+    out[prefix + "attn_proj.0.bias"] = _uniform(prefix + "attn_proj.0.bias", (d,), -0.05, 0.05, seed)
+    out[prefix + "attn_proj.3.weight"] = _uniform(prefix + "attn_proj.3.weight", (d,), 0.9, 1.1, seed)
+    out[prefix + "attn_proj.3.bias"] = _uniform(prefix + "attn_proj.3.bias", (d,), -0.1, 0.1, seed)
+    out[prefix + "cls_token"] = _normal(prefix + "cls_token", (d,), 1.0, seed)
+    for l in range(nlayers):
+        lp = f"{prefix}model.layers.{l}."
+        out[lp + "self_attn.in_proj_weight"] = _normal(lp + "self_attn.in_proj_weight", (3 * d, d), 1.0 / math.sqrt(d), seed)
+        out[lp + "self_attn.in_proj_bias"] = _uniform(lp + "self_attn.in_proj_bias", (3 * d,), -0.05, 0.05, seed)
+        out[lp + "self_attn.out_proj.weight"] = _normal(lp + "self_attn.out_proj.weight", (d, d), 1.0 / math.sqrt(d), seed)
+        out[lp + "self_attn.out_proj.bias"] = _uniform(lp + "self_attn.out_proj.bias", (d,), -0.05, 0.05, seed)
+        out[lp + "linear1.weight"] = _normal(lp + "linear1.weight", (dim_ff, d), math.sqrt(2.0 / d), seed)
+        out[lp + "linear1.bias"] = _uniform(lp + "linear1.bias", (dim_ff,), -0.05, 0.05, seed)
+        out[lp + "linear2.weight"] = _normal(lp + "linear2.weight", (d, dim_ff), 1.0 / math.sqrt(dim_ff), seed)
+        out[lp + "linear2.bias"] = _uniform(lp + "linear2.bias", (d,), -0.05, 0.05, seed)
+        for n in ("norm1", "norm2"):
+            out[lp + n + ".weight"] = _uniform(lp + n + ".weight", (d,), 0.9, 1.1, seed)
+            out[lp + n + ".bias"] = _uniform(lp + n + ".bias", (d,), -0.1, 0.1, seed)
+    return out
+
+
 def synthetic_wav(batch, n_samples, seed=BASE_SEED, varied=False, sample_rate=32000):
     """wav = clip(0.1*N(0,1), -1, 1), fp32, shape (B, L).
 

@@ -226,6 +226,28 @@ def decoder_forward(state, word, attn_emb, attn_emb_len, cap_padding_mask=None, 
 
 
 # ----------------------------------------------------------------------------------------
+# TransformerEncoder (transformer_encoder.py:93-116): attn_proj, cls token, post-LN nn.TransformerEncoderLayer x2
+# ----------------------------------------------------------------------------------------
+def transformer_encoder_forward(state, attn, attn_len, prefix="", nlayers=2, nhead=4):
+    """attn (N, T, A), attn_len (N,) -> attn_emb (N, T+1, d), fc_emb = attn_emb[:, 0], attn_emb_len = attn_len + 1."""
+    x = decoder_memory(state, attn, prefix)   # the same Linear -> ReLU -> (Dropout) -> LayerNorm stack
+    N, T, d = x.shape
+    x = torch.cat([state[prefix + "cls_token"].reshape(1, 1, d).repeat(N, 1, 1), x], dim=1)
+    lens = torch.as_tensor(attn_len).clone() + 1
+    pad = ~(torch.arange(T + 1)[None, :] < lens[:, None])
+    mask = torch.zeros(N, 1, 1, T + 1).masked_fill(pad[:, None, None, :], float("-inf"))
+    for l in range(nlayers):
+        lp = f"{prefix}model.layers.{l}."
+        sa = _mha(x, x, x, state[lp + "self_attn.in_proj_weight"], state[lp + "self_attn.in_proj_bias"],
+                  state[lp + "self_attn.out_proj.weight"], state[lp + "self_attn.out_proj.bias"], nhead, mask)
+        x = F.layer_norm(x + sa, (d,), state[lp + "norm1.weight"], state[lp + "norm1.bias"])
+        ff = F.linear(F.relu(F.linear(x, state[lp + "linear1.weight"], state[lp + "linear1.bias"])),
+                      state[lp + "linear2.weight"], state[lp + "linear2.bias"])
+        x = F.layer_norm(x + ff, (d,), state[lp + "norm2.weight"], state[lp + "norm2.bias"])
+    return {"attn_emb": x, "fc_emb": x[:, 0], "attn_emb_len": lens}
+
+
+# ----------------------------------------------------------------------------------------
 # greedy decoding (base.py:152-218, transformer_model.py:34-57)
 # ----------------------------------------------------------------------------------------
 def greedy_decode(state, attn_emb, attn_emb_len, max_length=20, prefix="decoder.",

@@ -203,6 +203,27 @@ def main():
     print(f"  G7 label-smoothing loss = {float(loss):.6f}")
 
 
+    # ---- G9: TransformerEncoder (transformer_encoder.py:64-116), the alternative temporal encoder -----------
+    from captioning.models.transformer_encoder import TransformerEncoder
+    trm_np = P.trm_encoder_state()
+    trm_state = P.to_torch(trm_np)
+    trm = TransformerEncoder(spec_dim=-1, fc_feat_dim=2048, attn_feat_dim=2048, d_model=256)
+    assert set(trm.state_dict()) == set(trm_state)
+    trm.load_state_dict(trm_state, strict=True)
+    trm.eval()
+    g9 = {}
+    for tag, lens in (("full", [31, 31]), ("ragged", [31, 20])):
+        lens_t = torch.tensor(lens)
+        ref_t = trm({"attn": attn, "attn_len": lens_t})
+        assert lens_t.tolist() == [v + 1 for v in lens]      # the reference increments the caller's tensor in place
+        o_t = O.transformer_encoder_forward(trm_state, attn, lens)
+        cmp(f"G9 {tag} attn_emb", o_t["attn_emb"], ref_t["attn_emb"])
+        assert torch.equal(o_t["attn_emb_len"], ref_t["attn_emb_len"])
+        g9[f"{tag}_lens"] = np.array(lens)
+        g9[f"{tag}_attn_emb"] = ref_t["attn_emb"].numpy()
+        g9[f"{tag}_attn_emb_len"] = ref_t["attn_emb_len"].numpy()
+    np.savez_compressed(os.path.join(out_dir, "g9_trm_encoder.npz"), **g9)
+
     # ---- G8: one TRAINING step (A13-A16), dropout p = 0 so that it is deterministic --------------------
     # scheduled-sampling forward (base.py:131-199, transformer_model.py:34-57), LabelSmoothingLoss, backward,
     # clip_grad_norm_(1.0) and one torch.optim.Adam(lr 5e-4, weight_decay 1e-6) update, all by the reference.

@@ -193,3 +193,34 @@ def test_forward_async_equals_blocking_forward(hip_model):
         assert torch.equal(w["seq"], g["seq"])
         assert torch.equal(w["logit"], g["logit"]) and torch.equal(w["attn_emb"], g["attn_emb"])
         assert torch.equal(w["sampled_logprob"], g["sampled_logprob"])
+
+
+def test_g9_transformer_encoder_vs_reference_golden(golden_dir):
+    """TransformerEncoder (row A7) on the HIP path against the reference's outputs; the length tensor is incremented
+    in place like the reference does (transformer_encoder.py:105)."""
+    import audiocaption_amd as A
+    from audiocaption_amd import procedural as P
+    from audiocaption_amd.transformer_encoder import TransformerEncoder
+    g1 = _load(golden_dir, "g1_cnn14.npz")
+    g9 = _load(golden_dir, "g9_trm_encoder.npz")
+    enc = TransformerEncoder(spec_dim=-1, fc_feat_dim=2048, attn_feat_dim=2048, d_model=256)
+    enc.load_state_dict(P.to_torch(P.trm_encoder_state()), strict=True)
+    enc = enc.eval().cuda()
+    attn = torch.from_numpy(g1["attn_emb"]).cuda()
+    for tag in ("full", "ragged"):
+        lens = torch.from_numpy(g9[f"{tag}_lens"]).clone()
+        out = enc({"attn": attn, "attn_len": lens})
+        assert lens.tolist() == g9[f"{tag}_attn_emb_len"].tolist()
+        assert out["attn_emb_len"].tolist() == g9[f"{tag}_attn_emb_len"].tolist()
+        assert _maxdiff(f"trm encoder {tag}", out["attn_emb"], g9[f"{tag}_attn_emb"]) < 5e-5
+        assert torch.equal(out["fc_emb"], out["attn_emb"][:, 0])
+    # the composite the reference builds from YAML (crnn_trm_encoder.py:214-246)
+    cfg = {"type": "captioning.models.crnn_trm_encoder.Cnn14TransformerEncoder", "args": {"freeze_cnn": True},
+           "cnn": {"type": "captioning.models.cnn_encoder.Cnn14Encoder", "args": {"sample_rate": 32000}},
+           "transformer": {"type": "captioning.models.transformer_encoder.TransformerEncoder",
+                           "args": {"spec_dim": -1, "fc_feat_dim": 2048, "attn_feat_dim": 2048, "d_model": 256}}}
+    from audiocaption_amd.config import init_obj_from_dict
+    comp = init_obj_from_dict(cfg).eval().cuda()
+    wav = torch.from_numpy(P.synthetic_wav(2, 64000)).cuda()
+    o = comp({"wav": wav, "wav_len": [64000, 40000], "specaug": False})
+    assert o["attn_emb"].shape == (2, 7, 256) and o["attn_emb_len"].tolist() == [7, 4]

@@ -87,3 +87,23 @@ def test_g7_label_smoothing_known_answer(golden_dir, state4981):
     mask = torch.arange(11)[None] < tgt_len[:, None]
     loss = (-(q * lp).sum(-1) * mask).sum() / mask.sum()
     assert abs(float(loss) - float(g["loss"])) < 1e-4
+
+
+def test_g9_transformer_encoder_oracle_vs_reference(golden_dir):
+    """TransformerEncoder: oracle against the reference's outputs, full and ragged lengths."""
+    import os
+    import numpy as np
+    import torch
+    from audiocaption_amd import procedural as P
+    from oracle import cpu_path as O
+    g1 = dict(np.load(os.path.join(golden_dir, "g1_cnn14.npz")))
+    g9 = dict(np.load(os.path.join(golden_dir, "g9_trm_encoder.npz")))
+    st = P.to_torch(P.trm_encoder_state())
+    attn = torch.from_numpy(g1["attn_emb"])
+    for tag in ("full", "ragged"):
+        lens = g9[f"{tag}_lens"].tolist()
+        out = O.transformer_encoder_forward(st, attn, lens)
+        assert out["attn_emb"].shape == (2, 32, 256)
+        assert float((out["attn_emb"] - torch.from_numpy(g9[f"{tag}_attn_emb"])).abs().max()) < 2e-5
+        assert out["attn_emb_len"].tolist() == g9[f"{tag}_attn_emb_len"].tolist() == [v + 1 for v in lens]
+        assert torch.equal(out["fc_emb"], out["attn_emb"][:, 0])
