@@ -133,7 +133,20 @@ def bench_effb2(args, world, rank, dev, dist, steps, warmup):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     assert tuple(out["seq"].shape) == (B, args.max_length)
+    # encoder alone (HBM-bound: SURVEY section 8(d)(iv) prices it at ~100 MB of activation traffic per 10 s clip)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        model.encoder(inp)
+    e1.record()
+    torch.cuda.synchronize()
+    enc_ms = e0.elapsed_time(e1) / 3
+    alg_bytes = 100e6 * (args.seconds / 10.0) * B
     return {
+        "encoder_roofline": {"bound": "hbm", "achieved": alg_bytes / (enc_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                             "frac": alg_bytes / (enc_ms * 1e-3) / 8e12, "traffic": None, "encoder_ms": enc_ms,
+                             "note": "algorithmic activation bytes (100 MB per 10 s clip, SURVEY 8(d)) / measured time of "
+                                     "log-mel + EfficientNet-B2 for the whole batch"},
         "metric": "clips/sec encode+decode, EffB2-Transformer", "value": world * B * steps / elapsed, "unit": "clips/s",
         "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -159,7 +172,7 @@ def main():
     ap.add_argument("--no-f32-path", action="store_true", help="skip the secondary exact-f32 measurement")
     ap.add_argument("--sync-steps", action="store_true", help="blocking model(input_dict) per step (no overlap)")
     ap.add_argument("--cpu-clips", type=int, default=4, help="clips per CPU-baseline pass")
-    ap.add_argument("--cpu-reps", type=int, default=3)
+    ap.add_argument("--cpu-reps", type=int, default=5)
     ap.add_argument("--mode", choices=["infer", "train", "effb2"], default="infer",
                     help="train: the JSON line is the TRAINING step (BASELINE configs[3]: forward + backward + Adam, "
                          "gradients all-reduced over RCCL when N > 1); effb2: EffB2-Transformer inference "
@@ -296,6 +309,25 @@ def main():
                              "ms_per_step": fdt / max(2, args.steps // 2) * 1e3,
                              "value": world * B * max(2, args.steps // 2) / fdt, "unit": "clips/s"}
         cnn.conv_algo, cnn._packed = algo, None
+    # the log-mel kernel on its own: HBM-bound (1.54 MB per 10 s clip: waveform in, log-mel out)
+    m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    cnn = model.encoder.cnn
+    pk = cnn._pack(dev)
+    hp0 = cnn.geometry(L)[2][0]
+    K.logmel(wav, cnn._tables, pk["bn0"][0], pk["bn0"][1], rows_per_clip=hp0, channels_last=True)
+    m0.record()
+    for _ in range(10):
+        K.logmel(wav, cnn._tables, pk["bn0"][0], pk["bn0"][1], rows_per_clip=hp0, channels_last=True)
+    m1.record()
+    torch.cuda.synchronize()
+    mel_ms = m0.elapsed_time(m1) / 10
+    mel_bytes = 1.54e6 * (args.seconds / 10.0) * B
+    extra["mel_roofline"] = {"bound": "hbm", "achieved": mel_bytes / (mel_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                             "frac": mel_bytes / (mel_ms * 1e-3) / 8e12, "traffic": None, "kernel": "logmel_kernel<1024>",
+                             "avg_launch_ms": mel_ms,
+                             "note": "wave-per-frame 1024-point FFT + mel + dB + bn0 in one pass; 1.54 MB algorithmic bytes "
+                                     "per 10 s clip but 0.09 GFLOP of FFT per clip, so the kernel is FFT-issue bound, not "
+                                     "HBM bound"}
     if world == 1 and not args.no_train:
         # secondary: the training step (BASELINE configs[3]) on this GPU
         del out
@@ -304,7 +336,8 @@ def main():
     if world == 1 and not args.no_effb2:
         # secondary: EffB2-Transformer inference (BASELINE configs[2])
         eb = bench_effb2(args, world, rank, dev, dist, max(3, args.steps // 2), 2)
-        extra["effb2_trm"] = {k: eb[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config")}
+        extra["effb2_trm"] = {k: eb[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config",
+                                                  "encoder_roofline")}
     result = None
     if rank == 0:
         clips = world * B * args.steps
@@ -345,6 +378,7 @@ def main():
             "reference on the golden fixtures" if algo.startswith("bf16x3") else "f32 end to end")
         if "f32_path" in extra:
             result["f32_path"] = extra["f32_path"]
+        result["rooflines_other"] = {"logmel": extra["mel_roofline"]}
         if "train_step" in extra:
             result["train_step"] = extra["train_step"]
         if "effb2_trm" in extra:
@@ -354,17 +388,26 @@ def main():
             nc = args.cpu_clips
             cwav = torch.from_numpy(P.synthetic_wav(B, L)[:nc])
             O.caption_forward(state, cwav[:1], [L], "greedy", max_length=args.max_length, force_steps=True)
-            times = []
-            for _ in range(args.cpu_reps):
+            t_enc, t_dec = [], []
+            for _ in range(args.cpu_reps):   # encode and decode timed separately
                 c0 = time.perf_counter()
-                O.caption_forward(state, cwav, [L] * nc, "greedy", max_length=args.max_length, force_steps=True)
-                times.append(time.perf_counter() - c0)
-            times.sort()
+                enc = O.cnn14_forward(state, cwav, [L] * nc)
+                enc = O.gru_forward(state, enc["attn_emb"], enc["attn_emb_len"])
+                c1 = time.perf_counter()
+                O.greedy_decode(state, enc["attn_emb"], enc["attn_emb_len"], args.max_length, force_steps=True)
+                c2 = time.perf_counter()
+                t_enc.append(c1 - c0)
+                t_dec.append(c2 - c1)
+            t_enc.sort()
+            t_dec.sort()
+            me, md = t_enc[len(t_enc) // 2], t_dec[len(t_dec) // 2]
             result["cpu_baseline"] = {
-                "value": nc / times[len(times) // 2], "unit": "clips/s", "cores": torch.get_num_threads(),
-                "kind": "port",
-                "sample": f"oracle/cpu_path.py caption_forward (fp32 torch CPU ops), {nc} clips x {args.seconds:g} s, "
-                          f"greedy {args.max_length} steps, median of {args.cpu_reps} passes after 1 warm-up"}
+                "value": nc / (me + md), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+                "encode_clips_per_s": nc / me, "decode_clips_per_s": nc / md,
+                "host_cpu_count": os.cpu_count(), "torch": torch.__version__,
+                "sample": f"oracle/cpu_path.py (fp32 torch CPU ops): log-mel + Cnn14 + bi-GRU, then greedy decoding that "
+                          f"re-runs the decoder on the whole prefix for {args.max_length} steps like the reference; {nc} "
+                          f"clips x {args.seconds:g} s, medians of {args.cpu_reps} passes after 1 warm-up"}
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
