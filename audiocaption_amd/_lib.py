@@ -86,7 +86,7 @@ SIGNATURES = {
     "ac_pointwise_conv": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _F, _P, _I, _P]),
     "ac_top_db_clamp": (_I, [_P, _L, _F, _P, _I, _P]),
     "ac_effnet_stem": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "ac_effnet_depthwise": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ac_effnet_depthwise": (_I, [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ac_effnet_se_gate": (_I, [_P, _F, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
 }
 

@@ -37,31 +37,47 @@ __global__ __launch_bounds__(256) void clamp_top_db_kernel(float* x, long n, con
 
 // ---- stem: 3x3 stride-2 convolution of the 1-channel log-mel + BN + swish ------------------------------------------
 // x [B][T][F], w [C][3 (mel)][3 (time)], y [B][To][Fo][C]; static "same" padding (pb before, pa after) on both axes.
-__global__ void stem_kernel(const float* x, const float* w, const float* scale, const float* shift, float* y, int B,
-                            int T, int F, int To, int Fo, int C, int pb) {
-  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-  const long n = (long)B * To * Fo * C;
-  if (i >= n) return;
-  const int c = (int)(i % C);
-  long r = i / C;
-  const int fo = (int)(r % Fo);
-  r /= Fo;
+// One thread per output position: the 9 input taps are loaded once and reused for all C (= 32) channels, the weights
+// sit in LDS (broadcast reads), the C outputs leave as float4 stores.
+__global__ __launch_bounds__(256) void stem_kernel(const float* x, const float* w, const float* scale, const float* shift,
+                                                   float* y, int B, int T, int F, int To, int Fo, int C, int pb) {
+  extern __shared__ float sw[];   // w [C][9] | scale [C] | shift [C]
+  for (int i = threadIdx.x; i < C * 9; i += 256) sw[i] = w[i];
+  for (int i = threadIdx.x; i < C; i += 256) {
+    sw[C * 9 + i] = scale[i];
+    sw[C * 10 + i] = shift[i];
+  }
+  __syncthreads();
+  const long pos = blockIdx.x * 256L + threadIdx.x;
+  const long npos = (long)B * To * Fo;
+  if (pos >= npos) return;
+  const int fo = (int)(pos % Fo);
+  const long r = pos / Fo;
   const int to = (int)(r % To);
   const int b = (int)(r / To);
   const float* xb = x + (long)b * T * F;
-  float acc = 0.f;
+  float tap[9];
 #pragma unroll
   for (int kf = 0; kf < 3; ++kf) {
     const int f = fo * 2 - pb + kf;
-    if (f < 0 || f >= F) continue;
 #pragma unroll
     for (int kt = 0; kt < 3; ++kt) {
       const int t = to * 2 - pb + kt;
-      if (t < 0 || t >= T) continue;
-      acc = fmaf(xb[(long)t * F + f], w[c * 9 + kf * 3 + kt], acc);
+      tap[kf * 3 + kt] = (f >= 0 && f < F && t >= 0 && t < T) ? xb[(long)t * F + f] : 0.f;
     }
   }
-  y[i] = swishf(acc * scale[c] + shift[c]);
+  float* yo = y + pos * C;
+  for (int c = 0; c < C; c += 4) {
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float acc = 0.f;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) acc = fmaf(tap[q], sw[(c + j) * 9 + q], acc);
+      v[j] = swishf(acc * sw[C * 9 + c + j] + sw[C * 10 + c + j]);
+    }
+    *(f32x4*)(yo + c) = v;
+  }
 }
 
 // ---- depthwise k x k convolution (stride s) + BN + swish, and the squeeze-excite channel sums ---------------------
@@ -70,49 +86,84 @@ struct DwP {
   const float* x; const float* w; const float* scale; const float* shift;
   float* y; float* pool;
   int T, F, To, Fo, C, k, s, pb, pos_per_block;
+  float pool_scale;
 };
 
-template <int K>
+// A thread owns one channel group (4 channels) and walks output rows `to`; inside a row it slides a K x K window of
+// float4 along the mel axis, so every input element is loaded K / S times instead of K*K / S^2 and the K*K weights
+// stay in registers.  The squeeze sums accumulate in registers and reach LDS once per thread.
+template <int K, int S>
 __global__ __launch_bounds__(256) void depthwise_kernel(DwP p) {
   extern __shared__ float spool[];   // [C]
   const int b = blockIdx.y;
   const int C4 = p.C >> 2;
+  const int lanes = C4 < 256 ? (256 / C4) * C4 : 256;   // threads in use
+  const int rstep = C4 < 256 ? 256 / C4 : 1;             // output rows handled per sweep
   for (int c = threadIdx.x; c < p.C; c += 256) spool[c] = 0.f;
   __syncthreads();
-  const int npos = p.To * p.Fo;
-  const int pos0 = blockIdx.x * p.pos_per_block;
-  const int pos1 = min(npos, pos0 + p.pos_per_block);
+  const int row0 = blockIdx.x * p.pos_per_block;         // pos_per_block = output rows (time) per workgroup here
+  const int row1 = min(p.To, row0 + p.pos_per_block);
   const float* xb = p.x + (long)b * p.T * p.F * p.C;
-  float* yb = p.y + (long)b * npos * p.C;
-  const int items = (pos1 - pos0) * C4;
-  for (int it = threadIdx.x; it < items; it += 256) {
-    const int pos = pos0 + it / C4, c = (it % C4) * 4;
-    const int to = pos / p.Fo, fo = pos % p.Fo;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float* yb = p.y + (long)b * p.To * p.Fo * p.C;
+  if ((int)threadIdx.x < lanes) {
+    const int cg0 = C4 < 256 ? threadIdx.x % C4 : threadIdx.x;
+    const int rofs = C4 < 256 ? threadIdx.x / C4 : 0;
+    for (int cg = cg0; cg < C4; cg += 256) {
+      const int c = cg * 4;
+      const f32x4 sc = *(const f32x4*)(p.scale + c), sh = *(const f32x4*)(p.shift + c);
+      f32x4 w[K][K];
 #pragma unroll
-    for (int kt = 0; kt < K; ++kt) {
-      const int t = to * p.s - p.pb + kt;
-      if (t < 0 || t >= p.T) continue;
+      for (int kt = 0; kt < K; ++kt)
 #pragma unroll
-      for (int kf = 0; kf < K; ++kf) {
-        const int f = fo * p.s - p.pb + kf;
-        if (f < 0 || f >= p.F) continue;
-        const f32x4 xv = *(const f32x4*)(xb + ((long)t * p.F + f) * p.C + c);
-        const f32x4 wv = *(const f32x4*)(p.w + (long)(kt * K + kf) * p.C + c);
-        acc += xv * wv;
+        for (int kf = 0; kf < K; ++kf) w[kt][kf] = *(const f32x4*)(p.w + (long)(kt * K + kf) * p.C + c);
+      f32x4 psum = {0.f, 0.f, 0.f, 0.f};
+      for (int to = row0 + rofs; to < row1; to += rstep) {
+        const float* rowp[K];
+        bool rok[K];
+#pragma unroll
+        for (int kt = 0; kt < K; ++kt) {
+          const int t = to * S - p.pb + kt;
+          rok[kt] = t >= 0 && t < p.T;
+          rowp[kt] = xb + (long)(rok[kt] ? t : 0) * p.F * p.C + c;
+        }
+        f32x4 win[K][K];
+        auto col = [&](int f, int slot) {
+          const bool fok = f >= 0 && f < p.F;
+#pragma unroll
+          for (int kt = 0; kt < K; ++kt) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (fok && rok[kt]) v = *(const f32x4*)(rowp[kt] + (long)f * p.C);
+            win[kt][slot] = v;
+          }
+        };
+#pragma unroll
+        for (int kf = 0; kf < K; ++kf) col(-p.pb + kf, kf);
+        for (int fo = 0; fo < p.Fo; ++fo) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kt = 0; kt < K; ++kt)
+#pragma unroll
+            for (int kf = 0; kf < K; ++kf) acc += win[kt][kf] * w[kt][kf];
+          f32x4 v = acc * sc + sh;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = swishf(v[j]);
+          psum += v;
+          *(f32x4*)(yb + ((long)to * p.Fo + fo) * p.C + c) = v;
+          // slide the window by S columns
+#pragma unroll
+          for (int kf = 0; kf + S < K; ++kf)
+#pragma unroll
+            for (int kt = 0; kt < K; ++kt) win[kt][kf] = win[kt][kf + S];
+#pragma unroll
+          for (int q = 0; q < S; ++q) col((fo + 1) * S - p.pb + K - S + q, K - S + q);
+        }
       }
-    }
-    const f32x4 sc = *(const f32x4*)(p.scale + c), sh = *(const f32x4*)(p.shift + c);
-    f32x4 v = acc * sc + sh;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      v[j] = swishf(v[j]);
-      atomicAdd(&spool[c + j], v[j]);
+      for (int j = 0; j < 4; ++j) atomicAdd(&spool[c + j], psum[j]);
     }
-    *(f32x4*)(yb + (long)pos * p.C + c) = v;
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < p.C; c += 256) atomicAdd(p.pool + (long)b * p.C + c, spool[c]);
+  for (int c = threadIdx.x; c < p.C; c += 256) atomicAdd(p.pool + (long)b * p.C + c, spool[c] * p.pool_scale);
 }
 
 // ---- squeeze-excite gate: g[b][c] = sigmoid(W2 swish(W1 mean[b] + b1) + b2) -----------------------------------------
@@ -242,34 +293,38 @@ int ac_effnet_stem(const float* x, const float* w, const float* scale, const flo
   if (!x || !w || !scale || !shift || !y || B <= 0 || T <= 0 || F <= 0 || C <= 0) return AC_ERR_ARG;
   const int To = (T + pad_before + pad_after - 3) / 2 + 1, Fo = (F + pad_before + pad_after - 3) / 2 + 1;
   if (To <= 0 || Fo <= 0) return AC_ERR_ARG;
-  const long n = (long)B * To * Fo * C;
-  hipLaunchKernelGGL(stem_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, w, scale, shift,
-                     y, B, T, F, To, Fo, C, pad_before);
+  if (C & 3) return AC_ERR_ARG;
+  const long n = (long)B * To * Fo;
+  hipLaunchKernelGGL(stem_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)C * 11 * sizeof(float),
+                     (hipStream_t)stream, x, w, scale, shift, y, B, T, F, To, Fo, C, pad_before);
   return ac_check_launch();
 }
 
 int ac_effnet_depthwise(const float* x, const float* w, const float* scale, const float* shift, float* y, float* pool,
-                        int B, int T, int F, int C, int k, int stride, int pad_before, int pad_after, void* stream) {
+                        float pool_scale, int B, int T, int F, int C, int k, int stride, int pad_before, int pad_after,
+                        void* stream) {
   if (!x || !w || !scale || !shift || !y || !pool || B <= 0 || T <= 0 || F <= 0 || C <= 0 || (C & 3) ||
       (k != 3 && k != 5) || (stride != 1 && stride != 2) || C > 8192)
     return AC_ERR_ARG;
   DwP p;
   p.x = x; p.w = w; p.scale = scale; p.shift = shift; p.y = y; p.pool = pool;
-  p.T = T; p.F = F; p.C = C; p.k = k; p.s = stride; p.pb = pad_before;
+  p.T = T; p.F = F; p.C = C; p.k = k; p.s = stride; p.pb = pad_before; p.pool_scale = pool_scale;
   p.To = (T + pad_before + pad_after - k) / stride + 1;
   p.Fo = (F + pad_before + pad_after - k) / stride + 1;
   if (p.To <= 0 || p.Fo <= 0) return AC_ERR_ARG;
-  // ~8 float4 items per thread per block
-  int ppb = (256 * 8) / (C / 4);
-  if (ppb < 1) ppb = 1;
-  p.pos_per_block = ppb;
-  const int npos = p.To * p.Fo;
-  dim3 grid((npos + ppb - 1) / ppb, B);
+  // output rows per workgroup: every thread (one channel group) should walk >= 2 rows when there are enough of them
+  const int C4 = C / 4;
+  const int rstep = C4 < 256 ? 256 / C4 : 1;
+  int rpb = rstep * 2;
+  if (rpb > p.To) rpb = p.To;
+  p.pos_per_block = rpb;
+  dim3 grid((p.To + rpb - 1) / rpb, B);
   const size_t lds = (size_t)C * sizeof(float);
-  if (k == 3)
-    hipLaunchKernelGGL(depthwise_kernel<3>, grid, dim3(256), lds, (hipStream_t)stream, p);
-  else
-    hipLaunchKernelGGL(depthwise_kernel<5>, grid, dim3(256), lds, (hipStream_t)stream, p);
+  hipStream_t st = (hipStream_t)stream;
+  if (k == 3 && stride == 1) hipLaunchKernelGGL((depthwise_kernel<3, 1>), grid, dim3(256), lds, st, p);
+  else if (k == 3) hipLaunchKernelGGL((depthwise_kernel<3, 2>), grid, dim3(256), lds, st, p);
+  else if (stride == 1) hipLaunchKernelGGL((depthwise_kernel<5, 1>), grid, dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((depthwise_kernel<5, 2>), grid, dim3(256), lds, st, p);
   return ac_check_launch();
 }
 

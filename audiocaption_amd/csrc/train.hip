@@ -57,7 +57,7 @@ struct GemmP {
   float* C; long ldc;
   int M, N, K;
   const float* bias;
-  int relu;       // activation: 0 none, 1 ReLU, 2 swish (x * sigmoid(x))
+  int relu;       // activation: 0 none, 1 ReLU, 2 swish (x * sigmoid(x)), 3 sigmoid
   const float* a_scale; int a_rows;   // optional per-(row group, k) multiplier on A: A(m,k) *= a_scale[(m / a_rows) * K + k]
   float beta;
   int splitk;     // > 1: K is cut into gridDim.z slices, results atomically added to C (beta must be 1)
@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256) void gemm_general_kernel(GemmP p) {
       float v = acc[r] + bias;
       if (p.relu == 1) v = fmaxf(v, 0.f);
       else if (p.relu == 2) v = v / (1.0f + expf(-v));
+      else if (p.relu == 3) v = 1.0f / (1.0f + expf(-v));
       v *= p.drop.mask((uint64_t)(p.row0 + m) * (uint64_t)p.N + (uint64_t)n);
       if (p.beta != 0.f) v += p.beta * *c;
       *c = v;
@@ -230,6 +231,7 @@ __global__ __launch_bounds__(256) void gemm_kk_kernel(GemmP p) {
     float v = ((acc[r] + red[0][row][col]) + (red[1][row][col] + red[2][row][col])) + bias;
     if (p.relu == 1) v = fmaxf(v, 0.f);
     else if (p.relu == 2) v = v / (1.0f + expf(-v));
+    else if (p.relu == 3) v = 1.0f / (1.0f + expf(-v));
     v *= p.drop.mask((uint64_t)(p.row0 + m) * (uint64_t)p.N + (uint64_t)n);
     float* c = p.C + (long)m * p.ldc + n;
     if (p.beta != 0.f) v += p.beta * *c;
@@ -858,7 +860,7 @@ extern "C" {
 int ac_gemm(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc, int M, int N,
             int K, const float* bias, int relu, float beta, int splitk, float drop_p, unsigned long long drop_seed,
             const unsigned long long* seed_dev, long row0, const float* a_scale, int a_rows, void* stream) {
-  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || relu < 0 || relu > 2 || (a_scale && a_rows <= 0)) return AC_ERR_ARG;
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || relu < 0 || relu > 3 || (a_scale && a_rows <= 0)) return AC_ERR_ARG;
   if (splitk > 1 && (bias || relu || drop_p > 0.f || beta != 1.0f)) return AC_ERR_ARG;
   GemmP p;
   p.A = A; p.sam = sam; p.sak = sak; p.B = B; p.sbk = sbk; p.sbn = sbn; p.C = C; p.ldc = ldc;

@@ -214,6 +214,7 @@ class EfficientNetB2(nn.Module):
         nxt = self._buf("act_d", big, dev)
         pool = self._buf("se_pool", B * 2112, dev)
         gate = self._buf("se_gate", B * 2112, dev)
+        sq_buf = self._buf("se_squeezed", B * 128, dev)
         for blk, d in zip(net._blocks, pk["blocks"]):
             rows = B * T * F
             xin = cur
@@ -227,11 +228,15 @@ class EfficientNetB2(nn.Module):
             pb, pa = blk.pad
             To, Fo = (T + pb + pa - blk.k) // blk.stride + 1, (F + pb + pa - blk.k) // blk.stride + 1
             pool[:B * blk.mid].zero_()
-            check(lib.ac_effnet_depthwise(ptr(xmid), ptr(wd), ptr(sc), ptr(sh), ptr(dw_buf), ptr(pool), B, T, F, blk.mid,
-                                          blk.k, blk.stride, pb, pa, s), "ac_effnet_depthwise")
+            check(lib.ac_effnet_depthwise(ptr(xmid), ptr(wd), ptr(sc), ptr(sh), ptr(dw_buf), ptr(pool), 1.0 / (To * Fo), B,
+                                          T, F, blk.mid, blk.k, blk.stride, pb, pa, s), "ac_effnet_depthwise")
+            # squeeze-excite gate for all clips at once: two small GEMMs (swish, then sigmoid, in the epilogues)
             w1, b1, w2, b2 = d["se"]
-            check(lib.ac_effnet_se_gate(ptr(pool), 1.0 / (To * Fo), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(gate), B,
-                                        blk.mid, w1.shape[0], s), "ac_effnet_se_gate")
+            Sq = w1.shape[0]
+            check(lib.ac_gemm(ptr(pool), blk.mid, 1, ptr(w1), 1, blk.mid, ptr(sq_buf), Sq, B, Sq, blk.mid, ptr(b1), 2, 0.0,
+                              1, 0.0, 0, None, 0, None, 0, s), "ac_gemm(se reduce)")
+            check(lib.ac_gemm(ptr(sq_buf), Sq, 1, ptr(w2), 1, Sq, ptr(gate), blk.mid, B, blk.mid, Sq, ptr(b2), 3, 0.0, 1,
+                              0.0, 0, None, 0, None, 0, s), "ac_gemm(se expand)")
             w, b = d["project"]
             rows_o = B * To * Fo
             if blk.skip:

@@ -180,7 +180,7 @@ int ac_trm_beam_reorder(const ac_trm_weights* w, int R, int max_len, int t, cons
 
 /* C[M][N] (row pitch ldc) = epi( sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] ): X W^T / dY W / dY^T X with one kernel
  * (replaces F.linear and its autograd, e.g. transformer_decoder.py:86-101, rnn_encoder.py:41).
- * epi: + bias[n], activation (relu = 1: ReLU, 2: swish x*sigmoid(x)), dropout(drop_p, drop_seed, index (row0+m)*N+n),
+ * epi: + bias[n], activation (relu = 1: ReLU, 2: swish x*sigmoid(x), 3: sigmoid), dropout(drop_p, drop_seed, index (row0+m)*N+n),
  * + beta*C.  splitk > 1: K is cut into splitk slices whose partial sums are atomically ADDED to C (weight gradients;
  * needs beta == 1, no bias/activation/dropout).  a_scale (optional): A(m,k) is multiplied by
  * a_scale[(m / a_rows)*K + k] on the way in - the squeeze-excite gate of an MBConv block applied inside its 1x1
@@ -293,10 +293,11 @@ int ac_top_db_clamp(float* x, long n, float top_db, float* scratch, int scratch_
 int ac_effnet_stem(const float* x, const float* w, const float* scale, const float* shift, float* y, int B, int T, int F,
                    int C, int pad_before, int pad_after, void* stream);
 /* Depthwise k x k conv (k = 3 / 5, stride 1 / 2) + BN + swish: x [B][T][F][C], w [k time][k mel][C] ->
- * y [B][To][Fo][C], To = (T + pad_before + pad_after - k) / stride + 1; pool [B][C] += sum of y over positions
- * (the squeeze of the squeeze-excite layer; zero it first). */
+ * y [B][To][Fo][C], To = (T + pad_before + pad_after - k) / stride + 1; pool [B][C] += pool_scale * sum of y over
+ * positions (the squeeze of the squeeze-excite layer: pool_scale = 1 / (To*Fo) gives the mean; zero it first). */
 int ac_effnet_depthwise(const float* x, const float* w, const float* scale, const float* shift, float* y, float* pool,
-                        int B, int T, int F, int C, int k, int stride, int pad_before, int pad_after, void* stream);
+                        float pool_scale, int B, int T, int F, int C, int k, int stride, int pad_before, int pad_after,
+                        void* stream);
 /* gate[b][c] = sigmoid(w2 swish(w1 (pool[b] * inv_count) + b1) + b2), w1 [S][C], w2 [C][S]. */
 int ac_effnet_se_gate(const float* pool, float inv_count, const float* w1, const float* b1, const float* w2,
                       const float* b2, float* gate, int B, int C, int S, void* stream);

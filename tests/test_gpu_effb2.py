@@ -74,7 +74,7 @@ def test_depthwise_kernel_and_squeeze_sums(lib, k, stride, pad):
     y = torch.empty(ref_cl.shape, device="cuda")
     pool = torch.zeros(B, C, device="cuda")
     wp = w[:, 0].permute(2, 1, 0).contiguous().cuda()        # [k time][k mel][C]
-    assert lib.ac_effnet_depthwise(P(x.cuda()), P(wp), P(sc.cuda()), P(sh.cuda()), P(y), P(pool), B, T, Fm, C, k, stride,
+    assert lib.ac_effnet_depthwise(P(x.cuda()), P(wp), P(sc.cuda()), P(sh.cuda()), P(y), P(pool), 1.0, B, T, Fm, C, k, stride,
                                    pad[0], pad[1], S()) == 0
     assert rel(f"depthwise k{k} s{stride}", y, ref_cl) < 1e-5
     assert rel("squeeze sums", pool, ref.sum(dim=(2, 3))) < 1e-5
