@@ -78,6 +78,7 @@ SIGNATURES = {
     "ac_label_smoothing_loss": (_I, [_P, _P, _L, _P, _I, _I, _I, _F, _F, _P, _P, _P, _F, _P, _P]),
     "ac_gru_layer_train": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ac_gru_layer_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "ac_swa_update": (_I, [_P, _P, _L, _I, _P]),
     "ac_grad_sumsq": (_I, [_P, _L, _P, _P]),
     "ac_clip_coef": (_I, [_P, _F, _F, _P]),
     "ac_scale_by_coef": (_I, [_P, _L, _P, _P]),

@@ -820,16 +820,21 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* g, long n, floa
   __syncthreads();
   if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
 }
-// norm_state[0] = sum of squares in, [1] = total norm out, [2] = clip coefficient out
+// norm_state[0] = sum of squares in, [1] = total norm out, [2] = clip coefficient out, [3] = 1 when the gradient is
+// not finite: the update is then skipped on the device, the reference's `if not torch.isnan(loss)` (run.py:123)
+// without a host synchronisation
 __global__ void clip_coef_kernel(float* norm_state, float max_norm, float grad_div) {
   const float norm = sqrtf(norm_state[0]) / grad_div;
   norm_state[1] = norm;
+  const bool bad = !(norm == norm) || norm > 3.0e38f;
   float c = max_norm > 0.f ? max_norm / (norm + 1e-6f) : 1.0f;
-  norm_state[2] = (c < 1.0f ? c : 1.0f) / grad_div;
+  norm_state[2] = bad ? 0.f : (c < 1.0f ? c : 1.0f) / grad_div;
+  norm_state[3] = bad ? 1.f : 0.f;
 }
 __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long n, const float* norm_state, float lr,
                             float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
   const float coef = norm_state ? norm_state[2] : 1.0f;
+  if (norm_state && norm_state[3] != 0.f) return;   // non-finite gradient: leave parameters and moments untouched
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float gi = g[i] * coef;
     const float pi = p[i];
@@ -840,6 +845,13 @@ __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long n
     v[i] = vi;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
     p[i] = pi - (lr / bc1) * (mi / denom);
+  }
+}
+// stochastic weight averaging (train_util.py:233-253 with torch's default avg_fn): avg += (p - avg) / (n_averaged + 1)
+__global__ void swa_kernel(float* avg, const float* p, long n, float inv) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float a = avg[i];
+    avg[i] = a + (p[i] - a) * inv;
   }
 }
 __global__ void scale_kernel(float* x, long n, const float* norm_state) {
@@ -1089,6 +1101,13 @@ int ac_clip_coef(float* norm_state, float max_norm, float grad_div, void* stream
 int ac_scale_by_coef(float* x, long n, const float* norm_state, void* stream) {
   if (!x || !norm_state || n <= 0) return AC_ERR_ARG;
   hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, x, n, norm_state);
+  return ac_check_launch();
+}
+
+int ac_swa_update(float* avg, const float* p, long n, int n_averaged, void* stream) {
+  if (!avg || !p || n <= 0 || n_averaged < 0) return AC_ERR_ARG;
+  hipLaunchKernelGGL(swa_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, avg, p, n,
+                     1.0f / (float)(n_averaged + 1));
   return ac_check_launch();
 }
 

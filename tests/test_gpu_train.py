@@ -516,3 +516,40 @@ def test_engine_step_trains_and_refreshes_inference_weights(train_model):
     gain = out["logit"][:, 0].gather(1, first[:, None]) - logit0.gather(1, first[:, None])
     print("first-word logit gain:", gain.flatten().tolist())
     assert float(gain.min()) > 0.0
+
+
+def test_swa_and_nan_skip_on_device(train_model):
+    """SWA over the flat parameter buffer (one launch) equals the running mean of the snapshots; a non-finite gradient
+    makes clip + Adam skip the update on the device (run.py:123) instead of poisoning the parameters."""
+    from audiocaption_amd import procedural as Pr
+    from audiocaption_amd.optim import FusedAdam, clip_grad_norm_
+    from audiocaption_amd.train import TrainEngine
+    from audiocaption_amd.trainer import SwaAverager
+    model = train_model
+    B, L = 2, 96000
+    wav = torch.from_numpy(Pr.synthetic_wav(B, L, seed=4)).cuda()
+    cap = torch.tensor([[1, 9, 30, 2, 0], [1, 7, 7, 12, 2]])
+    batch = {"mode": "train", "wav": wav, "wav_len": [L] * B, "specaug": False, "cap": cap.cuda(),
+             "cap_len": np.array([4, 5]), "ss_ratio": 0.9}
+    eng = TrainEngine(model)
+    model._train_engine = eng
+    opt = FusedAdam([p for p in model.parameters() if p.requires_grad], lr=1e-3)
+    swa = SwaAverager(model)
+    key = "decoder.classifier.weight"
+    snaps = []
+    for _ in range(3):
+        eng.step(batch, opt)
+        snaps.append(dict(model.named_parameters())[key].detach().clone())
+        swa.update_parameters(model)
+    want = sum(snaps) / 3
+    assert rel("swa average", swa.state_dict()[key], want) < 1e-6
+    assert swa.n_averaged == 3 and set(swa.state_dict()) == set(model.state_dict())
+    # poison one gradient entry: the norm is NaN -> flag set, coefficient 0, parameters and moments unchanged
+    before = eng.flat.flat.clone()
+    m_before = opt._flat_state[0]["m"].clone()
+    eng.flat.attach_grads()
+    eng.flat.grad[5] = float("nan")
+    clip = clip_grad_norm_(eng.flat.params, 1.0, scale_now=False)
+    opt.step(clip=clip)
+    assert float(clip.state[3]) == 1.0 and float(clip.state[2]) == 0.0
+    assert torch.equal(eng.flat.flat, before) and torch.equal(opt._flat_state[0]["m"], m_before)

@@ -109,3 +109,54 @@ def test_flat_gradient_allreduce_world2_gloo():
         assert w == 2 and torch.equal(flat, want)
         avg = want / 2
         assert coef * 2 == pytest.approx(min(1.0, 1.0 / (float(avg.norm()) + 1e-6)))
+
+
+def test_scheduled_sampling_ratio_follows_run_py():
+    from audiocaption_amd.trainer import ScheduledSampling
+    lin = ScheduledSampling(True, "linear", 0.7, 1000)
+    r = [lin.step() for _ in range(1000)]
+    assert r[0] == pytest.approx(1 - 0.3 / 1000) and r[-1] == pytest.approx(0.7)
+    ex = ScheduledSampling(True, "exponential", 0.7, 500)
+    r = [ex.step() for _ in range(500)]
+    assert r[-1] == pytest.approx(0.01) and r[0] == pytest.approx(0.01 ** (1 / 500))
+    off = ScheduledSampling(False)
+    assert off.step() == 1.0
+    with pytest.raises(Exception):
+        ScheduledSampling(True, "cosine")
+
+
+def test_dict_tokenizer_roundtrip_and_prediction_file(tmp_path):
+    import json
+    import pickle
+    from audiocaption_amd.text import DictTokenizer, write_predictions
+    words = {"<pad>": 0, "<start>": 1, "<end>": 2, "<unk>": 3, "a": 4, "dog": 5, "barks": 6}
+    p = tmp_path / "vocab.pkl"
+    p.write_bytes(pickle.dumps(words))
+    tok = DictTokenizer(str(p), max_length=3)
+    assert tok.loaded and len(tok) == 7 and (tok.bos, tok.eos, tok.pad) == (1, 2, 0)
+    enc = tok(["a dog barks loudly today", "a cat"])
+    assert enc["cap"].tolist() == [[1, 4, 5, 6, 2], [1, 4, 3, 2, 0]] and enc["cap_len"].tolist() == [5, 4]
+    seqs = np.array([[4, 5, 6, 2, 2, 2], [1, 4, 5, 2, 6, 6], [4, 4, 4, 4, 4, 4]])
+    assert tok.decode(seqs) == ["a dog barks", "a dog", "a a a a a a"]
+    out = tmp_path / "sub" / "pred.json"
+    write_predictions({"x.wav": ["a dog barks"], "y.wav": ["a dog"]}, str(out))
+    assert json.loads(out.read_text()) == {"predictions": [{"filename": "x.wav", "tokens": "a dog barks"},
+                                                           {"filename": "y.wav", "tokens": "a dog"}]}
+
+
+def test_swa_averager_on_cpu_tensors():
+    from audiocaption_amd.trainer import SwaAverager
+    m = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.BatchNorm1d(3))
+    swa = SwaAverager(m)
+    snaps = []
+    for k in range(4):
+        with torch.no_grad():
+            for p in m.parameters():
+                p.add_(k + 1.0)
+        snaps.append({n: t.detach().clone() for n, t in m.state_dict().items()})
+        swa.update_parameters(m)
+    sd = swa.state_dict()
+    assert set(sd) == set(m.state_dict())
+    for n in ("0.weight", "0.bias", "1.weight"):
+        want = sum(s[n] for s in snaps) / 4
+        assert torch.allclose(sd[n], want, atol=1e-6)
