@@ -89,6 +89,8 @@ SIGNATURES = {
     "ac_effnet_stem": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ac_effnet_depthwise": (_I, [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ac_effnet_se_gate": (_I, [_P, _F, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    # waveform ingest (csrc/ingest.hip)
+    "ac_ingest_resample": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
 }
 
 _lib = None

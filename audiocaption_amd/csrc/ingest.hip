@@ -1,0 +1,68 @@
+// Waveform ingest in front of the hot path: float16 / float32 clips of different
+// lengths -> one zero-padded float32 batch at the model's sample rate, in ONE pass over the samples.
+//
+// Replaces, per clip, np.float32(h5 float16) (caption_dataset.py:131-145), torchaudio.functional.resample
+// (caption_dataset.py:110-120; the windowed-sinc polyphase filter of torchaudio==0.13.1, un-vendored: PARITY UNPINNED)
+// and the padding collate (inference.py:81-111).  torchaudio evaluates the filter as a dense strided conv1d over
+// 2*width + orig taps per output sample; all but ~2*6*orig/(0.99*min(orig,new)) of them are exactly zero (the Hann
+// window is clamped), so each output sample here only walks the non-zero tap range of its phase.
+#include <hip/hip_fp16.h>
+#include "ac_common.h"
+
+namespace {
+
+struct IngestP {
+  const void* src;         // all clips back to back
+  int src_half;            // 1: float16, 0: float32
+  const long* src_off;     // [B + 1] sample offsets of the clips in src
+  const float* kernel;     // [new][kw] polyphase filters (kw = 2 * width + orig)
+  const int* tap_lo;       // [new] first non-zero tap of each phase
+  const int* tap_hi;       // [new] one past the last non-zero tap
+  float* out;              // [B][lmax]
+  const int* out_len;      // [B] resampled lengths
+  int B, lmax, orig, new_, width, kw;
+};
+
+__global__ void ingest_kernel(IngestP p) {
+  const int b = blockIdx.y;
+  const long len = p.src_off[b + 1] - p.src_off[b];
+  const int olen = p.out_len[b];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < p.lmax; i += gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    if (i < olen) {
+      if (p.new_ == p.orig) {
+        const long s = p.src_off[b] + i;
+        acc = p.src_half ? __half2float(((const __half*)p.src)[s]) : ((const float*)p.src)[s];
+      } else {
+        const int phase = i % p.new_;
+        const long first = (long)(i / p.new_) * p.orig - p.width;   // source index of tap 0
+        const float* k = p.kernel + (long)phase * p.kw;
+        for (int t = p.tap_lo[phase]; t < p.tap_hi[phase]; ++t) {
+          const long s = first + t;
+          if (s < 0 || s >= len) continue;
+          const long g = p.src_off[b] + s;
+          const float x = p.src_half ? __half2float(((const __half*)p.src)[g]) : ((const float*)p.src)[g];
+          acc = fmaf(x, k[t], acc);
+        }
+      }
+    }
+    p.out[(long)b * p.lmax + i] = acc;
+  }
+}
+
+}  // namespace
+
+extern "C" int ac_ingest_resample(const void* src, int src_half, const long* src_off, const float* kernel, const int* tap_lo,
+                                  const int* tap_hi, float* out, const int* out_len, int B, int lmax, int orig, int new_,
+                                  int width, void* stream) {
+  if (!src || !src_off || !out || !out_len || B <= 0 || lmax <= 0 || orig <= 0 || new_ <= 0 || width < 0) return AC_ERR_ARG;
+  if (orig != new_ && (!kernel || !tap_lo || !tap_hi)) return AC_ERR_ARG;
+  IngestP p;
+  p.src = src; p.src_half = src_half; p.src_off = src_off; p.kernel = kernel; p.tap_lo = tap_lo; p.tap_hi = tap_hi;
+  p.out = out; p.out_len = out_len; p.B = B; p.lmax = lmax; p.orig = orig; p.new_ = new_; p.width = width;
+  p.kw = 2 * width + orig;
+  int gx = (lmax + 255) / 256;
+  if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(ingest_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, p);
+  return ac_check_launch();
+}

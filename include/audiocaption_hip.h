@@ -307,6 +307,17 @@ int ac_effnet_depthwise(const float* x, const float* w, const float* scale, cons
 int ac_effnet_se_gate(const float* pool, float inv_count, const float* w1, const float* b1, const float* w2,
                       const float* b2, float* gate, int B, int C, int S, void* stream);
 
+/* ===================================== waveform ingest =====================================
+ * B clips stored back to back in src (float16 when src_half, else float32; clip b = src[src_off[b] .. src_off[b+1]))
+ * -> out [B][lmax] float32: converted, resampled by the windowed-sinc polyphase filter of
+ * torchaudio.functional.resample (call site caption_dataset.py:110-120; kernel [new][2*width + orig] with the non-zero
+ * tap range [tap_lo, tap_hi) of each phase; orig / new are the gcd-reduced rates; orig == new: conversion only) and
+ * zero-padded beyond out_len[b] (WavPadCollate, inference.py:81-111).  PARITY UNPINNED for the filter (torchaudio is
+ * not vendored). */
+int ac_ingest_resample(const void* src, int src_half, const long* src_off, const float* kernel, const int* tap_lo,
+                       const int* tap_hi, float* out, const int* out_len, int B, int lmax, int orig, int new_, int width,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif
