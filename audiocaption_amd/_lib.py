@@ -54,6 +54,7 @@ SIGNATURES = {
     "ac_trm_greedy": (_I, [_WP, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "ac_trm_forward_tokens": (_I, [_WP, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
     "ac_trm_beam_step": (_I, [_WP, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P]),
+    "ac_trm_beam_update": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ac_trm_beam_reorder": (_I, [_WP, _I, _I, _I, _P, _P, _P]),
     # training step (csrc/train.hip)
     "ac_gemm": (_I, [_P, _L, _L, _P, _L, _L, _P, _L, _I, _I, _I, _P, _I, _F, _I, _F, _U64, _P, _L, _P, _I, _P]),

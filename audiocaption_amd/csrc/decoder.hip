@@ -544,6 +544,60 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(const float* lp, int bea
   }
 }
 
+// Per-clip beam bookkeeping of base.py:290-323 on the device (one workgroup per clip, thread 0 does the serial part):
+// re-gather the token rows by the chosen previous beams, append the new words, record the beams that END this step
+// (in beam order, score = logprob / (t + 1)), apply the -1000 trick to their cumulative scores and retire the clip
+// when its number of finished beams EQUALS the beam size (the reference's '==').  A retired clip keeps its rows.
+__global__ __launch_bounds__(64) void beam_update_kernel(const float* top_val, const int* top_idx, const int* tok_in,
+                                                        int* tok_out, unsigned char* mask_out, float* cum, int* active,
+                                                        int* done_cnt, int* done_seq, float* done_score, int* src_row,
+                                                        int* n_active, int beam, int V, int max_len, int t, int end_idx,
+                                                        int pad_idx, int cap) {
+  __shared__ int s_src[64];
+  __shared__ int s_word[64];
+  const int clip = blockIdx.x, tid = threadIdx.x;
+  const int ld = max_len + 1;
+  const bool act = active[clip] != 0;
+  if (tid < beam) {
+    const int flat = top_idx[clip * beam + tid];
+    s_src[tid] = act ? clip * beam + flat / V : clip * beam + tid;
+    s_word[tid] = flat % V;
+    src_row[clip * beam + tid] = s_src[tid];
+  }
+  __syncthreads();
+  // token rows (and the key-padding mask the decoder step reads)
+  for (int e = tid; e < beam * ld; e += 64) {
+    const int k = e / ld, c = e % ld;
+    int v = tok_in[(size_t)s_src[k] * ld + c];
+    if (act && c == t + 1) v = s_word[k];
+    tok_out[(size_t)(clip * beam + k) * ld + c] = v;
+    mask_out[(size_t)(clip * beam + k) * ld + c] = v == pad_idx ? 1 : 0;
+  }
+  __syncthreads();
+  if (tid == 0 && act) {
+    int cnt = done_cnt[clip];
+    for (int k = 0; k < beam; ++k) {
+      const float v = top_val[clip * beam + k];
+      const bool is_end = s_word[k] == end_idx || t == max_len - 1;
+      if (is_end) {
+        if (cnt < cap) {
+          int* dst = done_seq + ((size_t)clip * cap + cnt) * max_len;
+          const int* row = tok_out + (size_t)(clip * beam + k) * ld;
+          for (int c = 0; c < max_len; ++c) dst[c] = c <= t ? row[c + 1] : end_idx;
+          done_score[(size_t)clip * cap + cnt] = v / (float)(t + 1);
+        }
+        ++cnt;
+      }
+      cum[clip * beam + k] = v - (is_end ? 1000.0f : 0.0f);
+    }
+    done_cnt[clip] = cnt;
+    if (cnt == beam) {
+      active[clip] = 0;
+      atomicSub(n_active, 1);
+    }
+  }
+}
+
 // dst[l][r][0..t][:] = src[l][src_row[r]][0..t][:] for both K and V caches
 __global__ void cache_gather_kernel(const float* src, float* dst, const int* src_row, int R, int max_len, int t,
                                     int d, size_t set_stride /* floats between K and V sets and layers */, int nsets) {
@@ -867,6 +921,20 @@ extern "C" int ac_trm_beam_step(const ac_trm_weights* w, const float* memkv, con
   AC_TRY(ac_check_launch());
   hipLaunchKernelGGL(beam_topk_kernel, dim3(B), dim3(256), 0, s, lp, beam, t == 0 ? 1 : beam, V, top_val,
                      top_idx);
+  return ac_check_launch();
+}
+
+extern "C" int ac_trm_beam_update(const float* top_val, const int* top_idx, const int* tokens_in, int* tokens_out,
+                                  unsigned char* key_mask_out, float* cum_logprob, int* active, int* done_count,
+                                  int* done_seq, float* done_score, int* src_row, int* n_active, int B, int beam, int V,
+                                  int max_len, int t, int end_idx, int pad_idx, int done_capacity, void* stream) {
+  if (!top_val || !top_idx || !tokens_in || !tokens_out || !key_mask_out || !cum_logprob || !active || !done_count ||
+      !done_seq || !done_score || !src_row || !n_active || B <= 0 || beam <= 0 || beam > 64 || V <= 0 || max_len <= 0 ||
+      t < 0 || t >= max_len || done_capacity <= 0)
+    return AC_ERR_ARG;
+  hipLaunchKernelGGL(beam_update_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, top_val, top_idx, tokens_in, tokens_out,
+                     key_mask_out, cum_logprob, active, done_count, done_seq, done_score, src_row, n_active, beam, V,
+                     max_len, t, end_idx, pad_idx, done_capacity);
   return ac_check_launch();
 }
 

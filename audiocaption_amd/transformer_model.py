@@ -18,6 +18,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import _lib
+from ._lib import check, ptr, stream
 from .transformer_decoder import TransformerDecoder
 
 
@@ -193,53 +195,51 @@ class TransformerModel(CaptionModel):
         memkv = dec.memory(attn_emb)
         ws = dec.workspace(R, max_length, dev)
 
-        tokens = np.full((R, max_length + 1), self.end_idx, dtype=np.int32)
-        tokens[:, 0] = self.start_idx
-        cum = np.zeros((B, beam), dtype=np.float32)
-        done = [[] for _ in range(B)]
-        active = np.ones(B, dtype=bool)
-        base = (np.arange(B, dtype=np.int64) * beam)[:, None]
-        identity = np.arange(R, dtype=np.int32)
+        # Everything per step stays on the device: decoder step + scores + per-clip top-k (ac_trm_beam_step), the
+        # per-clip bookkeeping of base.py:290-323 (ac_trm_beam_update) and the KV-cache re-gather
+        # (ac_trm_beam_reorder).  The host only asks now and then whether any clip is still searching.
+        lib = _lib.load()
+        ld = max_length + 1
+        cap = beam * max_length                    # upper bound of finished beams per clip
+        i32 = dict(device=dev, dtype=torch.int32)
+        tok = [torch.full((R, ld), self.end_idx, **i32) for _ in range(2)]
+        tok[0][:, 0] = self.start_idx
+        mask = torch.zeros(R, ld, device=dev, dtype=torch.uint8)
+        if self.start_idx == self.pad_idx or self.end_idx == self.pad_idx:
+            mask = (tok[0] == self.pad_idx).to(torch.uint8)
+        cum = torch.zeros(B * beam, device=dev, dtype=torch.float32)
+        active = torch.ones(B, **i32)
+        done_cnt = torch.zeros(B, **i32)
+        done_seq = torch.empty(B, cap, max_length, **i32)
+        done_score = torch.empty(B, cap, device=dev, dtype=torch.float32)
+        src_row = torch.empty(R, **i32)
+        n_active = torch.full((1,), B, **i32)
         for t in range(max_length):
-            tok_dev = torch.from_numpy(tokens).to(dev)
-            mask_dev = torch.from_numpy((tokens == self.pad_idx).astype(np.uint8)).to(dev)
-            cum_dev = torch.from_numpy(cum.reshape(-1)).to(dev)
-            top_val, top_idx = dec.beam_step(memkv, mem_len, B, beam, Tm, max_length, t, temp, tok_dev, mask_dev,
-                                             cum_dev, ws)
-            top_val = top_val.cpu().numpy()
-            top_idx = top_idx.cpu().numpy().astype(np.int64)
-            # per-clip bookkeeping of base.py:290-323, vectorised over the clips (only beams that END are visited
-            # one by one, in beam order, to keep the reference's append order and its '==' stop rule)
-            act = active[:, None]
-            prev_beam, word = top_idx // V, top_idx % V
-            src_row = np.where(act, base + prev_beam, identity.reshape(B, beam)).astype(np.int32).reshape(-1)
-            new_tokens = tokens[src_row]
-            new_tokens[:, t + 1] = np.where(act, word, new_tokens[:, t + 1].reshape(B, beam)).reshape(-1)
-            is_end = (word == self.end_idx) | (t == max_length - 1)
-            is_end &= act
-            for i, k in zip(*np.nonzero(is_end)):
-                done[i].append({"seq": new_tokens[i * beam + k, 1:t + 2].copy(), "score": float(top_val[i, k]) / (t + 1)})
-            cum = np.where(act, top_val - np.where(is_end, np.float32(1000.0), np.float32(0.0)), cum).astype(np.float32)
-            for i in np.nonzero(is_end.any(axis=1))[0]:
-                if len(done[i]) == beam:  # '==' as in base.py:321
-                    active[i] = False
-            tokens = new_tokens
-            if not active.any():
+            top_val, top_idx = dec.beam_step(memkv, mem_len, B, beam, Tm, max_length, t, temp, tok[t & 1], mask, cum, ws)
+            check(lib.ac_trm_beam_update(ptr(top_val), ptr(top_idx), ptr(tok[t & 1]), ptr(tok[(t + 1) & 1]), ptr(mask),
+                                         ptr(cum), ptr(active), ptr(done_cnt), ptr(done_seq), ptr(done_score),
+                                         ptr(src_row), ptr(n_active), B, beam, V, max_length, t, self.end_idx,
+                                         self.pad_idx, cap, stream()), "ac_trm_beam_update")
+            if t in (7, 11, 15) and int(n_active.item()) == 0:   # every clip has its `beam` finished beams
                 break
-            dec.beam_reorder(R, max_length, t, torch.from_numpy(src_row).to(dev), ws)
+            if t + 1 < max_length:
+                dec.beam_reorder(R, max_length, t, src_row, ws)
+        counts = done_cnt.cpu().numpy()
+        seqs = done_seq.cpu().numpy()
+        scores = done_score.cpu().numpy()
 
         if n_best:
             seq = torch.full((B, n_best_size, max_length), self.end_idx, dtype=torch.long)
         else:
             seq = torch.full((B, max_length), self.end_idx, dtype=torch.long)
         for i in range(B):
-            beams = sorted(done[i], key=lambda x: -x["score"])
+            n = min(int(counts[i]), cap)
+            order = sorted(range(n), key=lambda j: -scores[i, j])   # stable: ties keep the append order
             if n_best:
-                for j, bm in enumerate(beams[:n_best_size]):
-                    seq[i, j, :len(bm["seq"])] = torch.from_numpy(bm["seq"].astype(np.int64))
+                for j, o in enumerate(order[:n_best_size]):
+                    seq[i, j] = torch.from_numpy(seqs[i, o].astype(np.int64))
             else:
-                s = beams[0]["seq"]
-                seq[i, :len(s)] = torch.from_numpy(s.astype(np.int64))
+                seq[i] = torch.from_numpy(seqs[i, order[0]].astype(np.int64))
         # logit / embed / sampled_logprob are not filled by the reference's beam search either
         # (base.py:124-127 leaves them at torch.empty / zeros)
         return {

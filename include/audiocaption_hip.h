@@ -163,6 +163,16 @@ int ac_trm_forward_tokens(const ac_trm_weights* w, const float* memkv, const int
 int ac_trm_beam_step(const ac_trm_weights* w, const float* memkv, const int* mem_len, int B, int beam, int Tm,
                      int max_len, int t, float temp, const int* tokens, const unsigned char* key_mask,
                      const float* cum_logprob, float* top_val, int* top_idx, float* ws, void* stream);
+/* Per-clip beam bookkeeping on the device (base.py:290-323), one call per step after ac_trm_beam_step: for every clip
+ * still active, row k of tokens_out = row (top_idx / V) of tokens_in with the word (top_idx % V) appended at column
+ * t + 1 (key_mask_out = tokens_out == pad_idx); beams whose word is end_idx (all of them at t == max_len - 1) are
+ * appended, in beam order, to the clip's finished list done_seq [B][done_capacity][max_len] (padded with end_idx) /
+ * done_score (= logprob / (t + 1)), their cumulative score gets the reference's -1000; the clip retires when its
+ * finished count EQUALS beam (n_active is decremented).  src_row [B*beam] is what ac_trm_beam_reorder needs. */
+int ac_trm_beam_update(const float* top_val, const int* top_idx, const int* tokens_in, int* tokens_out,
+                       unsigned char* key_mask_out, float* cum_logprob, int* active, int* done_count, int* done_seq,
+                       float* done_score, int* src_row, int* n_active, int B, int beam, int V, int max_len, int t,
+                       int end_idx, int pad_idx, int done_capacity, void* stream);
 /* Re-gather the beams after selection (base.py:294-302): row r of cache set ((t+1) & 1) takes the
  * self-attention KV cache (positions 0..t) of row src_row[r] of set (t & 1). */
 int ac_trm_beam_reorder(const ac_trm_weights* w, int R, int max_len, int t, const int* src_row, float* ws,
