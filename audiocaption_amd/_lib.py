@@ -44,6 +44,7 @@ SIGNATURES = {
     "ac_conv3x3_bn_relu_bf16x3_gw": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ac_conv3x3_first": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ac_linear": (_I, [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _P]),
+    "ac_gru_pack_whh": (_I, [_P, _P, _I, _P]),
     "ac_gru_layer": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ac_mean_with_lens": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "ac_add_layernorm": (_I, [_P, _P, _P, _P, _P, _I, _I, _L, _L, _L, _P]),

@@ -8,15 +8,15 @@
 // workgroup that walks its own valid steps (forward: 0..len-1, reverse: len-1..0 - i.e. the reverse
 // direction starts at the clip's own last valid frame, exactly what packing does) with the hidden
 // state in LDS; no inter-workgroup synchronisation exists anywhere.  The 768x256 recurrent matrix is
-// streamed from L2 every step in a k-major transposed copy so that the 768 threads read it fully
-// coalesced.  Steps t >= len are written as zeros (pad_packed_sequence semantics).
+// streamed from L2 every step in a packed copy [k/4][column][4] (ac_gru_pack_whh): thread n reads 4
+// consecutive k of its column with one 16-byte load, consecutive threads consecutive 16-byte words.  Steps t >= len are written as zeros (pad_packed_sequence semantics).
 #include "ac_common.h"
 
 namespace {
 
 struct GruParams {
   const float* gx;     // [B][T][2][3H]  x W_ih^T + b_ih, gate order r, z, n
-  const float* whhT;   // [2][H][3H]     W_hh transposed (k-major)
+  const float* whhT;   // [2][H/4][3H][4] W_hh packed by ac_gru_pack_whh
   const float* bhh;    // [2][3H]
   const int* lens;     // [B]
   float* out;          // [B][T][2H]
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(768) void gru_layer_kernel(GruParams p) {
   const int b = blockIdx.x >> 1, dir = blockIdx.x & 1;
   int len = p.lens[b];
   len = len < 0 ? 0 : (len > p.T ? p.T : len);
-  const float* W = p.whhT + (size_t)dir * H * 3 * H + n;
+  const float* W = p.whhT + (size_t)dir * H * 3 * H + (size_t)n * 4;
   const float bias = p.bhh[dir * 3 * H + n];
   if (n < H) sh[n] = 0.f;
   __syncthreads();
@@ -44,10 +44,11 @@ __global__ __launch_bounds__(768) void gru_layer_kernel(GruParams p) {
 #pragma unroll 8
     for (int k = 0; k < H; k += 4) {
       const float4 hv = *(const float4*)(sh + k);
-      acc = fmaf(W[(size_t)(k + 0) * 3 * H], hv.x, acc);
-      acc = fmaf(W[(size_t)(k + 1) * 3 * H], hv.y, acc);
-      acc = fmaf(W[(size_t)(k + 2) * 3 * H], hv.z, acc);
-      acc = fmaf(W[(size_t)(k + 3) * 3 * H], hv.w, acc);
+      const float4 wv = *(const float4*)(W + (size_t)(k >> 2) * 3 * H * 4);   // k..k+3 of this thread's column
+      acc = fmaf(wv.x, hv.x, acc);
+      acc = fmaf(wv.y, hv.y, acc);
+      acc = fmaf(wv.z, hv.z, acc);
+      acc = fmaf(wv.w, hv.w, acc);
     }
     sg[n] = acc;
     __syncthreads();
@@ -92,7 +93,22 @@ __global__ void maxmean_lens_kernel(const float* x, const int* lens, float* out,
   }
 }
 
+// packed[d][k/4][n][k%4] = whh[d][n][k]
+__global__ void gru_pack_whh_kernel(const float* whh, float* packed, int total) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int kk = i & 3, n = (i >> 2) % (3 * H), k4 = ((i >> 2) / (3 * H)) % (H / 4), d = i / (3 * H * H);
+  packed[i] = whh[((size_t)d * 3 * H + n) * H + k4 * 4 + kk];
+}
+
 }  // namespace
+
+extern "C" int ac_gru_pack_whh(const float* whh, float* packed, int hidden, void* stream) {
+  if (!whh || !packed || hidden != H) return AC_ERR_ARG;
+  const int total = 2 * 3 * H * H;
+  hipLaunchKernelGGL(gru_pack_whh_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, whh, packed, total);
+  return ac_check_launch();
+}
 
 // C ABI: see include/audiocaption_hip.h
 extern "C" int ac_gru_layer(const float* gx, const float* whhT, const float* bhh, const int* lens, float* out,

@@ -711,7 +711,7 @@ __global__ __launch_bounds__(768) void gru_train_fwd_kernel(const float* gx, con
   const int b = blockIdx.x >> 1, dir = blockIdx.x & 1;
   int len = lens[b];
   len = len < 0 ? 0 : (len > T ? T : len);
-  const float* W = whhT + (size_t)dir * H * 3 * H + n;
+  const float* W = whhT + (size_t)dir * H * 3 * H + (size_t)n * 4;
   const float bias = bhh[dir * 3 * H + n];
   if (n < H) sh[n] = 0.f;
   __syncthreads();
@@ -721,10 +721,11 @@ __global__ __launch_bounds__(768) void gru_train_fwd_kernel(const float* gx, con
 #pragma unroll 8
     for (int k = 0; k < H; k += 4) {
       const float4 hv = *(const float4*)(sh + k);
-      acc = fmaf(W[(size_t)(k + 0) * 3 * H], hv.x, acc);
-      acc = fmaf(W[(size_t)(k + 1) * 3 * H], hv.y, acc);
-      acc = fmaf(W[(size_t)(k + 2) * 3 * H], hv.z, acc);
-      acc = fmaf(W[(size_t)(k + 3) * 3 * H], hv.w, acc);
+      const float4 wv = *(const float4*)(W + (size_t)(k >> 2) * 3 * H * 4);   // k..k+3 of this thread's column
+      acc = fmaf(wv.x, hv.x, acc);
+      acc = fmaf(wv.y, hv.y, acc);
+      acc = fmaf(wv.z, hv.z, acc);
+      acc = fmaf(wv.w, hv.w, acc);
     }
     sg[n] = acc;
     __syncthreads();

@@ -167,6 +167,15 @@ def linear(x, w, b=None, relu=False, out=None):
     return out
 
 
+def gru_pack_whh(whh, hidden):
+    """nn.GRU weight_hh of both directions [2][3H][H] -> the recurrence kernel's layout [2][H/4][3H][4]."""
+    lib = _lib.load()
+    whh = f32c(_dev(whh))
+    out = torch.empty_like(whh)
+    check(lib.ac_gru_pack_whh(ptr(whh), ptr(out), hidden, stream()), "ac_gru_pack_whh")
+    return out
+
+
 def gru_layer(gx, whhT, bhh, lens_i32, B, T, hidden):
     lib = _lib.load()
     out = torch.empty(B, T, 2 * hidden, device=gx.device, dtype=torch.float32)

@@ -49,7 +49,8 @@ class RnnEncoder(nn.Module):
                 f, r = f"_l{l}", f"_l{l}_reverse"
                 w_ih = torch.cat([ps["weight_ih" + f], ps["weight_ih" + r]], 0).float().contiguous()
                 b_ih = torch.cat([ps["bias_ih" + f], ps["bias_ih" + r]], 0).float().contiguous()
-                whhT = torch.stack([ps["weight_hh" + f].t(), ps["weight_hh" + r].t()], 0).float().contiguous()
+                whh = torch.stack([ps["weight_hh" + f], ps["weight_hh" + r]], 0).float().contiguous()
+                whhT = K.gru_pack_whh(whh, self.hidden_size)   # [2][H/4][3H][4]
                 bhh = torch.stack([ps["bias_hh" + f], ps["bias_hh" + r]], 0).float().contiguous()
                 layers.append((w_ih, b_ih, whhT, bhh))
         self._packed, self._packed_key = layers, key

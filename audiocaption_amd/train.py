@@ -339,7 +339,7 @@ class TrainEngine:
             gx = ws.f(f"gx{l}", rows_g, 6 * H)
             self._lin(s, x_in, w_ih, b_ih, gx, rows_g, 6 * H, in_dim)
             whhT = ws.f(f"whhT{l}", 2 * 3 * H * H)
-            check(lib.ac_transpose(w_hh, whhT, 2, 3 * H, H, s), "ac_transpose")
+            check(lib.ac_gru_pack_whh(w_hh, whhT, H, s), "ac_gru_pack_whh")
             out = ws.f(f"gru_out{l}", rows_g, 2 * H)
             save = ws.f(f"gru_save{l}", rows_g, 2 * 4 * H)
             check(lib.ac_gru_layer_train(gx, whhT, b_hh, lens_p, out, save, B, Tq, H, s), "ac_gru_layer_train")

@@ -84,8 +84,10 @@ int ac_linear(const float* X, const float* W, const float* bias, float* Y, int M
 
 /* ---- GRU recurrence + pooling -------------------------------------------------------------------
  * One bidirectional layer of the packed GRU (rnn_encoder.py:41 via model_util.py:22-27):
- * gx [B][T][2][3H] = input projections incl. b_ih (gate order r,z,n), whhT [2][H][3H] = W_hh^T,
+ * gx [B][T][2][3H] = input projections incl. b_ih (gate order r,z,n), whhT [2][H/4][3H][4] = W_hh packed by ac_gru_pack_whh,
  * bhh [2][3H], lens [B] int32; out [B][T][2H], zeros at t >= lens[b].  H must be 256. */
+/* packed[d][k/4][n][k%4] = whh[d][n][k] for nn.GRU's weight_hh of both directions, whh [2][3H][H]. */
+int ac_gru_pack_whh(const float* whh, float* packed, int hidden, void* stream);
 int ac_gru_layer(const float* gx, const float* whhT, const float* bhh, const int* lens, float* out, int B,
                  int T, int hidden, void* stream);
 /* mean_with_lens (model_util.py:41-63); add_max != 0 adds max_with_lens (cnn_encoder.py:451-453). */

@@ -228,6 +228,8 @@ def test_gru_layer_train_forward_backward(lib):
     whh_d = whh.to(dev)
     assert lib.ac_transpose(P(whh_d), P(whhT), 2, 3 * H, H, S()) == 0
     assert torch.equal(whhT.cpu(), whh.transpose(1, 2).contiguous())
+    assert lib.ac_gru_pack_whh(P(whh_d), P(whhT), H, S()) == 0          # [2][H/4][3H][4]
+    assert torch.equal(whhT.cpu().view(2, H // 4, 3 * H, 4), whh.view(2, 3 * H, H // 4, 4).permute(0, 2, 1, 3))
     out = torch.empty(B, T, 2 * H, device=dev)
     save = torch.empty(B, T, 2, 4 * H, device=dev)
     lens_d = torch.tensor(lens, dtype=torch.int32, device=dev)
