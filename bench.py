@@ -180,6 +180,9 @@ def main():
     ap.add_argument("--effb2-batch", type=int, default=128, help="clips per GPU per step in the EffB2 measurement")
     ap.add_argument("--beam", type=int, default=3, help="beam size of the EffB2 measurement (0: greedy)")
     ap.add_argument("--no-effb2", action="store_true", help="skip the secondary EffB2-Trm measurement")
+    ap.add_argument("--clotho-shape", action="store_true",
+                    help="ragged Clotho-shape set (SURVEY 8(d)): durations ~ U[15 s, 30 s] zero-padded to the batch "
+                         "maximum, wav_len = true lengths, clips dealt to the ranks by total duration")
     ap.add_argument("--train-batch", type=int, default=32, help="clips per GPU per training step")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement")
     args = ap.parse_args()
@@ -222,8 +225,25 @@ def main():
 
     L = int(args.seconds * 32000)
     B = args.batch
-    wav = torch.from_numpy(P.synthetic_wav(B, L, seed=P.BASE_SEED + rank)).to(dev)  # resident in HBM
-    wav_len = [L] * B
+    audio_seconds = args.seconds * B
+    if args.clotho_shape:
+        # the same global set on every rank (seeded), dealt out by total duration: encoder cost ~ duration
+        import numpy as np
+        from audiocaption_amd.sharding import shard_by_duration
+        rng = np.random.default_rng(P.BASE_SEED)
+        dur = rng.uniform(15.0, 30.0, size=world * B)
+        mine = shard_by_duration(dur.tolist(), world)[rank]
+        B = len(mine)
+        wav_len = [int(dur[i] * 32000) for i in mine]
+        L = max(wav_len)
+        full = P.synthetic_wav(B, L, seed=P.BASE_SEED + rank)
+        for j, n in enumerate(wav_len):
+            full[j, n:] = 0.0
+        wav = torch.from_numpy(full).to(dev)
+        audio_seconds = float(sum(wav_len)) / 32000.0
+    else:
+        wav = torch.from_numpy(P.synthetic_wav(B, L, seed=P.BASE_SEED + rank)).to(dev)  # resident in HBM
+        wav_len = [L] * B
     inp = {"mode": "inference", "wav": wav, "wav_len": wav_len, "specaug": False, "sample_method": "greedy",
            "max_length": args.max_length}
 
@@ -357,6 +377,9 @@ def main():
             "config": {"workload": f"Cnn14Rnn-Trm greedy decode, batch {B} per GPU, {args.seconds:g} s @ 32 kHz "
                                    f"synthetic clips, max_length {args.max_length}, vocab {vocab} (BASELINE configs[1])",
                        "global_batch": world * B, "decode_steps_executed": args.max_length,
+                       "input_set": ("Clotho-shape: ragged 15-30 s clips, zero-padded, duration-balanced sharding; "
+                                     "%.0f s of audio per step on rank 0" % audio_seconds) if args.clotho_shape else
+                                    "fixed-length",
                        "decode_steps_reference_would_run": ref_steps, "conv_algo": algo,
                        "sharding": f"clips sharded over {world} rank(s), no data-path collective",
                        "schedule": "blocking model() per step" if args.sync_steps else
