@@ -142,9 +142,15 @@ def bench_effb2(args, world, rank, dev, dist, steps, warmup):
     torch.cuda.synchronize()
     enc_ms = e0.elapsed_time(e1) / 3
     alg_bytes = 100e6 * (args.seconds / 10.0) * B
+    traffic = None
+    tpath = os.path.join(REPO, "profiles", "r01_traffic_effb2.json")
+    if os.path.exists(tpath) and args.seconds == 10.0:
+        with open(tpath) as f:   # PMC-measured HBM bytes per clip (collected in separate --pmc passes), scaled to B
+            traffic = json.load(f).get("hbm_bytes_per_clip")
+            traffic = traffic * B if traffic else None
     return {
         "encoder_roofline": {"bound": "hbm", "achieved": alg_bytes / (enc_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                             "frac": alg_bytes / (enc_ms * 1e-3) / 8e12, "traffic": None, "encoder_ms": enc_ms,
+                             "frac": alg_bytes / (enc_ms * 1e-3) / 8e12, "traffic": traffic, "encoder_ms": enc_ms,
                              "note": "algorithmic activation bytes (100 MB per 10 s clip, SURVEY 8(d)) / measured time of "
                                      "log-mel + EfficientNet-B2 for the whole batch"},
         "metric": "clips/sec encode+decode, EffB2-Transformer", "value": world * B * steps / elapsed, "unit": "clips/s",
