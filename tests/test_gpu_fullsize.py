@@ -1,0 +1,131 @@
+"""GPU tests at BASELINE.json's FULL sizes (batch 64 x 10 s, 30 s clips, EffB2 batch 128, training batch 32), where the
+CPU oracle is too slow to be the checker: size-independent properties instead - batch-composition invariance and
+permutation equivariance of clip-parallel work, and linearity of the gradient in the batch."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _inp(wav, wav_len, **kw):
+    d = {"mode": "inference", "wav": wav, "wav_len": wav_len, "specaug": False, "sample_method": "greedy", "max_length": 20}
+    d.update(kw)
+    return d
+
+
+def test_bench_size_batch_invariance_and_permutation(hip_model):
+    """BASELINE configs[1]: 64 clips x 10 s.  Clips never interact: the first 4 clips of the 64-batch must give what a
+    4-clip batch gives (that size IS checked against the oracle and the reference fixtures elsewhere), and permuting
+    the clips must permute the outputs."""
+    from audiocaption_amd import procedural as Pr
+    B, L = 64, 320000
+    wav = torch.from_numpy(Pr.synthetic_wav(B, L, seed=77, varied=True)).cuda()
+    lens = [L - 3200 * (i % 7) for i in range(B)]
+    for i, n in enumerate(lens):
+        wav[i, n:] = 0
+    full = hip_model(_inp(wav, lens))
+    assert full["attn_emb"].shape == (B, 31, 512) and full["seq"].shape == (B, 20)
+    sub = hip_model(_inp(wav[:4].contiguous(), lens[:4]))
+    assert float((full["attn_emb"][:4] - sub["attn_emb"]).abs().max()) < 1e-5
+    assert torch.equal(full["seq"][:4], sub["seq"])
+    assert float((full["logit"][:4] - sub["logit"]).abs().max()) < 1e-4
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(1))
+    pout = hip_model(_inp(wav[perm.cuda()].contiguous(), [lens[i] for i in perm.tolist()]))
+    assert float((pout["attn_emb"] - full["attn_emb"][perm.cuda()]).abs().max()) < 1e-5
+    assert torch.equal(pout["seq"], full["seq"][perm])
+    # checksum of checksums: the batch total equals the sum of the two halves' totals
+    a = hip_model(_inp(wav[:32].contiguous(), lens[:32]))["attn_emb"].double().sum()
+    b = hip_model(_inp(wav[32:].contiguous(), lens[32:]))["attn_emb"].double().sum()
+    tot = full["attn_emb"].double().sum()
+    assert abs(float(a + b - tot)) < 1e-6 * float(full["attn_emb"].double().abs().sum())
+
+
+def test_thirty_second_clips_and_beam(hip_model):
+    """Longest supported clips (30 s: 93 frames, the Clotho maximum) with ragged lengths: batch vs one-by-one."""
+    from audiocaption_amd import procedural as Pr
+    B, L = 6, 960000
+    wav = torch.from_numpy(Pr.synthetic_wav(B, L, seed=5, varied=True)).cuda()
+    lens = [960000, 700000, 480001, 960000, 333333, 900000]
+    for i, n in enumerate(lens):
+        wav[i, n:] = 0
+    out = hip_model(_inp(wav, lens, sample_method="beam", beam_size=4))
+    assert out["attn_emb"].shape[0] == B and out["attn_emb_len"].tolist() == [(n // 320 + 1) // 32 for n in lens]
+    for i in (0, 2, 4):
+        one = hip_model(_inp(wav[i:i + 1].contiguous(), [lens[i]], sample_method="beam", beam_size=4))
+        t = one["attn_emb"].shape[1]
+        assert float((one["attn_emb"][0] - out["attn_emb"][i, :t]).abs().max()) < 1e-5
+        assert torch.equal(one["seq"][0], out["seq"][i])
+
+
+def test_effb2_full_batch_permutation(state_effb2):
+    """BASELINE configs[2]: EffB2-Trm, 128 clips x 10 s @ 16 kHz.  (The log-mel floor depends on the loudest clip of the
+    batch by design, so the invariance that holds is permutation equivariance.)"""
+    import audiocaption_amd as A
+    from audiocaption_amd import procedural as Pr
+    model = A.init_model_from_config(A.effb2_trm_config(4981), print_fn=lambda s: None)
+    model.load_state_dict(state_effb2, strict=True)
+    model = model.eval().cuda()
+    B, L = 128, 160000
+    wav = torch.from_numpy(Pr.synthetic_wav(B, L, seed=9, varied=True, sample_rate=16000)).cuda()
+    lens = [L - 1600 * (i % 11) for i in range(B)]
+    out = model(_inp(wav, lens, sample_method="beam", beam_size=3))
+    assert out["attn_emb"].shape == (B, 32, 1408)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(2))
+    pout = model(_inp(wav[perm.cuda()].contiguous(), [lens[i] for i in perm.tolist()], sample_method="beam", beam_size=3))
+    d = float((pout["attn_emb"] - out["attn_emb"][perm.cuda()]).abs().max())
+    assert d < 1e-5 * float(out["attn_emb"].abs().max()) + 1e-6
+    assert torch.equal(pout["seq"], out["seq"][perm])
+
+
+def test_training_gradient_is_linear_in_the_batch(state4981):
+    """BASELINE configs[3] shape (32 clips, 22-token captions), dropout 0, teacher forcing (deterministic): the loss is a
+    mean over tokens, so  count * grad(batch) = count_A * grad(A) + count_B * grad(B)  for a split of the batch."""
+    import audiocaption_amd as A
+    from audiocaption_amd import procedural as Pr
+    from audiocaption_amd.loss import _launch
+    from audiocaption_amd.train import TrainEngine
+    model = A.init_model_from_config(A.cnn14rnn_trm_config(4981), print_fn=lambda s: None)
+    model.load_state_dict(state4981, strict=True)
+    model = model.cuda().train()
+    for m in model.decoder.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if isinstance(m, torch.nn.MultiheadAttention):
+            m.dropout = 0.0
+    model.encoder.rnn.network.dropout = 0.0
+    model.encoder.cnn.eval()
+    B, L, Tc = 32, 320000, 22
+    wav = torch.from_numpy(Pr.synthetic_wav(B, L, seed=31, varied=True)).cuda()
+    g = torch.Generator().manual_seed(4)
+    cap = torch.randint(4, 4981, (B, Tc), generator=g)
+    cap_len = torch.randint(8, Tc + 1, (B,), generator=g)
+    cap_len[0] = cap_len[16] = Tc
+    cap[:, 0] = 1
+    for i, n in enumerate(cap_len.tolist()):
+        cap[i, n - 1] = 2
+        cap[i, n:] = 0
+    eng = TrainEngine(model)
+
+    def grads(sl):
+        n = sl.stop - sl.start
+        out = eng.forward({"mode": "train", "wav": wav[sl].contiguous(), "wav_len": [L] * n, "specaug": False,
+                           "cap": cap[sl].cuda(), "cap_len": cap_len[sl].numpy(), "ss_ratio": 1})
+        tl = (cap_len[sl] - 1)
+        count = float(tl.sum())
+        logit = out["logit"]
+        dlogit = torch.empty_like(logit)
+        loss, _ = _launch(logit, cap[sl][:, 1:].cuda(), tl.to(device="cuda", dtype=torch.int32), 0.1, 1.0 / count, dlogit,
+                          1.0 / count, None)
+        eng.backward(dlogit)
+        return count, float(loss), eng.flat.grad.double().clone()
+
+    c, loss, gfull = grads(slice(0, B))
+    ca, la, ga = grads(slice(0, 16))
+    cb, lb, gb = grads(slice(16, B))
+    assert c == ca + cb
+    assert abs(c * loss - (ca * la + cb * lb)) < 1e-5 * c * loss
+    comb = (ca * ga + cb * gb) / c
+    err = float((comb - gfull).abs().max()) / float(gfull.abs().max())
+    print(f"gradient linearity: max|diff| / max|grad| = {err:.3e}, loss {loss:.5f}")
+    assert err < 2e-5
