@@ -507,22 +507,55 @@ __global__ __launch_bounds__(256) void beam_logprob_kernel(const float* logit, c
   for (int c = tid; c < V; c += 256) lp[(size_t)r * V + c] = cr + ((row[c] - lse1) * inv_t - lse2);
 }
 
-// per clip: the `beam` largest entries of lp[clip*beam .. +nrows][V] flattened (lowest index wins ties)
+// per clip: the `beam` largest entries of lp[clip*beam .. +nrows][V] flattened (lowest index wins ties).
+// One pass over the scores: every thread keeps its own best TOPK_LOCAL candidates in registers; the workgroup then
+// picks the winners from the 256 x TOPK_LOCAL survivors in LDS (the global top `beam` is contained in them because each
+// thread's list holds its own best `beam`).  beam > TOPK_LOCAL falls back to one full scan per winner.
+constexpr int TOPK_LOCAL = 4;
+__device__ __forceinline__ bool cand_better(float v, int i, float ov, int oi) { return v > ov || (v == ov && i < oi); }
+
 __global__ __launch_bounds__(256) void beam_topk_kernel(const float* lp, int beam, int nrows, int V,
                                                         float* top_val, int* top_idx) {
   __shared__ float sv[4];
   __shared__ int si[4];
   __shared__ int chosen[64];
+  __shared__ float cv[256 * TOPK_LOCAL];
+  __shared__ int ci[256 * TOPK_LOCAL];
   const int clip = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* base = lp + (size_t)clip * beam * V;
   const int n = nrows * V;
+  const bool local = beam <= TOPK_LOCAL;
+  if (local) {
+    float bv[TOPK_LOCAL];
+    int bi[TOPK_LOCAL];
+#pragma unroll
+    for (int j = 0; j < TOPK_LOCAL; ++j) { bv[j] = -INFINITY; bi[j] = 0x7fffffff; }
+    for (int c = tid; c < n; c += 256) {
+      float v = base[c];
+      int idx = c;
+      if (cand_better(v, idx, bv[TOPK_LOCAL - 1], bi[TOPK_LOCAL - 1])) {
+#pragma unroll
+        for (int j = 0; j < TOPK_LOCAL; ++j)   // insertion into the sorted list (best first)
+          if (cand_better(v, idx, bv[j], bi[j])) {
+            const float tv = bv[j]; const int ti = bi[j];
+            bv[j] = v; bi[j] = idx; v = tv; idx = ti;
+          }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TOPK_LOCAL; ++j) { cv[tid * TOPK_LOCAL + j] = bv[j]; ci[tid * TOPK_LOCAL + j] = bi[j]; }
+    __syncthreads();
+  }
+  const int ncand = local ? 256 * TOPK_LOCAL : n;
   for (int k = 0; k < beam; ++k) {
     float v = -INFINITY;
     int idx = 0x7fffffff;
-    for (int c = tid; c < n; c += 256) {
+    for (int c = tid; c < ncand; c += 256) {
+      const float x = local ? cv[c] : base[c];
+      const int xi = local ? ci[c] : c;
       bool skip = false;
-      for (int j = 0; j < k; ++j) skip |= (chosen[j] == c);
-      if (!skip) argmax_merge(v, idx, base[c], c);
+      for (int j = 0; j < k; ++j) skip |= (chosen[j] == xi);
+      if (!skip) argmax_merge(v, idx, x, xi);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
