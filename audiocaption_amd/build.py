@@ -37,13 +37,32 @@ def _digest():
     return h.hexdigest()
 
 
-def build(force=False, verbose=False):
-    """Compile every .hip source for gfx950 and link the shared library.  Returns its path."""
-    digest = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(STAMP):
+def _up_to_date(digest):
+    if os.path.exists(LIB) and os.path.exists(STAMP):
         with open(STAMP) as f:
-            if f.read().strip() == digest:
+            return f.read().strip() == digest
+    return False
+
+
+def build(force=False, verbose=False):
+    """Compile every .hip source for gfx950 and link the shared library.  Returns its path.  Safe to call from the N
+    ranks of a torchrun launch at once: one of them compiles under a file lock, the others wait and reuse the result."""
+    import fcntl
+    digest = _digest()
+    if not force and _up_to_date(digest):
+        return LIB
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    with open(os.path.join(HERE, "build", ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and _up_to_date(digest):
                 return LIB
+            return _compile(digest, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _compile(digest, verbose):
     hipcc = _hipcc()
     objs = []
     procs = []
@@ -61,10 +80,12 @@ def build(force=False, verbose=False):
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
         if verbose and out.strip():
             print(out)
-    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs
+    tmp_lib = LIB + ".tmp"   # link aside, then rename: a process that already loaded the old library keeps a valid file
+    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", tmp_lib] + objs
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout.decode())
+    os.replace(tmp_lib, LIB)
     with open(STAMP, "w") as f:
         f.write(digest)
     return LIB
