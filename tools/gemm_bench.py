@@ -38,3 +38,8 @@ run(32, 4981, 256)
 run(7392, 256, 256, "dx"); run(7392, 1024, 256, "dx"); run(7392, 256, 1024, "dx"); run(20832, 256, 512, "dx")
 run(256, 256, 7392, "dw", 8); run(1024, 256, 7392, "dw", 8); run(768, 256, 7392, "dw", 8); run(512, 256, 20832, "dw", 16)
 run(1536, 2048, 992, "dw", 3)
+
+print("x W^T shapes (EffB2 late stages, training row space):")
+for M, N, K in ((32256, 528, 88), (32256, 720, 120), (32256, 120, 720), (8192, 1248, 208), (8192, 208, 1248), (8192, 2112, 352),
+                (8192, 352, 2112), (8192, 1408, 352), (7392, 768, 256), (7392, 1024, 256), (7392, 256, 1024), (20832, 512, 256)):
+    run(M, N, K)
