@@ -921,14 +921,36 @@ __global__ __launch_bounds__(768) void gru_bwd_kernel(const float* dout, const f
 // Optimiser (run.py:122-126, torch.optim.Adam with weight_decay = L2 added to the gradient):
 //   sumsq -> total norm -> clip coefficient min(1, max_norm / (norm + 1e-6)) -> Adam, all on flat buffers.
 // =========================================================================================================
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, long n, float* out) {
+// Deterministic: every workgroup leaves its partial in norm_state[AC_NORM_PARTIALS ..]; the LAST one to finish (ticket
+// counter behind them) adds them up in index order.  An atomicAdd per workgroup would make the norm - and through the
+// clip coefficient every parameter - differ in the last bit between the ranks of a data-parallel job.
+constexpr int AC_NORM_PARTIALS = 4, AC_NORM_MAXBLOCKS = 1024, AC_NORM_TICKET = AC_NORM_PARTIALS + AC_NORM_MAXBLOCKS;
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, long n, float* st) {
   __shared__ float red[4];
+  __shared__ bool last;
   float a = 0.f;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) a = fmaf(g[i], g[i], a);
   a = wave_sum(a);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+  if (threadIdx.x == 0) {
+    st[AC_NORM_PARTIALS + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    __threadfence();
+    const unsigned t = atomicAdd((unsigned*)(st + AC_NORM_TICKET), 1u);
+    last = t == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  float s = 0.f;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) s += ((volatile float*)st)[AC_NORM_PARTIALS + i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    st[0] += (red[0] + red[1]) + (red[2] + red[3]);
+    *(unsigned*)(st + AC_NORM_TICKET) = 0u;   // ready for the next call
+  }
 }
 // norm_state[0] = sum of squares in, [1] = total norm out, [2] = clip coefficient out, [3] = 1 when the gradient is
 // not finite: the update is then skipped on the device, the reference's `if not torch.isnan(loss)` (run.py:123)

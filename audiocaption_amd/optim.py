@@ -14,6 +14,9 @@ from . import _lib
 from ._lib import check, stream
 
 
+NORM_STATE_FLOATS = 1032   # include/audiocaption_hip.h: 4 results + the scratch of the deterministic sum of squares
+
+
 def _flat_span(tensors):
     """(storage_tensor_ptr, first_byte, n_floats) if the tensors are fp32 views of ONE storage, else None."""
     if not tensors:
@@ -51,7 +54,7 @@ def clip_grad_norm_(parameters, max_norm, grad_div=1.0, scale_now=True):
     if not grads:
         raise ValueError("no gradients to clip")
     dev = grads[0].device
-    state = torch.zeros(4, device=dev, dtype=torch.float32)
+    state = torch.zeros(NORM_STATE_FLOATS, device=dev, dtype=torch.float32)
     s = stream()
     span = _flat_span(grads)
     if span is not None:

@@ -279,7 +279,9 @@ int ac_gru_layer_bwd(const float* dout, const float* out, const float* save, con
  * norm_state[0] += sum g^2;  ac_clip_coef: [1] = sqrt([0]) / grad_div (total norm of the averaged gradient),
  * [2] = min(1, max_norm / (norm + 1e-6)) / grad_div (max_norm <= 0: no clipping);  ac_scale_by_coef: x *= [2];
  * ac_adam_step: g' = g * [2] (norm_state may be NULL) + wd * p, then Adam's update for 1-based `step`. */
-/* norm_state has 4 floats; [3] is set to 1 by ac_clip_coef when the gradient norm is not finite, and ac_adam_step
+/* norm_state has AC_NORM_STATE_FLOATS = 1032 floats, zero-initialised: [0..3] as described here, the rest is scratch of
+ * ac_grad_sumsq (per-workgroup partials summed in a fixed order, so that every rank of a data-parallel job gets the
+ * same bits); [3] is set to 1 by ac_clip_coef when the gradient norm is not finite, and ac_adam_step
  * then leaves parameters and moments untouched (the reference's NaN-loss skip, run.py:123, without a host sync).
  * ac_swa_update: avg += (p - avg) / (n_averaged + 1) (AveragedModel.update_parameters, train_util.py:233-253;
  * n_averaged = 0 copies). */
