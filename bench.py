@@ -200,12 +200,20 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # one rank per GPU over RCCL ("nccl").  AUDIOCAPTION_BENCH_BACKEND=gloo lets the multi-process flow be exercised
+        # on a single-GPU box (ranks share the device; RCCL refuses that)
+        backend = os.environ.get("AUDIOCAPTION_BENCH_BACKEND", "nccl")
+        dev_index = local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     else:
         dist = None
+        dev_index = 0
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", dev_index)
 
     import audiocaption_amd as A
     from audiocaption_amd import build, kernels as K, procedural as P
