@@ -272,7 +272,9 @@ int ac_pointwise_conv(const float* x, const float* w, const float* bias, float* 
   if (N <= 32) hipLaunchKernelGGL(pointwise_kernel<1>, grid, dim3(256), 0, s, p);
   else if (N <= 64) hipLaunchKernelGGL(pointwise_kernel<2>, grid, dim3(256), 0, s, p);
   else if (N <= 96) hipLaunchKernelGGL(pointwise_kernel<3>, grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL(pointwise_kernel<4>, grid, dim3(256), 0, s, p);
+  else if (N <= 128) hipLaunchKernelGGL(pointwise_kernel<4>, grid, dim3(256), 0, s, p);
+  else if (N <= 160 || (N > 256 && N <= 320)) hipLaunchKernelGGL(pointwise_kernel<5>, grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(pointwise_kernel<6>, grid, dim3(256), 0, s, p);
   return ac_check_launch();
 }
 
