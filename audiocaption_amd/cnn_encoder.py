@@ -200,3 +200,8 @@ class Cnn14Encoder(nn.Module):
             pooled = K.mean_with_lens(attn_emb, lens, add_max=True)
             out["fc_emb"] = K.linear(pooled, self.fc1.weight.float(), self.fc1.bias.float(), relu=True)
         return out
+
+
+# The reference keeps its EfficientNet-B2 encoder in the same module (cnn_encoder.py:770-839); re-export ours so that
+# ``captioning.models.cnn_encoder.EfficientNetB2`` resolves after ``compat.install()``.
+from .effnet_encoder import EfficientNetB2  # noqa: E402,F401
