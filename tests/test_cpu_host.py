@@ -180,3 +180,17 @@ def test_mel_filterbank_properties():
     assert int(nz.sum(1).max()) <= 2            # triangular: a bin feeds at most 2 filters
     freqs = torch.linspace(0, 16000, 513)
     assert float(fb[freqs < 50.0].abs().max()) == 0 and float(fb[freqs > 14000.0].abs().max()) == 0
+
+
+def test_product_code_never_imports_the_oracle():
+    """oracle/ is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it."""
+    pat = re.compile(r"^\s*(from\s+oracle\b|import\s+oracle\b|from\s+\.+oracle\b)", re.M)
+    offenders = []
+    for root in ("audiocaption_amd", "tools"):
+        for dirpath, _, files in os.walk(os.path.join(REPO, root)):
+            for f in files:
+                if f.endswith(".py") and pat.search(open(os.path.join(dirpath, f)).read()):
+                    offenders.append(os.path.join(dirpath, f))
+    assert not offenders, offenders
+    bench = open(os.path.join(REPO, "bench.py")).read()
+    assert len(pat.findall(bench)) == 1 and "cpu_baseline" in bench[bench.index("from oracle"):][:3000]
