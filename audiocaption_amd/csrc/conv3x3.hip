@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16x3_kernel(ConvParams p) {
 // per 32-channel chunk = per 216 MFMAs of a wave), half the LDS fragment reads.
 // ------------------------------------------------------------------------------------------------
 template <int BN, int MODE>
-__global__ __launch_bounds__(256, 1) void conv3x3_bf16x3_gw_kernel(ConvParams p) {
+__global__ __launch_bounds__(256, 3) void conv3x3_bf16x3_gw_kernel(ConvParams p) {
   constexpr int NTW = BN / 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm_raw[];
   const int tid = threadIdx.x;
@@ -516,18 +516,38 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16x3_gw_kernel(ConvParams p)
 #pragma unroll
           for (int pl = 0; pl < 2; ++pl) w[ks][n][pl] = wf[((size_t)it * 2 + ks) * ks_stride + (n * 2 + pl) * 64];
     };
-    auto stage_patch = [&](int c) {
-      for (int idx = tid; idx < NPIX * 8; idx += 256) {
+    // Patch staging descriptors, computed ONCE per workgroup: which halo pixel / channel quad each of this thread's
+    // (up to GW_MAXIT) items is, as a global element offset and an LDS offset.  The per-chunk staging loop is then a
+    // load, the hi/lo split and two LDS stores per item - the divisions and bounds tests used to be redone for every
+    // 32-channel chunk and made the kernel's VALU time comparable to its MFMA time.
+    constexpr int GW_MAXIT = 9;
+    constexpr unsigned GW_NONE = 0xffffffffu, GW_OOB = 0x80000000u;
+    unsigned goff[GW_MAXIT], loff[GW_MAXIT];
+#pragma unroll
+    for (int j = 0; j < GW_MAXIT; ++j) {
+      const int idx = tid + j * 256;
+      loff[j] = GW_NONE;
+      goff[j] = 0;
+      if (idx < NPIX * 8) {
         const int pix = idx >> 3, c4 = idx & 7;
         const int pr = pix / PW, pc = pix - pr * PW;
         const int gr = row0 - 1 + pr, gc = col0 - 1 + pc;
+        const bool ok = gr >= 0 && gr < p.rows_total && gc >= 0 && gc < p.W;
+        goff[j] = ok ? (unsigned)(((size_t)gr * p.W + gc) * p.Cin + c4 * 4) : 0u;
+        loff[j] = (unsigned)(pr * PITCH + pc * BROW + c4 * 4) | (ok ? 0u : GW_OOB);
+      }
+    }
+    auto stage_patch = [&](int c) {
+#pragma unroll
+      for (int j = 0; j < GW_MAXIT; ++j) {
+        if (loff[j] == GW_NONE) continue;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (gr >= 0 && gr < p.rows_total && gc >= 0 && gc < p.W)
-          v = *(const f32x4*)(p.in + ((size_t)gr * p.W + gc) * p.Cin + c * 32 + c4 * 4);
+        if (!(loff[j] & GW_OOB)) v = *(const f32x4*)(p.in + (size_t)goff[j] + c * 32);
         u32x2 hi, lo;
         split_bf16x4(v, hi, lo);
-        *(u32x2*)(sAh + pr * PITCH + pc * BROW + c4 * 4) = hi;
-        *(u32x2*)(sAl + pr * PITCH + pc * BROW + c4 * 4) = lo;
+        const unsigned lo_off = loff[j] & 0x7fffffffu;
+        *(u32x2*)(sAh + lo_off) = hi;
+        *(u32x2*)(sAl + lo_off) = lo;
       }
     };
     const int total = nchunk * 9;
