@@ -101,13 +101,12 @@ __device__ __forceinline__ void stockham_pass(const float2* in, float2* out, con
 }
 
 template <int N>
-__global__ __launch_bounds__(256) void logmel_kernel(LogmelParams p) {
+__global__ __launch_bounds__(256, 4) void logmel_kernel(LogmelParams p) {
   constexpr int M = N / 2;
   constexpr int R0 = (N == 1024) ? 8 : 4;  // first radix; the remaining two passes are radix 8
   constexpr int WAVES = 4;
   __shared__ float2 s_tw[N];
   __shared__ float2 s_buf[WAVES][2][M];
-  __shared__ float s_pow[WAVES][M + 8];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -117,7 +116,10 @@ __global__ __launch_bounds__(256) void logmel_kernel(LogmelParams p) {
 
   float2* bufA = s_buf[wave][0];
   float2* bufB = s_buf[wave][1];
-  float* pw = s_pow[wave];
+  float* pw = (float*)bufB;   // the power spectrum (M + 1 floats) reuses the ping-pong half that is free after the last pass
+  // A frame belongs to ONE wave: its passes only need the wave's own LDS writes to have landed (the lanes run in lock
+  // step), not a workgroup barrier - the four waves of a workgroup drift apart and hide each other's latencies.
+#define WAVE_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
   const long total = (long)p.B * p.rows_per_clip;
 
   for (long slot0 = (long)blockIdx.x * WAVES; slot0 < total; slot0 += (long)gridDim.x * WAVES) {
@@ -142,11 +144,11 @@ __global__ __launch_bounds__(256) void logmel_kernel(LogmelParams p) {
       }
       stockham_store<M, R0, 1, N>(u, bufA, s_tw, lane);
     }
-    __syncthreads();
+    WAVE_LDS_SYNC();
     if (active) stockham_pass<M, 8, R0, N>(bufA, bufB, s_tw, lane);
-    __syncthreads();
+    WAVE_LDS_SYNC();
     if (active) stockham_pass<M, 8, R0 * 8, N>(bufB, bufA, s_tw, lane);
-    __syncthreads();
+    WAVE_LDS_SYNC();
     if (active) {
       // ---- unpack the packed-real transform to bins 0..M and take the power ----
       for (int k = lane; k <= M; k += 64) {
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(LogmelParams p) {
         pw[k] = xk.x * xk.x + xk.y * xk.y;
       }
     }
-    __syncthreads();
+    WAVE_LDS_SYNC();
     if (in_range) {
       float v = 0.f;
       if (active) {
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(LogmelParams p) {
       }
       p.out[b * p.stride_b + t * p.stride_t + lane * p.stride_m] = v;
     }
-    __syncthreads();
+    WAVE_LDS_SYNC();
   }
 }
 
