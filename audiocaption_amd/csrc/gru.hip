@@ -27,22 +27,57 @@ constexpr int H = 256;
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// The 786 KB recurrent matrix cannot stay on a CU, and re-streaming all of it from L2 every step runs at the CU's
+// L1 fill rate (~50 B/clk: 6.7 us per step).  So the part that fits stays resident for the whole sequence: the first
+// GRU_KREG k of every column in registers (24 float4 per thread), the next GRU_KLDS k in LDS (144 KB); only the last
+// 44 % is streamed per step.  The accumulation order (k ascending) is unchanged.
+constexpr int GRU_KREG = 96, GRU_KLDS = 48;
 __global__ __launch_bounds__(768) void gru_layer_kernel(GruParams p) {
   __shared__ __attribute__((aligned(16))) float sh[H];
   __shared__ float sg[3 * H];
+  extern __shared__ __attribute__((aligned(16))) float swl[];   // [GRU_KLDS / 4][3H][4]
   const int n = threadIdx.x;
   const int b = blockIdx.x >> 1, dir = blockIdx.x & 1;
   int len = p.lens[b];
   len = len < 0 ? 0 : (len > p.T ? p.T : len);
   const float* W = p.whhT + (size_t)dir * H * 3 * H + (size_t)n * 4;
   const float bias = p.bhh[dir * 3 * H + n];
+  float4 wreg[GRU_KREG / 4];
+  if (len > 0) {
+#pragma unroll
+    for (int q = 0; q < GRU_KREG / 4; ++q) wreg[q] = *(const float4*)(W + (size_t)q * 3 * H * 4);
+#pragma unroll
+    for (int q = 0; q < GRU_KLDS / 4; ++q)
+      *(float4*)(swl + ((size_t)q * 3 * H + n) * 4) = *(const float4*)(W + (size_t)(GRU_KREG / 4 + q) * 3 * H * 4);
+  }
   if (n < H) sh[n] = 0.f;
   __syncthreads();
   for (int step = 0; step < len; ++step) {
     const int t = dir ? (len - 1 - step) : step;
+    // the input-side gate pre-activations of this step are requested before the matrix-vector product
+    const float* gxp = p.gx + (((size_t)b * p.T + t) * 2 + dir) * 3 * H;
+    float gr = 0.f, gz = 0.f, gn = 0.f;
+    if (n < H) { gr = gxp[n]; gz = gxp[H + n]; gn = gxp[2 * H + n]; }
     float acc = bias;
-#pragma unroll 8
-    for (int k = 0; k < H; k += 4) {
+#pragma unroll
+    for (int q = 0; q < GRU_KREG / 4; ++q) {
+      const float4 hv = *(const float4*)(sh + 4 * q);
+      acc = fmaf(wreg[q].x, hv.x, acc);
+      acc = fmaf(wreg[q].y, hv.y, acc);
+      acc = fmaf(wreg[q].z, hv.z, acc);
+      acc = fmaf(wreg[q].w, hv.w, acc);
+    }
+#pragma unroll
+    for (int q = 0; q < GRU_KLDS / 4; ++q) {
+      const float4 hv = *(const float4*)(sh + GRU_KREG + 4 * q);
+      const float4 wv = *(const float4*)(swl + ((size_t)q * 3 * H + n) * 4);
+      acc = fmaf(wv.x, hv.x, acc);
+      acc = fmaf(wv.y, hv.y, acc);
+      acc = fmaf(wv.z, hv.z, acc);
+      acc = fmaf(wv.w, hv.w, acc);
+    }
+#pragma unroll 7
+    for (int k = GRU_KREG + GRU_KLDS; k < H; k += 4) {
       const float4 hv = *(const float4*)(sh + k);
       const float4 wv = *(const float4*)(W + (size_t)(k >> 2) * 3 * H * 4);   // k..k+3 of this thread's column
       acc = fmaf(wv.x, hv.x, acc);
@@ -53,10 +88,9 @@ __global__ __launch_bounds__(768) void gru_layer_kernel(GruParams p) {
     sg[n] = acc;
     __syncthreads();
     if (n < H) {
-      const float* gxp = p.gx + (((size_t)b * p.T + t) * 2 + dir) * 3 * H;
-      const float r = sigmoidf_(gxp[n] + sg[n]);
-      const float z = sigmoidf_(gxp[H + n] + sg[H + n]);
-      const float c = tanhf(gxp[2 * H + n] + r * sg[2 * H + n]);
+      const float r = sigmoidf_(gr + sg[n]);
+      const float z = sigmoidf_(gz + sg[H + n]);
+      const float c = tanhf(gn + r * sg[2 * H + n]);
       const float hn = (1.0f - z) * c + z * sh[n];
       sh[n] = hn;
       p.out[((size_t)b * p.T + t) * 2 * H + dir * H + n] = hn;
@@ -116,7 +150,14 @@ extern "C" int ac_gru_layer(const float* gx, const float* whhT, const float* bhh
   if (!gx || !whhT || !bhh || !lens || !out || B <= 0 || T <= 0 || hidden != H) return AC_ERR_ARG;
   GruParams p;
   p.gx = gx; p.whhT = whhT; p.bhh = bhh; p.lens = lens; p.out = out; p.B = B; p.T = T;
-  hipLaunchKernelGGL(gru_layer_kernel, dim3(2 * B), dim3(768), 0, (hipStream_t)stream, p);
+  const size_t lds = (size_t)GRU_KLDS * 3 * H * sizeof(float);
+  static bool allowed = false;
+  if (!allowed) {
+    if (hipFuncSetAttribute((const void*)gru_layer_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return AC_ERR_LAUNCH;
+    allowed = true;
+  }
+  hipLaunchKernelGGL(gru_layer_kernel, dim3(2 * B), dim3(768), lds, (hipStream_t)stream, p);
   return ac_check_launch();
 }
 

@@ -812,25 +812,58 @@ __global__ void sum_scale_kernel(const float* x, long n, float scale, float* out
 constexpr int H = 256;
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Same residency scheme as csrc/gru.hip's inference kernel (the first 96 k of every column in registers, the next 48 k
+// in LDS, the rest streamed per step) and the same k-ascending accumulation order: bit-identical outputs.
+constexpr int GRU_KREG = 96, GRU_KLDS = 48;
 __global__ __launch_bounds__(768) void gru_train_fwd_kernel(const float* gx, const float* whhT, const float* bhh,
                                                             const int* lens, float* out, float* save, int T) {
   __shared__ __attribute__((aligned(16))) float sh[H];
   __shared__ float sg[3 * H];
+  extern __shared__ __attribute__((aligned(16))) float swl[];   // [GRU_KLDS / 4][3H][4]
   const int n = threadIdx.x;
   const int b = blockIdx.x >> 1, dir = blockIdx.x & 1;
   int len = lens[b];
   len = len < 0 ? 0 : (len > T ? T : len);
   const float* W = whhT + (size_t)dir * H * 3 * H + (size_t)n * 4;
   const float bias = bhh[dir * 3 * H + n];
+  float4 wreg[GRU_KREG / 4];
+  if (len > 0) {
+#pragma unroll
+    for (int q = 0; q < GRU_KREG / 4; ++q) wreg[q] = *(const float4*)(W + (size_t)q * 3 * H * 4);
+#pragma unroll
+    for (int q = 0; q < GRU_KLDS / 4; ++q)
+      *(float4*)(swl + ((size_t)q * 3 * H + n) * 4) = *(const float4*)(W + (size_t)(GRU_KREG / 4 + q) * 3 * H * 4);
+  }
   if (n < H) sh[n] = 0.f;
   __syncthreads();
   for (int step = 0; step < len; ++step) {
     const int t = dir ? (len - 1 - step) : step;
+    const size_t cell = ((size_t)b * T + t) * 2 + dir;
+    const float* gxp = gx + cell * 3 * H;
+    float gr = 0.f, gz = 0.f, gn = 0.f;
+    if (n < H) { gr = gxp[n]; gz = gxp[H + n]; gn = gxp[2 * H + n]; }
     float acc = bias;
-#pragma unroll 8
-    for (int k = 0; k < H; k += 4) {
+#pragma unroll
+    for (int q = 0; q < GRU_KREG / 4; ++q) {
+      const float4 hv = *(const float4*)(sh + 4 * q);
+      acc = fmaf(wreg[q].x, hv.x, acc);
+      acc = fmaf(wreg[q].y, hv.y, acc);
+      acc = fmaf(wreg[q].z, hv.z, acc);
+      acc = fmaf(wreg[q].w, hv.w, acc);
+    }
+#pragma unroll
+    for (int q = 0; q < GRU_KLDS / 4; ++q) {
+      const float4 hv = *(const float4*)(sh + GRU_KREG + 4 * q);
+      const float4 wv = *(const float4*)(swl + ((size_t)q * 3 * H + n) * 4);
+      acc = fmaf(wv.x, hv.x, acc);
+      acc = fmaf(wv.y, hv.y, acc);
+      acc = fmaf(wv.z, hv.z, acc);
+      acc = fmaf(wv.w, hv.w, acc);
+    }
+#pragma unroll 7
+    for (int k = GRU_KREG + GRU_KLDS; k < H; k += 4) {
       const float4 hv = *(const float4*)(sh + k);
-      const float4 wv = *(const float4*)(W + (size_t)(k >> 2) * 3 * H * 4);   // k..k+3 of this thread's column
+      const float4 wv = *(const float4*)(W + (size_t)(k >> 2) * 3 * H * 4);
       acc = fmaf(wv.x, hv.x, acc);
       acc = fmaf(wv.y, hv.y, acc);
       acc = fmaf(wv.z, hv.z, acc);
@@ -839,12 +872,10 @@ __global__ __launch_bounds__(768) void gru_train_fwd_kernel(const float* gx, con
     sg[n] = acc;
     __syncthreads();
     if (n < H) {
-      const size_t cell = ((size_t)b * T + t) * 2 + dir;
-      const float* gxp = gx + cell * 3 * H;
-      const float r = sigmoidf_(gxp[n] + sg[n]);
-      const float z = sigmoidf_(gxp[H + n] + sg[H + n]);
+      const float r = sigmoidf_(gr + sg[n]);
+      const float z = sigmoidf_(gz + sg[H + n]);
       const float ghn = sg[2 * H + n];
-      const float c = tanhf(gxp[2 * H + n] + r * ghn);
+      const float c = tanhf(gn + r * ghn);
       const float hn = (1.0f - z) * c + z * sh[n];
       sh[n] = hn;
       out[((size_t)b * T + t) * 2 * H + dir * H + n] = hn;
@@ -1211,7 +1242,14 @@ int ac_label_smoothing_loss(const float* logit, const long long* tgt, long tgt_l
 int ac_gru_layer_train(const float* gx, const float* whhT, const float* bhh, const int* lens, float* out, float* save,
                        int B, int T, int hidden, void* stream) {
   if (!gx || !whhT || !bhh || !lens || !out || !save || B <= 0 || T <= 0 || hidden != H) return AC_ERR_ARG;
-  hipLaunchKernelGGL(gru_train_fwd_kernel, dim3(2 * B), dim3(768), 0, (hipStream_t)stream, gx, whhT, bhh, lens, out, save, T);
+  const size_t lds = (size_t)GRU_KLDS * 3 * H * sizeof(float);
+  static bool allowed = false;
+  if (!allowed) {
+    if (hipFuncSetAttribute((const void*)gru_train_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return AC_ERR_LAUNCH;
+    allowed = true;
+  }
+  hipLaunchKernelGGL(gru_train_fwd_kernel, dim3(2 * B), dim3(768), lds, (hipStream_t)stream, gx, whhT, bhh, lens, out, save, T);
   return ac_check_launch();
 }
 
