@@ -172,13 +172,17 @@ __global__ __launch_bounds__(256) void gemm_general_kernel(GemmP p) {
 // consecutive rows touches every bank group exactly twice, the minimum), so one 16-byte LDS read gives a lane the 4
 // consecutive k of its row that feed 4 MFMAs (lane l: k offset 4 * (l >> 5) of every 8-k group); global loads and LDS
 // stores are 16 bytes wide as well.  The next K chunk is fetched into registers while the current one is multiplied.
-constexpr int NT_T = 128, NT_K = 32, NT_P = NT_K + 4;
+constexpr int NT_K = 32, NT_P = NT_K + 4;
+// TM = 2: 128x128 tile (2x2 MFMA tiles per wave) for the largest products; TM = 1: 64x64 (one MFMA tile per wave) when
+// 128x128 tiles would leave CUs idle.
+template <int TM>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
+  constexpr int NT_T = 64 * TM, NL = 2 * TM;
   __shared__ __attribute__((aligned(16))) float As[NT_T][NT_P];
   __shared__ __attribute__((aligned(16))) float Bs[NT_T][NT_P];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.x * NT_T, n0 = blockIdx.y * NT_T;
-  const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
+  const int wm = (wave & 1) * 32 * TM, wn = (wave >> 1) * 32 * TM;
   int kbeg = 0, kend = p.K;
   if (p.splitk > 1) {
     const int per = ((p.K + p.splitk - 1) / p.splitk + NT_K - 1) / NT_K * NT_K;
@@ -186,14 +190,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
     kend = min(p.K, kbeg + per);
     if (kbeg >= kend) return;
   }
-  // thread -> 4 float4 of each operand tile per chunk: row = (tid >> 3) + 32 * i, k4 = tid & 7
+  // thread -> NL float4 of each operand tile per chunk: row = (tid >> 3) + 32 * i, k4 = tid & 7
   const int lr = tid >> 3, lk = (tid & 7) * 4;
-  const float* ap[4];
-  const float* bp[4];
-  const float* gp[4];
-  bool aok[4], bok[4];
+  const float* ap[NL];
+  const float* bp[NL];
+  const float* gp[NL];
+  bool aok[NL], bok[NL];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NL; ++i) {
     const int am = m0 + lr + 32 * i, bn = n0 + lr + 32 * i;
     aok[i] = am < p.M;
     bok[i] = bn < p.N;
@@ -201,12 +205,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
     bp[i] = p.B + (long)min(bn, p.N - 1) * p.sbn + lk;
     gp[i] = p.a_scale ? p.a_scale + (long)(min(am, p.M - 1) / p.a_rows) * p.K + lk : nullptr;
   }
-  f32x4 ra[4], rb[4];
+  f32x4 ra[NL], rb[NL];
   auto load = [&](int k0) {
     const bool kok = k0 + lk < kend;                       // K % 4 == 0: a float4 is inside or outside as a whole
     const int kc = kok ? k0 : kbeg;                        // clamped (valid) address, zeroed below
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NL; ++i) {
       f32x4 va = *(const f32x4*)(ap[i] + kc);
       const f32x4 vb = *(const f32x4*)(bp[i] + kc);
       if (gp[i]) va *= *(const f32x4*)(gp[i] + kc);
@@ -215,18 +219,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
       rb[i] = (kok && bok[i]) ? vb : z;
     }
   };
-  f32x16 acc[2][2];
+  f32x16 acc[TM][TM];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TM; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   load(kbeg);
   const int frow = lane & 31, fk = 4 * (lane >> 5);
   for (int k0 = kbeg; k0 < kend; k0 += NT_K) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NL; ++i) {
       *(f32x4*)(&As[lr + 32 * i][lk]) = ra[i];
       *(f32x4*)(&Bs[lr + 32 * i][lk]) = rb[i];
     }
@@ -234,28 +238,28 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
     if (k0 + NT_K < kend) load(k0 + NT_K);
 #pragma unroll
     for (int g8 = 0; g8 < NT_K; g8 += 8) {
-      f32x4 a[2], b[2];
+      f32x4 a[TM], b[TM];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < TM; ++i) {
         a[i] = *(const f32x4*)(&As[wm + 32 * i + frow][g8 + fk]);
         b[i] = *(const f32x4*)(&Bs[wn + 32 * i + frow][g8 + fk]);
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(a[i][q], b[j][q], acc[i][j]);
+          for (int j = 0; j < TM; ++j) acc[i][j] = mfma32(a[i][q], b[j][q], acc[i][j]);
     }
     lds_barrier();
   }
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < TM; ++j) {
     const int n = n0 + wn + 32 * j + (lane & 31);
     if (n >= p.N) continue;
     const float bias = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -1049,12 +1053,16 @@ int ac_gemm(const float* A, long sam, long sak, const float* B, long sbk, long s
   const bool small = p.splitk == 1 && grid.x * grid.y <= 256 && K >= 128;
   const bool kk_ok = sak == 1 && sbk == 1 && K % 4 == 0 && sam % 4 == 0 && sbn % 4 == 0 && ((uintptr_t)A & 15) == 0 &&
                      ((uintptr_t)B & 15) == 0 && (!a_scale || ((uintptr_t)a_scale & 15) == 0);
-  const long nt_tiles = (long)((M + NT_T - 1) / NT_T) * ((N + NT_T - 1) / NT_T) * p.splitk;
+  const long nt_tiles = (long)((M + 127) / 128) * ((N + 127) / 128) * p.splitk;      // 128x128 tiles
+  const long nt_tiles64 = (long)((M + 63) / 64) * ((N + 63) / 64) * p.splitk;
   if (small && !a_scale && sak == 1 && sbk == 1 && K % 32 == 0 && sam % 4 == 0 && sbn % 4 == 0 &&
       ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0)
     hipLaunchKernelGGL(gemm_kk_kernel, dim3((M + KT - 1) / KT, (N + KT - 1) / KT), dim3(256), 0, (hipStream_t)stream, p);
-  else if (kk_ok && N >= 96 && nt_tiles >= 192 && (N + NT_T - 1) / NT_T <= 65535)
-    hipLaunchKernelGGL(gemm_nt_kernel, dim3((M + NT_T - 1) / NT_T, (N + NT_T - 1) / NT_T, p.splitk), dim3(256), 0,
+  else if (kk_ok && N >= 96 && nt_tiles >= 512)
+    hipLaunchKernelGGL(gemm_nt_kernel<2>, dim3((M + 127) / 128, (N + 127) / 128, p.splitk), dim3(256), 0,
+                       (hipStream_t)stream, p);
+  else if (kk_ok && N >= 48 && nt_tiles64 >= 128)
+    hipLaunchKernelGGL(gemm_nt_kernel<1>, dim3((M + 63) / 64, (N + 63) / 64, p.splitk), dim3(256), 0,
                        (hipStream_t)stream, p);
   else
     hipLaunchKernelGGL(gemm_general_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
