@@ -172,10 +172,10 @@ class EfficientNetB2(nn.Module):
     @staticmethod
     def _gemm(x, w, bias, y, M, N, Kd, act=0, beta=0.0, a_scale=None, a_rows=0):
         lib = _lib.load()
-        # two kernels for the same contract (tools/pointwise_bench.py): millions of rows against a small weight matrix
-        # are HBM-bound -> the streaming kernel that reads each activation once; the late stages (<= 32 k rows against
-        # up to 3 MB of weights) -> the LDS-tiled GEMM that shares the weight tile between 64 rows
-        if (N <= 128 and M >= 30000) or N * Kd <= 16384:
+        # two kernels for the same contract (tools/pointwise_bench.py): the full-resolution stages (>= 0.4 M rows against
+        # a few KB of weights) are HBM-bound -> the streaming kernel that reads each activation once; everything later
+        # -> the LDS-tiled x W^T GEMM, which shares each weight tile between 64 or 128 rows
+        if M >= 400000 or (M >= 100000 and Kd <= 64):
             check(lib.ac_pointwise_conv(ptr(x), ptr(w), ptr(bias), ptr(y), M, N, Kd, act, beta, ptr(a_scale), a_rows,
                                         stream()), "ac_pointwise_conv")
         else:
