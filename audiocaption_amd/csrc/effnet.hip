@@ -229,25 +229,33 @@ __global__ __launch_bounds__(256) void pointwise_kernel(PwP p) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const f32x4 vb = *(const f32x4*)(b[t] + 8 * gq);
+        // weights as the MFMA's row operand, activations as its column operand: the accumulator is the TRANSPOSED
+        // tile, lane = output row m, registers 4g..4g+3 = four consecutive channels -> 16-byte stores
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[t] = mfma32(va[j], vb[j], acc[t]);
+        for (int j = 0; j < 4; ++j) acc[t] = mfma32(vb[j], va[j], acc[t]);
       }
     }
+    const long m = m0 + (lane & 31);
+    if (m < p.M) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int n = n0 + t * 32 + (lane & 31);
-      if (n >= p.N) continue;
-      const float bias = p.bias ? p.bias[n] : 0.f;
+      for (int t = 0; t < NT; ++t) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const long m = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m >= p.M) continue;
-        float v = acc[t][r] + bias;
-        if (p.act == 2) v = swishf(v);
-        else if (p.act == 1) v = fmaxf(v, 0.f);
-        float* c = p.y + m * p.N + n;
-        if (p.beta != 0.f) v += p.beta * *c;
-        *c = v;
+        for (int gr = 0; gr < 4; ++gr) {
+          const int n = n0 + t * 32 + 8 * gr + 4 * (lane >> 5);
+          if (n >= p.N) continue;                       // N % 4 == 0: a quad is inside or outside as a whole
+          f32x4 v = {acc[t][4 * gr], acc[t][4 * gr + 1], acc[t][4 * gr + 2], acc[t][4 * gr + 3]};
+          if (p.bias) v += *(const f32x4*)(p.bias + n);
+          if (p.act == 2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = swishf(v[j]);
+          } else if (p.act == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+          }
+          float* c = p.y + m * p.N + n;
+          if (p.beta != 0.f) v += p.beta * *(const f32x4*)c;
+          *(f32x4*)c = v;
+        }
       }
     }
   }
@@ -259,8 +267,9 @@ extern "C" {
 
 int ac_pointwise_conv(const float* x, const float* w, const float* bias, float* y, long M, int N, int K, int act, float beta,
                       const float* gate, int gate_rows, void* stream) {
-  if (!x || !w || !y || M <= 0 || N <= 0 || K <= 0 || (K & 7) || act < 0 || act > 2 || (gate && gate_rows <= 0) ||
-      ((uintptr_t)x & 15) || ((uintptr_t)w & 15))
+  if (!x || !w || !y || M <= 0 || N <= 0 || K <= 0 || (K & 7) || (N & 3) || act < 0 || act > 2 ||
+      (gate && gate_rows <= 0) || ((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 15) ||
+      (bias && ((uintptr_t)bias & 15)))
     return AC_ERR_ARG;
   PwP p;
   p.x = x; p.w = w; p.bias = bias; p.y = y; p.gate = gate; p.gate_rows = gate_rows;

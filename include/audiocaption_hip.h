@@ -301,7 +301,8 @@ int ac_adam_step(float* p, const float* g, float* m, float* v, long n, const flo
 
 /* 1x1 convolution over channels-last rows: y[M][N] = act((x[M][K] .* gate[m / gate_rows][K]) w[N][K]^T + bias) + beta*y
  * (_expand_conv / _project_conv / _conv_head of efficientnet_pytorch with BatchNorm folded into w and bias; act 0 none,
- * 1 ReLU, 2 swish; gate = the squeeze-excite gate or NULL; beta = 1 adds the block input in place).  K % 8 == 0. */
+ * 1 ReLU, 2 swish; gate = the squeeze-excite gate or NULL; beta = 1 adds the block input in place).  K % 8 == 0,
+ * N % 4 == 0, 16-byte aligned pointers. */
 int ac_pointwise_conv(const float* x, const float* w, const float* bias, float* y, long M, int N, int K, int act, float beta,
                       const float* gate, int gate_rows, void* stream);
 /* AmplitudeToDB(top_db) on a (batch, mel, time) tensor: x = max(x, max(x over the WHOLE buffer) - top_db)
