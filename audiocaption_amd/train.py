@@ -19,7 +19,6 @@ Here the whole step is HIP kernels driven from this file through the C ABI (csrc
 through the same engine and returns ``logit`` attached to torch.autograd by ONE bridge node, so the reference's
 runner (``loss.backward()``, any torch optimizer) works unchanged.
 """
-import ctypes
 import random
 
 import torch

@@ -2,9 +2,7 @@
 oracle/effb2_path.py.  PARITY UNPINNED: the oracle restates the published efficientnet_pytorch / torchaudio algorithms
 (not vendored by the reference); what IS checked here is that the HIP path computes exactly that restatement."""
 import ctypes
-import math
 
-import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F

@@ -1,7 +1,6 @@
 """GPU tests at BASELINE.json's FULL sizes (batch 64 x 10 s, 30 s clips, EffB2 batch 128, training batch 32), where the
 CPU oracle is too slow to be the checker: size-independent properties instead - batch-composition invariance and
 permutation equivariance of clip-parallel work, and linearity of the gradient in the batch."""
-import numpy as np
 import pytest
 import torch
 

@@ -3,7 +3,6 @@ same seeded inputs.  Tolerances are absolute, fp32, stated per test."""
 import math
 import os
 
-import numpy as np
 import pytest
 import torch
 
