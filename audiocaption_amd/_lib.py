@@ -72,6 +72,7 @@ SIGNATURES = {
                              _I, _I, _I, _I, _I, _F, _U64, _P, _P]),
     "ac_gather_rows": (_I, [_P, _P, _P, _L, _I, _P]),
     "ac_scatter_add_rows": (_I, [_P, _P, _P, _L, _I, _P]),
+    "ac_specaug": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ac_sum_replicas": (_I, [_P, _P, _L, _I, _P]),
     "ac_rows_mean_w": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "ac_transpose": (_I, [_P, _P, _I, _I, _I, _P]),

@@ -139,12 +139,14 @@ class Cnn14Encoder(nn.Module):
         Hp = [hp6 << (5 - k) for k in range(6)]
         return T, H, Hp
 
-    def encode(self, wav, dropout=None):
+    def encode(self, wav, dropout=None, specaug=None):
         """wav (B, L) on the ROCm device -> attn_emb (B, T // 32, 2048).
 
         ``dropout = (p, op_code, seed_dev_ptr)``: the train-mode forward of the frozen network, F.dropout(p) after
         every conv block (cnn_encoder.py:431-442); the mask of block b is the counter hash of csrc/train.hip with seed
-        op_code + b (+ the device-side step seed) over the block's output buffer."""
+        op_code + b (+ the device-side step seed) over the block's output buffer.
+        ``specaug``: int32 device tensor (B, 4, 2) of (begin, length) stripes - 2 over time, 2 over mel - masked on the
+        log-mel as the reference's SpecAugmentation does in train mode (cnn_encoder.py:423-425)."""
         if wav.dim() != 2:
             raise ValueError("wav must be (batch, samples)")
         dev = wav.device
@@ -155,6 +157,8 @@ class Cnn14Encoder(nn.Module):
         B, L = wav.shape
         T, H, Hp = self.geometry(L)
         x0 = K.logmel(wav, self._tables, pk["bn0"][0], pk["bn0"][1], rows_per_clip=Hp[0], channels_last=True)
+        if specaug is not None:
+            K.specaug_(x0, specaug, pk["bn0"][1], B, Hp[0], T)
         full = self._buf("full", B * Hp[0] * 64 * 64, dev)      # conv1 outputs (largest: level 1)
         pooled = self._buf("pooled", B * Hp[1] * 32 * 64, dev)  # block outputs (largest: block 1)
         W = 64

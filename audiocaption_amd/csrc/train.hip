@@ -693,6 +693,22 @@ __global__ void transpose_kernel(const float* src, float* dst, int rows, int col
   }
 }
 
+// SpecAugment on the bn0-normalised log-mel (the reference masks BEFORE bn0, cnn_encoder.py:423-429, so a masked bin
+// becomes bn0(0) = shift[mel]): x [B*rows_per_clip][F], stripes [B][n_time + n_freq][2] = (begin, length).
+__global__ void specaug_kernel(float* x, const int* stripes, const float* fill, int B, int rows_per_clip, int T, int F,
+                               int n_time, int n_freq) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= (long)B * T * F) return;
+  const int f = (int)(i % F);
+  const int t = (int)((i / F) % T);
+  const int b = (int)(i / ((long)F * T));
+  const int* st = stripes + (long)b * (n_time + n_freq) * 2;
+  bool hit = false;
+  for (int k = 0; k < n_time; ++k) hit |= t >= st[2 * k] && t < st[2 * k] + st[2 * k + 1];
+  for (int k = 0; k < n_freq; ++k) hit |= f >= st[2 * (n_time + k)] && f < st[2 * (n_time + k)] + st[2 * (n_time + k) + 1];
+  if (hit) x[((long)b * rows_per_clip + t) * F + f] = fill ? fill[f] : 0.f;
+}
+
 // ---- column sums (bias gradients): out[n] += sum_m X[m][n] ---------------------------------------------------
 __global__ __launch_bounds__(256) void colsum_kernel(const float* x, long ld, float* out, long M, int N) {
   const int n = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -1199,6 +1215,14 @@ int ac_scatter_add_rows(const float* src, const int* index, float* dst, long nro
   if (!src || !index || !dst || nrows <= 0 || C <= 0) return AC_ERR_ARG;
   hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid_for(nrows * C)), dim3(256), 0, (hipStream_t)stream, src, index, dst,
                      nrows, C);
+  return ac_check_launch();
+}
+
+int ac_specaug(float* x, const int* stripes, const float* fill, int B, int rows_per_clip, int T, int F, int n_time,
+               int n_freq, void* stream) {
+  if (!x || !stripes || B <= 0 || T <= 0 || T > rows_per_clip || F <= 0 || n_time < 0 || n_freq < 0) return AC_ERR_ARG;
+  hipLaunchKernelGGL(specaug_kernel, dim3(grid_for((long)B * T * F)), dim3(256), 0, (hipStream_t)stream, x, stripes, fill, B,
+                     rows_per_clip, T, F, n_time, n_freq);
   return ac_check_launch();
 }
 

@@ -214,3 +214,28 @@ def rows_mean_w(x, out, B, Hp, H, W, C):
     lib = _lib.load()
     check(lib.ac_rows_mean_w(ptr(x), ptr(out), B, Hp, H, W, C, stream()), "ac_rows_mean_w")
     return out
+
+
+def specaug_(x, stripes, fill, B, rows_per_clip, T, n_time=2, n_freq=2):
+    """In-place SpecAugment stripes on the bn0-normalised log-mel rows (csrc/train.hip)."""
+    lib = _lib.load()
+    check(lib.ac_specaug(ptr(x), ptr(stripes), ptr(fill), B, rows_per_clip, T, 64, n_time, n_freq, stream()), "ac_specaug")
+    return x
+
+
+def specaug_stripes(seed, B, T, F=64, time_width=64, time_num=2, freq_width=8, freq_num=2):
+    """Stripe draws of torchlibrosa's SpecAugmentation(time_drop_width=64, time_stripes_num=2, freq_drop_width=8,
+    freq_stripes_num=2) (cnn_encoder.py:352-354): per clip and stripe a width in [0, drop_width) and a start in
+    [0, total - width); all time stripes of the batch first, then all mel stripes.  numpy Generator instead of torch's."""
+    import numpy as np
+    rng = np.random.default_rng(int(seed) & 0xFFFFFFFFFFFFFFFF)
+    out = np.zeros((B, time_num + freq_num, 2), dtype=np.int32)
+    for b in range(B):
+        for k in range(time_num):
+            d = int(rng.integers(0, time_width))
+            out[b, k] = (int(rng.integers(0, T - d)), d)
+    for b in range(B):
+        for k in range(freq_num):
+            d = int(rng.integers(0, freq_width))
+            out[b, time_num + k] = (int(rng.integers(0, F - d)), d)
+    return out

@@ -29,6 +29,7 @@ from .cnn_encoder import cnn14_feat_len
 
 # dropout site codes (low 16 bits of the seed; oracle/train_path.py restates them)
 OP_CNN_BLOCK = 1
+OP_SPECAUG = 9
 OP_GRU_LAYER = 10
 OP_MEM = 20
 OP_EMB_A, OP_EMB_B = 21, 22
@@ -233,9 +234,7 @@ class TrainEngine:
         enc, dec = model.encoder, model.decoder
         if not model.training:
             raise RuntimeError("TrainEngine needs model.train() (run.py:79)")
-        if input_dict.get("specaug", False):
-            raise NotImplementedError("TrainEngine: SpecAugment is not built (the reference config disables it, "
-                                      "cnn14rnn_trm.yaml:38)")
+        specaug = bool(input_dict.get("specaug", False)) and enc.cnn.training
         wav = input_dict["wav"]
         dev = wav.device
         if not wav.is_cuda:
@@ -255,7 +254,7 @@ class TrainEngine:
         p_rnn = float(enc.rnn.network.dropout)
         p_cnn = 0.2 if enc.cnn.training else 0.0
         key = (dev, N, Tc, tuple(wav.shape) if hook is None else ("hook", Tq), teacher_forcing, p_dec, p_rnn, p_cnn,
-               model.start_idx, model.pad_idx)
+               model.start_idx, model.pad_idx, specaug and hook is None)
         st = self._states.get(key)
         if st is None:
             lay = self._layout(N, T, Tq, teacher_forcing, dev)
@@ -265,6 +264,8 @@ class TrainEngine:
                   "wav": torch.empty_like(wav, dtype=torch.float32) if hook is None else None,
                   "cnn_attn_in": torch.empty(N, Tq, 2048, device=dev) if hook is not None else None,
                   "cap": torch.empty(N, Tc, device=dev, dtype=torch.int64),
+                  "specaug": torch.zeros(N, 4, 2, device=dev, dtype=torch.int32) if (specaug and hook is None) else None,
+                  "specaug_pinned": [],
                   # one pinned staging block -> one device block (int32 words):
                   #   seed (int64) | lens [N] | tgt_len [N] | use_cap [T] | mvalid [S]
                   # a ring of staging blocks, each guarded by an event, because the host runs ahead of the device
@@ -293,6 +294,14 @@ class TrainEngine:
         h[2 + 2 * N + max(T, 1):] = lens.to(torch.int32).repeat(S // N)
         st["small"].copy_(h, non_blocking=True)
         ev.record()
+        if st["specaug"] is not None:
+            # SpecAugment stripes of this iteration (torchlibrosa draws them with torch's generator; here a numpy stream
+            # seeded by the dropout seed): pinned staging kept alive for a few iterations, the host runs ahead
+            from .kernels import specaug_stripes
+            T_frames = wav.shape[1] // enc.cnn.hop_length + 1
+            host = torch.from_numpy(specaug_stripes((base_seed << 16) + OP_SPECAUG, N, T_frames)).pin_memory()
+            st["specaug_pinned"] = (st["specaug_pinned"] + [host])[-4:]
+            st["specaug"].copy_(host, non_blocking=True)
         if hook is None:
             st["wav"].copy_(wav, non_blocking=True)
         else:
@@ -322,7 +331,8 @@ class TrainEngine:
         if st["cnn_attn_in"] is not None:
             cnn_attn = st["cnn_attn_in"]
         else:
-            cnn_attn = enc.cnn.encode(st["wav"], dropout=(p_cnn, OP_CNN_BLOCK, self._seed_ptr) if p_cnn > 0 else None)
+            cnn_attn = enc.cnn.encode(st["wav"], dropout=(p_cnn, OP_CNN_BLOCK, self._seed_ptr) if p_cnn > 0 else None,
+                                      specaug=st["specaug"])
         st["cnn_attn"] = cnn_attn
         Cin = cnn_attn.shape[2]
 

@@ -249,6 +249,12 @@ int ac_attn_seq_bwd(const float* q, long ldq, const float* k, long ldk, const fl
  * base.py:181-183). */
 int ac_gather_rows(const float* src, const int* index, float* dst, long nrows, int C, void* stream);
 int ac_scatter_add_rows(const float* src, const int* index, float* dst, long nrows, int C, void* stream);
+/* SpecAugment of the train-mode Cnn14 (torchlibrosa SpecAugmentation as the reference configures it,
+ * cnn_encoder.py:352-354,423-425: 2 time stripes of width < 64 frames and 2 mel stripes of width < 8 bins per clip,
+ * zeroed before bn0): x [B*rows_per_clip][F] is the bn0-normalised log-mel, stripes [B][n_time + n_freq][2] =
+ * (begin, length) drawn on the host; a masked bin is set to fill[mel] = bn0(0) (0 when fill is NULL). */
+int ac_specaug(float* x, const int* stripes, const float* fill, int B, int rows_per_clip, int T, int F, int n_time,
+               int n_freq, void* stream);
 /* out[r] = sum_t x[t*n + r], t < reps (gradient of the projected audio memory shared by all passes). */
 int ac_sum_replicas(const float* x, float* out, long n, int reps, void* stream);
 /* Cnn14 head when dropout sits between the last block and the mel mean (train mode, cnn_encoder.py:441-444):

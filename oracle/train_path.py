@@ -29,6 +29,7 @@ from . import cpu_path as O
 
 # operation codes that, together with the per-step base seed, give each dropout site its own stream
 OP_CNN_BLOCK = 1        # + block index 0..5
+OP_SPECAUG = 9
 OP_GRU_LAYER = 10       # + layer index
 OP_MEM = 20
 OP_EMB_A, OP_EMB_B = 21, 22
@@ -62,11 +63,44 @@ def _mask_t(seed, idx0, shape, p):
 # ---------------------------------------------------------------------------------------------------------
 # frozen Cnn14, train mode
 # ---------------------------------------------------------------------------------------------------------
-def cnn14_train_from_logmel(state, lms, base_seed, p=0.2, rows_per_clip=None, prefix="encoder.cnn."):
+def specaug_stripes(seed, B, T, F=64, time_width=64, time_num=2, freq_width=8, freq_num=2):
+    """(B, time_num + freq_num, 2) int32 (begin, length) stripes: torchlibrosa's SpecAugmentation as the reference
+    configures it (cnn_encoder.py:352-354; DropStripes: width ~ randint(0, drop_width), begin ~ randint(0, total - width),
+    all time stripes of the batch first, then all mel stripes).  PARITY UNPINNED for the draws themselves (torchlibrosa is
+    not vendored and uses torch's generator); the masking arithmetic is what is compared."""
+    rng = np.random.default_rng(int(seed) & 0xFFFFFFFFFFFFFFFF)
+    out = np.zeros((B, time_num + freq_num, 2), dtype=np.int32)
+    for b in range(B):
+        for k in range(time_num):
+            d = int(rng.integers(0, time_width))
+            out[b, k] = (int(rng.integers(0, T - d)), d)
+    for b in range(B):
+        for k in range(freq_num):
+            d = int(rng.integers(0, freq_width))
+            out[b, time_num + k] = (int(rng.integers(0, F - d)), d)
+    return out
+
+
+def apply_specaug(lms, stripes):
+    """lms (B, 64, T): zero the striped frames / mel bins (before bn0, cnn_encoder.py:423-429)."""
+    out = lms.clone()
+    for b in range(lms.shape[0]):
+        for k in range(2):
+            bg, ln = int(stripes[b, k, 0]), int(stripes[b, k, 1])
+            out[b, :, bg:bg + ln] = 0.0
+        for k in range(2, 4):
+            bg, ln = int(stripes[b, k, 0]), int(stripes[b, k, 1])
+            out[b, bg:bg + ln, :] = 0.0
+    return out
+
+
+def cnn14_train_from_logmel(state, lms, base_seed, p=0.2, rows_per_clip=None, prefix="encoder.cnn.", specaug=False):
     """As cpu_path.cnn14_from_logmel plus F.dropout(p) after every block.  The mask of block b is indexed over the
     HIP path's activation layout [clip][row < rows_per_clip[b]][w][c] (rows beyond the valid ones exist there as
     zero padding), so ``rows_per_clip`` (6 ints, the Hp of the level the block's output lives at) must be given
     when p > 0."""
+    if specaug:
+        lms = apply_specaug(lms, specaug_stripes(op_seed(base_seed, OP_SPECAUG), lms.shape[0], lms.shape[2]))
     x = lms.transpose(1, 2).unsqueeze(1)
     x = O._bn_eval(x.transpose(1, 3), state, prefix + "bn0").transpose(1, 3)
     for b in range(1, 7):

@@ -425,8 +425,8 @@ def test_training_step_vs_reference_gradients(train_model, golden_dir, tag):
 
 
 def test_training_step_with_dropout_vs_oracle(train_model, state4981):
-    """Dropout ACTIVE everywhere (Cnn14 0.2, GRU 0.5, decoder 0.2): the HIP step and the CPU oracle regenerate the
-    same counter-hash masks, so logits, tokens, loss and gradients must agree."""
+    """Dropout ACTIVE everywhere (Cnn14 0.2, GRU 0.5, decoder 0.2) and SpecAugment on: the HIP step and the CPU oracle
+    regenerate the same counter-hash masks and stripe draws, so logits, tokens, loss and gradients must agree."""
     from audiocaption_amd import kernels as K
     from audiocaption_amd import procedural as Pr
     from audiocaption_amd.train import TrainEngine
@@ -449,7 +449,7 @@ def test_training_step_with_dropout_vs_oracle(train_model, state4981):
     eng = TrainEngine(model)
     cnn = model.encoder.cnn
     cnn.conv_algo = "winograd"
-    out = eng.forward({"mode": "train", "wav": wav, "wav_len": wav_len, "specaug": False, "cap": cap.cuda(),
+    out = eng.forward({"mode": "train", "wav": wav, "wav_len": wav_len, "specaug": True, "cap": cap.cuda(),
                        "cap_len": cap_len, "ss_ratio": 0.5, "_use_cap": use_cap, "dropout_seed": seed})
     sv = eng._saved
     cnn_attn = sv["cnn_attn"].cpu()
@@ -457,7 +457,11 @@ def test_training_step_with_dropout_vs_oracle(train_model, state4981):
     T, Hs, Hp = cnn.geometry(L)
     pk = cnn._pack(wav.device)
     lms = K.logmel(wav, cnn._tables, rows_per_clip=Hp[0], channels_last=True).view(B, Hp[0], 64)[:, :T].transpose(1, 2)
-    o_cnn = OT.cnn14_train_from_logmel(state4981, lms.cpu(), seed, 0.2, rows_per_clip=Hp[1:] + [Hp[5]])
+    stripes = OT.specaug_stripes(OT.op_seed(seed, OT.OP_SPECAUG), B, T)
+    assert stripes[:, :2, 1].max() < 64 and stripes[:, 2:, 1].max() < 8 and (stripes[:, :2].sum(-1) <= T).all()
+    o_cnn = OT.cnn14_train_from_logmel(state4981, lms.cpu(), seed, 0.2, rows_per_clip=Hp[1:] + [Hp[5]], specaug=True)
+    o_plain = OT.cnn14_train_from_logmel(state4981, lms.cpu(), seed, 0.2, rows_per_clip=Hp[1:] + [Hp[5]])
+    assert float((o_cnn - o_plain).abs().max()) > 1e-3       # the stripes did change the features
     assert rel("cnn attn (dropout)", cnn_attn, o_cnn) < 1e-4
     # (2) the rest from the HIP Cnn14 output
     lens = OT.O.cnn14_feat_len(wav_len)
