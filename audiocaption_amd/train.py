@@ -116,11 +116,14 @@ def allreduce_flat_gradients(flat_grad, process_group=None):
 
 
 class _Ws:
-    """Named device buffers of one (N, T, Tm, ...) shape, allocated once."""
+    """Named device buffers shared by every batch shape of an engine: a buffer is re-allocated only when a shape needs
+    more than it holds, and ``gen`` counts those re-allocations (captured graphs hold raw addresses and are re-captured
+    when it moves)."""
 
     def __init__(self, device):
         self.device = device
         self.t = {}
+        self.gen = 0
 
     def f(self, name, *shape):
         n = 1
@@ -130,6 +133,7 @@ class _Ws:
         if b is None or b.numel() < n:
             b = torch.empty(max(n, 1), device=self.device, dtype=torch.float32)
             self.t[name] = b
+            self.gen += 1
         return b.data_ptr()
 
     def i(self, name, n):
@@ -137,6 +141,7 @@ class _Ws:
         if b is None or b.numel() < n:
             b = torch.empty(max(n, 1), device=self.device, dtype=torch.int32)
             self.t[name] = b
+            self.gen += 1
         return b.data_ptr()
 
     def tensor(self, name):
@@ -157,7 +162,7 @@ class TrainEngine:
         self.model = model
         self.lib = _lib.load()
         self.flat = None
-        self._ws = {}
+        self._wsg = None
         self.seed = int(seed)          # bumped after every forward (fresh dropout masks per step)
         self._seed_ptr = None
         self._saved = None
@@ -259,7 +264,9 @@ class TrainEngine:
         if st is None:
             lay = self._layout(N, T, Tq, teacher_forcing, dev)
             S = lay["S"]
-            st = {"key": key, "ws": _Ws(dev), "lay": lay, "N": N, "T": T, "Tc": Tc, "Tq": Tq, "teacher_forcing": teacher_forcing,
+            if self._wsg is None or self._wsg.device != dev:
+                self._wsg = _Ws(dev)
+            st = {"key": key, "ws": self._wsg, "lay": lay, "N": N, "T": T, "Tc": Tc, "Tq": Tq, "teacher_forcing": teacher_forcing,
                   "p_dec": p_dec, "p_rnn": p_rnn, "p_cnn": p_cnn, "graph": None, "steps": 0,
                   "wav": torch.empty_like(wav, dtype=torch.float32) if hook is None else None,
                   "cnn_attn_in": torch.empty(N, Tq, 2048, device=dev) if hook is not None else None,
@@ -273,6 +280,12 @@ class TrainEngine:
                            for _ in range(4)],
                   "small": torch.zeros(2 + 2 * N + max(T, 1) + S, device=dev, dtype=torch.int32)}
             self._states[key] = st
+            # real batches are padded to their longest clip / caption: shapes keep changing, so the per-shape states
+            # (index tables, static inputs, a captured graph) are kept for the 16 most recently used shapes only
+            while len(self._states) > 16:
+                self._states.pop(next(iter(self._states)))
+        else:
+            self._states[key] = self._states.pop(key)     # most recently used last
         if wav.shape[0] != N:
             raise ValueError("cap and wav batch sizes differ")
         lens = cnn14_feat_len(input_dict["wav_len"], enc.cnn.hop_length, enc.cnn.downsample_ratio)
@@ -648,12 +661,13 @@ class TrainEngine:
         elif st["graph"] is None and st["steps"] < 2:
             self._launch_step_body(st, smoothing)          # first iteration of this shape: eager (also the warm-up)
         else:
-            if st["graph"] is None or st["graph_key"] != (smoothing, _lib.param_generation_flat(self)):
+            gkey = (smoothing, _lib.param_generation_flat(self), st["ws"].gen)
+            if st["graph"] is None or st["graph_key"] != gkey:
                 torch.cuda.synchronize(st["cap"].device)
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     self._launch_step_body(st, smoothing)
-                st["graph"], st["graph_key"] = graph, (smoothing, _lib.param_generation_flat(self))
+                st["graph"], st["graph_key"] = graph, (smoothing, _lib.param_generation_flat(self), st["ws"].gen)
             st["graph"].replay()
         self.flat.attach_grads()
         world = allreduce_flat_gradients(self.flat.grad, process_group)

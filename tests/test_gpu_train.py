@@ -559,3 +559,46 @@ def test_swa_and_nan_skip_on_device(train_model):
     opt.step(clip=clip)
     assert float(clip.state[3]) == 1.0 and float(clip.state[2]) == 0.0
     assert torch.equal(eng.flat.flat, before) and torch.equal(opt._flat_state[0]["m"], m_before)
+
+
+def test_changing_batch_shapes_share_one_workspace(train_model):
+    """Real batches are padded to their longest clip / caption, so shapes change all the time: the activation workspace is
+    shared (grows to the largest shape only), per-shape states are an LRU, and a graph captured for a shape is
+    re-captured when a later, larger shape re-allocated the buffers it points into."""
+    from audiocaption_amd import procedural as Pr
+    from audiocaption_amd.optim import FusedAdam
+    from audiocaption_amd.train import TrainEngine
+    model = train_model
+    eng = TrainEngine(model, seed=7)
+    opt = FusedAdam([p for p in model.parameters() if p.requires_grad], lr=1e-4)
+    rng = np.random.default_rng(0)
+    base = torch.from_numpy(Pr.synthetic_wav(4, 224000, seed=12)).cuda()
+    g = torch.Generator().manual_seed(3)
+
+    def batch(L, Tc, n=4):
+        cap = torch.randint(4, 4981, (n, Tc), generator=g)
+        cap[:, 0], cap[:, -1] = 1, 2
+        return {"mode": "train", "wav": base[:n, :L].contiguous(), "wav_len": [L] * n, "specaug": False, "cap": cap.cuda(),
+                "cap_len": np.array([Tc] * n), "ss_ratio": 0.8}
+
+    random.seed(2)
+    small = batch(96000, 6)
+    for _ in range(3):                       # eager, capture, replay
+        r = eng.step(small, opt)
+    st_small = next(iter(eng._states.values()))
+    assert st_small["graph"] is not None
+    gen0 = eng._wsg.gen
+    losses = [float(r["loss"])]
+    torch.cuda.synchronize()
+    mem0 = torch.cuda.memory_allocated()
+    for i in range(24):                      # 24 different shapes: lengths and caption lengths keep changing
+        L = int(rng.integers(30, 70)) * 3200
+        losses.append(float(eng.step(batch(L, int(rng.integers(5, 12))), opt)["loss"]))
+    assert len(eng._states) <= 16 and all(np.isfinite(losses))
+    assert eng._wsg.gen > gen0               # larger shapes re-allocated shared buffers ...
+    r = eng.step(small, opt)                 # ... so the small shape (if still cached) must re-capture, not replay stale addresses
+    assert np.isfinite(float(r["loss"]))
+    torch.cuda.synchronize()
+    grown = torch.cuda.memory_allocated() - mem0
+    print(f"memory growth over 24 shapes: {grown / 2**20:.0f} MiB, states {len(eng._states)}, workspace generation {eng._wsg.gen}")
+    assert grown < 3 * 2**30
