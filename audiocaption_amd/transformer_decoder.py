@@ -200,19 +200,22 @@ class TransformerDecoder(BaseDecoder):
         """On-device greedy search.  Returns device tensors seq (int64), logit, logprob, embed, cnt.
 
         The ~370 short launches of a decode are latency-bound, so the fixed launch sequence (memory
-        preparation + max_length decoder steps) is captured ONCE per shape into a HIP graph over static
-        buffers and replayed; inputs are copied in, outputs are cloned out (fresh tensors per call, as the
+        preparation + max_length decoder steps) is captured once per shape (on its second use) into a HIP graph over
+        static buffers and replayed; inputs are copied in, outputs are cloned out (fresh tensors per call, as the
         reference returns).  Set AUDIOCAPTION_DECODE_GRAPH=0 to launch eagerly."""
         dev = attn_emb.device
         B, Tm, A = attn_emb.shape
         use_graph = os.environ.get("AUDIOCAPTION_DECODE_GRAPH", "1") != "0"
         key = (dev, B, Tm, max_length, start_idx, end_idx, pad_idx, self._weights_key())
-        st = self._greedy_state if self._greedy_state is not None and self._greedy_state["key"] == key else None
+        if self._greedy_state is None:
+            self._greedy_state = {}
+        states = self._greedy_state
+        st = states.pop(key, None)
         if st is None:
             f32 = dict(device=dev, dtype=torch.float32)
             ws_n = _lib.load().ac_trm_workspace_floats(ctypes.byref(self.weights()), B, max_length)
             st = {
-                "key": key, "graph": None,
+                "key": key, "graph": None, "uses": 0,
                 "attn_emb": torch.empty(B, Tm, A, **f32), "mem_len": torch.empty(B, device=dev, dtype=torch.int32),
                 "memkv": torch.empty(self.nlayers, B * Tm, 2 * self.d_model, **f32),
                 "tmp": torch.empty(B * Tm, self.d_model, **f32), "ws": torch.empty(ws_n, **f32),
@@ -222,15 +225,18 @@ class TransformerDecoder(BaseDecoder):
                 "embed": torch.empty(B, max_length, self.d_model, **f32),
                 "unfinished_cnt": torch.empty(max_length, device=dev, dtype=torch.int32),
             }
-            self._greedy_state = st
+        states[key] = st                       # most recently used last; batches of changing length keep 8 shapes
+        while len(states) > 8:
+            states.pop(next(iter(states)))
+        st["uses"] += 1
         st["attn_emb"].copy_(attn_emb)
         st["mem_len"].copy_(torch.as_tensor(attn_emb_len).to(device=dev, dtype=torch.int32))
-        if not use_graph:
+        if not use_graph or st["uses"] < 2:
+            # first batch of this shape: plain launches (also the warm-up a capture needs); a shape that never comes
+            # back is never captured
             self._greedy_launch(st, max_length, start_idx, end_idx, pad_idx)
         else:
             if st["graph"] is None:
-                # warm-up launch outside capture (module load, LDS attribute calls), then capture
-                self._greedy_launch(st, max_length, start_idx, end_idx, pad_idx)
                 torch.cuda.synchronize(dev)
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
