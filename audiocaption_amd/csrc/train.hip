@@ -915,14 +915,25 @@ __global__ __launch_bounds__(768) void gru_bwd_kernel(const float* dout, const f
   __shared__ float sdh[H];
   __shared__ float sdg[3 * H];
   __shared__ float spart[3][H];
+  extern __shared__ float swb[];   // [GRU_KLDS][3][H]: rows 96..143 of every gate block of W_hh
   const int tid = threadIdx.x;
   const int b = blockIdx.x >> 1, dir = blockIdx.x & 1;
   int len = lens[b];
   len = len < 0 ? 0 : (len > T ? T : len);
   const float* W = whh + (size_t)dir * 3 * H * H;
+  const int part = tid >> 8, k = tid & 255;
+  // same residency as the forward: this thread's column of W_hh^T (row index n of its gate block) is kept in
+  // registers for n < 96, in LDS for the next 48, and streamed for the rest
+  const float* wp = W + (size_t)(part * H) * H + k;
+  float wreg[GRU_KREG];
+  if (len > 0) {
+#pragma unroll
+    for (int n = 0; n < GRU_KREG; ++n) wreg[n] = wp[(size_t)n * H];
+#pragma unroll
+    for (int j = 0; j < GRU_KLDS; ++j) swb[(j * 3 + part) * H + k] = wp[(size_t)(GRU_KREG + j) * H];
+  }
   if (tid < H) sdh[tid] = 0.f;
   __syncthreads();
-  const int part = tid >> 8, k = tid & 255;
   for (int step = len - 1; step >= 0; --step) {
     const int t = dir ? (len - 1 - step) : step;
     const size_t cell = ((size_t)b * T + t) * 2 + dir;
@@ -951,9 +962,12 @@ __global__ __launch_bounds__(768) void gru_bwd_kernel(const float* dout, const f
     }
     __syncthreads();
     float a = 0.f;
-    const float* wp = W + (size_t)(part * H) * H + k;
+#pragma unroll
+    for (int n = 0; n < GRU_KREG; ++n) a = fmaf(sdg[part * H + n], wreg[n], a);
+#pragma unroll
+    for (int j = 0; j < GRU_KLDS; ++j) a = fmaf(sdg[part * H + GRU_KREG + j], swb[(j * 3 + part) * H + k], a);
 #pragma unroll 8
-    for (int n = 0; n < H; ++n) a = fmaf(sdg[part * H + n], wp[(size_t)n * H], a);
+    for (int n = GRU_KREG + GRU_KLDS; n < H; ++n) a = fmaf(sdg[part * H + n], wp[(size_t)n * H], a);
     spart[part][k] = a;
     __syncthreads();
     if (tid < H) sdh[tid] = direct + (spart[0][tid] + spart[1][tid]) + spart[2][tid];
@@ -1289,7 +1303,14 @@ int ac_gru_layer_bwd(const float* dout, const float* out, const float* save, con
                      float* dgx, float* dgh, float* hprev, int B, int T, int hidden, void* stream) {
   if (!dout || !out || !save || !whh || !lens || !dgx || !dgh || !hprev || B <= 0 || T <= 0 || hidden != H)
     return AC_ERR_ARG;
-  hipLaunchKernelGGL(gru_bwd_kernel, dim3(2 * B), dim3(768), 0, (hipStream_t)stream, dout, out, save, whh, lens, dgx, dgh,
+  const size_t lds = (size_t)GRU_KLDS * 3 * H * sizeof(float);
+  static bool allowed = false;
+  if (!allowed) {
+    if (hipFuncSetAttribute((const void*)gru_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return AC_ERR_LAUNCH;
+    allowed = true;
+  }
+  hipLaunchKernelGGL(gru_bwd_kernel, dim3(2 * B), dim3(768), lds, (hipStream_t)stream, dout, out, save, whh, lens, dgx, dgh,
                      hprev, T);
   return ac_check_launch();
 }
