@@ -42,7 +42,9 @@ SIGNATURES = {
     "ac_conv3x3_bn_relu_winograd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ac_conv3x3_bn_relu_bf16x3": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ac_conv3x3_bn_relu_bf16x3_gw": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ac_conv3x3_bn_relu_f16x2_gw": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ac_conv3x3_first": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ac_conv3x3_first_f16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ac_linear": (_I, [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _P]),
     "ac_gru_pack_whh": (_I, [_P, _P, _I, _P]),
     "ac_gru_layer": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),

@@ -74,10 +74,12 @@ __device__ __forceinline__ int window_pos(int q) { return (0x73261540 >> (4 * q)
 
 // ---- epilogue: BN scale/shift, ReLU, pooling, zero rows; lanes 0..31 store 32 consecutive channels ----
 // acc[m][n] = 32x32 tile (m-th pixel tile, n-th channel tile of this wave), MFMA row i = 4*window + 2*dy + dx
-template <int BN, int MODE>
-__device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 (&acc)[2][BN / 64], int n_tile, int row0,
+// A wave owns MW pixel tiles (wm * MW + m of the block's four) and NTW channel tiles (wn * NTW + n).
+// OUT16: the FULL / POOL outputs are stored as fp16 (the activations of the "f16x2" tier live in HBM as fp16: the
+// consumer would round them to fp16 anyway, so the numbers are the same and the traffic is half).
+template <int BN, int MODE, int MW = 2, int NTW = BN / 64, bool OUT16 = false>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 (&acc)[MW][NTW], int n_tile, int row0,
                                               int col0, int wm, int wn, int lane) {
-  constexpr int NTW = BN / 64;
   const int half = lane >> 5;
   const int TC = 1 << p.tc_log2;
   const int QR2 = 32 >> p.tc_log2;
@@ -86,14 +88,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 
     const int ch = n_tile * BN + (wn * NTW + n) * 32 + (lane & 31);
     const float sc = p.scale[ch], sh = p.shift[ch];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < MW; ++m) {
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
         // window q = 2*rq + half of this MFMA tile; registers 4*rq + (2*dy + dx)
         const int q = window_pos(2 * rq + half);
         const int qc = q & ((TC >> 1) - 1);
         const int qr = q >> (p.tc_log2 - 1);
-        const int wy = row0 + (2 * wm + m) * QR2 + 2 * qr;  // physical row of the window's dy = 0
+        const int wy = row0 + (MW * wm + m) * QR2 + 2 * qr;  // physical row of the window's dy = 0
         const int wx = col0 + 2 * qc;
         float y[4];
 #pragma unroll
@@ -104,7 +106,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 
             const int gr = wy + (e >> 1), gc = wx + (e & 1);
             if (gr < p.rows_total) {
               const bool valid = (gr % p.Hp) < p.H;
-              p.out[((size_t)gr * p.W + gc) * p.Cout + ch] = valid ? y[e] : 0.f;
+              const size_t o = ((size_t)gr * p.W + gc) * p.Cout + ch;
+              if (OUT16) ((_Float16*)p.out)[o] = (_Float16)(valid ? y[e] : 0.f);
+              else p.out[o] = valid ? y[e] : 0.f;
             }
           }
         } else if (MODE == MODE_POOL) {
@@ -112,7 +116,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 
           if (wy < p.rows_total) {
             const bool valid = (orow % p.Hp_out) < p.H_out;
             const float o = 0.25f * ((y[0] + y[1]) + (y[2] + y[3]));
-            p.out[((size_t)orow * p.W_out + ocol) * p.Cout + ch] = valid ? o : 0.f;
+            const size_t oi = ((size_t)orow * p.W_out + ocol) * p.Cout + ch;
+            if (OUT16) ((_Float16*)p.out)[oi] = (_Float16)(valid ? o : 0.f);
+            else p.out[oi] = valid ? o : 0.f;
           }
         } else {  // MODE_MEANW: W == 2, mean over the two mel columns, dense (B, H, Cout) output
 #pragma unroll
@@ -456,15 +462,31 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16x3_kernel(ConvParams p) {
 // one contiguous 1 KiB read; the fragments of tap t+1 are requested into VGPRs while tap t runs on the
 // matrix cores.  LDS then holds only the split halo patch: no weight ring, no per-tap barrier (2 barriers
 // per 32-channel chunk = per 216 MFMAs of a wave), half the LDS fragment reads.
+//
+// PREC = 0: split-bf16, three products per f32 product (x_lo w_hi + x_hi w_lo + x_hi w_hi), 2^-16 operand error.
+// PREC = 1 ("f16x2"): activations rounded ONCE to fp16 (RNE, 2^-12 relative), weights split into fp16 hi + lo
+//   (2^-22; the host scales every output channel by a power of two so that the lo parts are normal numbers and
+//   folds the inverse into the BN scale), two products per f32 product on v_mfma_f32_32x32x16_f16, f32
+//   accumulation.  One LDS plane instead of two.  More accurate than the TF32 convolutions (2^-11 on BOTH operands)
+//   the reference itself runs with on its GPUs (torch.backends.cudnn.allow_tf32 defaults to True).
 // ------------------------------------------------------------------------------------------------
-template <int BN, int MODE>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {
+  const f16x2v h = {(_Float16)a, (_Float16)b};
+  return __builtin_bit_cast(unsigned, h);
+}
+
+template <int BN, int MODE, int PREC, int WM>
 __global__ __launch_bounds__(256, 3) void conv3x3_bf16x3_gw_kernel(ConvParams p) {
-  constexpr int NTW = BN / 64;
+  // wave grid WM (pixel tiles) x WN (channel tiles); WM = 1 makes every wave walk all 128 pixels of the block for
+  // 32 channels: half the weight-fragment bytes per MFMA (the L1/L2 stream that limits the two-product tier)
+  constexpr int WN = 4 / WM, MW = 4 / WM, NTW = (BN / 32) / WN;
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm_raw[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int half = lane >> 5;
 
   int m_tile, n_tile;
@@ -481,20 +503,20 @@ __global__ __launch_bounds__(256, 3) void conv3x3_bf16x3_gw_kernel(ConvParams p)
   __bf16* sAl = sAh + PLANE;
 
   const int QR2 = 32 >> p.tc_log2;
-  int pbase[2];
+  int pbase[MW];
   {
     const int i = lane & 31;
     const int q = window_pos(i >> 2), dy = (i >> 1) & 1, dx = i & 1;
     const int qc = q & ((TC >> 1) - 1);
     const int qr = q >> (p.tc_log2 - 1);
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
-      pbase[m] = ((2 * wm + m) * QR2 + 2 * qr + dy) * PITCH + (2 * qc + dx) * BROW + half * 8;
+    for (int m = 0; m < MW; ++m)
+      pbase[m] = ((MW * wm + m) * QR2 + 2 * qr + dy) * PITCH + (2 * qc + dx) * BROW + half * 8;
   }
 
-  f32x16 acc[2][NTW];
+  f32x16 acc[MW][NTW];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < MW; ++m)
 #pragma unroll
     for (int n = 0; n < NTW; ++n)
 #pragma unroll
@@ -520,7 +542,9 @@ __global__ __launch_bounds__(256, 3) void conv3x3_bf16x3_gw_kernel(ConvParams p)
     // (up to GW_MAXIT) items is, as a global element offset and an LDS offset.  The per-chunk staging loop is then a
     // load, the hi/lo split and two LDS stores per item - the divisions and bounds tests used to be redone for every
     // 32-channel chunk and made the kernel's VALU time comparable to its MFMA time.
-    constexpr int GW_MAXIT = 9;
+    // An item is 16 bytes of one pixel: 4 f32 channels (PREC 0) or 8 fp16 channels (PREC 1, copied as they are).
+    constexpr int IPP = PREC == 0 ? 8 : 4;          // items per pixel and 32-channel chunk
+    constexpr int GW_MAXIT = PREC == 0 ? 9 : 5;     // >= ceil(MAX_NPIX * IPP / 256)
     constexpr unsigned GW_NONE = 0xffffffffu, GW_OOB = 0x80000000u;
     unsigned goff[GW_MAXIT], loff[GW_MAXIT];
 #pragma unroll
@@ -528,26 +552,32 @@ __global__ __launch_bounds__(256, 3) void conv3x3_bf16x3_gw_kernel(ConvParams p)
       const int idx = tid + j * 256;
       loff[j] = GW_NONE;
       goff[j] = 0;
-      if (idx < NPIX * 8) {
-        const int pix = idx >> 3, c4 = idx & 7;
+      if (idx < NPIX * IPP) {
+        const int pix = idx / IPP, ci = idx % IPP;
         const int pr = pix / PW, pc = pix - pr * PW;
         const int gr = row0 - 1 + pr, gc = col0 - 1 + pc;
         const bool ok = gr >= 0 && gr < p.rows_total && gc >= 0 && gc < p.W;
-        goff[j] = ok ? (unsigned)(((size_t)gr * p.W + gc) * p.Cin + c4 * 4) : 0u;
-        loff[j] = (unsigned)(pr * PITCH + pc * BROW + c4 * 4) | (ok ? 0u : GW_OOB);
+        goff[j] = ok ? (unsigned)(((size_t)gr * p.W + gc) * p.Cin + ci * (32 / IPP)) : 0u;
+        loff[j] = (unsigned)(pr * PITCH + pc * BROW + ci * (32 / IPP)) | (ok ? 0u : GW_OOB);
       }
     }
     auto stage_patch = [&](int c) {
 #pragma unroll
       for (int j = 0; j < GW_MAXIT; ++j) {
         if (loff[j] == GW_NONE) continue;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (!(loff[j] & GW_OOB)) v = *(const f32x4*)(p.in + (size_t)goff[j] + c * 32);
-        u32x2 hi, lo;
-        split_bf16x4(v, hi, lo);
         const unsigned lo_off = loff[j] & 0x7fffffffu;
-        *(u32x2*)(sAh + lo_off) = hi;
-        *(u32x2*)(sAl + lo_off) = lo;
+        if (PREC == 0) {
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (!(loff[j] & GW_OOB)) v = *(const f32x4*)(p.in + (size_t)goff[j] + c * 32);
+          u32x2 hi, lo;
+          split_bf16x4(v, hi, lo);
+          *(u32x2*)(sAh + lo_off) = hi;
+          *(u32x2*)(sAl + lo_off) = lo;
+        } else {
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if (!(loff[j] & GW_OOB)) v = *(const u32x4*)((const _Float16*)p.in + (size_t)goff[j] + c * 32);
+          *(u32x4*)(sAh + lo_off) = v;
+        }
       }
     };
     const int total = nchunk * 9;
@@ -563,19 +593,25 @@ __global__ __launch_bounds__(256, 3) void conv3x3_bf16x3_gw_kernel(ConvParams p)
       const int aoff = ky * PITCH + kx * BROW;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 ah[2], al[2];
+        bf16x8 ah[MW], al[MW];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
+        for (int m = 0; m < MW; ++m) {
           ah[m] = *(const bf16x8*)(sAh + aoff + pbase[m] + ks * 16);
-          al[m] = *(const bf16x8*)(sAl + aoff + pbase[m] + ks * 16);
+          if (PREC == 0) al[m] = *(const bf16x8*)(sAl + aoff + pbase[m] + ks * 16);
         }
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MW; ++m)
 #pragma unroll
           for (int n = 0; n < NTW; ++n) {
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], wc[ks][n][0], acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], wc[ks][n][1], acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], wc[ks][n][0], acc[m][n], 0, 0, 0);
+            if (PREC == 0) {
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], wc[ks][n][0], acc[m][n], 0, 0, 0);
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], wc[ks][n][1], acc[m][n], 0, 0, 0);
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], wc[ks][n][0], acc[m][n], 0, 0, 0);
+            } else {
+              const f16x8 a = __builtin_bit_cast(f16x8, ah[m]);
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(f16x8, wc[ks][n][1]), acc[m][n], 0, 0, 0);
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(f16x8, wc[ks][n][0]), acc[m][n], 0, 0, 0);
+            }
           }
       }
 #pragma unroll
@@ -594,10 +630,10 @@ __global__ __launch_bounds__(256, 3) void conv3x3_bf16x3_gw_kernel(ConvParams p)
       }
     }
   }
-  conv_epilogue<BN, MODE>(p, acc, n_tile, row0, col0, wm, wn, lane);
+  conv_epilogue<BN, MODE, MW, NTW, PREC == 1>(p, acc, n_tile, row0, col0, wm, wn, lane);
 }
 
-template <int BN, int MODE>
+template <int BN, int MODE, int PREC = 0, int WM = 2>
 int launch_conv_bf16x3_gw(const ConvParams& p, hipStream_t s) {
   unsigned grid;
   if (p.map_mode == 2) grid = (unsigned)(((p.MT + 7) / 8) * 8 * p.NT);
@@ -605,8 +641,8 @@ int launch_conv_bf16x3_gw(const ConvParams& p, hipStream_t s) {
   else grid = (unsigned)(p.MT * p.NT);
   const int TC = 1 << p.tc_log2, TR = 128 >> p.tc_log2;
   const int pitch = (TC + 2) * BROW + patch_row_pad_slots(TC) * 8;
-  const size_t lds = (size_t)(TR + 2) * pitch * 2 * 2;  // hi + lo planes, bf16
-  hipLaunchKernelGGL((conv3x3_bf16x3_gw_kernel<BN, MODE>), dim3(grid), dim3(256), lds, s, p);
+  const size_t lds = (size_t)(TR + 2) * pitch * 2 * (PREC == 0 ? 2 : 1);  // hi + lo planes (bf16) or one fp16 plane
+  hipLaunchKernelGGL((conv3x3_bf16x3_gw_kernel<BN, MODE, PREC, WM>), dim3(grid), dim3(256), lds, s, p);
   return ac_check_launch();
 }
 
@@ -642,6 +678,7 @@ struct ConvFirstParams {
   int rows_total, Hp, H, W;
 };
 
+template <bool OUT16>
 __global__ __launch_bounds__(256) void conv_first_kernel(ConvFirstParams p) {
   constexpr int RT = 4;  // rows per block
   __shared__ float patch[RT + 2][64 + 2];
@@ -683,7 +720,15 @@ __global__ __launch_bounds__(256) void conv_first_kernel(ConvFirstParams p) {
       }
       o = make_float4(a[0], a[1], a[2], a[3]);
     }
-    *(float4*)(p.out + ((size_t)gr * p.W + c) * 64 + cg * 4) = o;
+    const size_t oi = ((size_t)gr * p.W + c) * 64 + cg * 4;
+    if (OUT16) {
+      u32x2 h;
+      h.x = cvt_pk_f16(o.x, o.y);
+      h.y = cvt_pk_f16(o.z, o.w);
+      *(u32x2*)((_Float16*)p.out + oi) = h;
+    } else {
+      *(float4*)(p.out + oi) = o;
+    }
   }
 }
 
@@ -771,9 +816,9 @@ extern "C" int ac_conv3x3_bn_relu_bf16x3(const float* in, const void* wpk, const
   }
 }
 
-extern "C" int ac_conv3x3_bn_relu_bf16x3_gw(const float* in, const void* wfrag, const float* scale, const float* shift,
-                                            float* out, int B, int Hp, int H, int W, int Cin, int Cout, int mode,
-                                            int map_mode, void* stream) {
+static int conv_gw_dispatch(int prec, const float* in, const void* wfrag, const float* scale, const float* shift,
+                            float* out, int B, int Hp, int H, int W, int Cin, int Cout, int mode, int map_mode,
+                            void* stream) {
   if (!in || !wfrag || !scale || !shift || !out) return AC_ERR_ARG;
   if (B <= 0 || Hp <= H || W < 2 || (W & (W - 1)) || Cin % 32 || Cout % 64) return AC_ERR_ARG;
   if (mode < 0 || mode > 2) return AC_ERR_ARG;
@@ -797,15 +842,48 @@ extern "C" int ac_conv3x3_bn_relu_bf16x3_gw(const float* in, const void* wfrag, 
   if (map_mode == 3 && (p.NT > 8 || (8 % p.NT) != 0)) return AC_ERR_ARG;
   p.map_mode = map_mode;
   hipStream_t s = (hipStream_t)stream;
-  if (BN == 128) {
-    if (mode == MODE_FULL) return launch_conv_bf16x3_gw<128, MODE_FULL>(p, s);
-    if (mode == MODE_POOL) return launch_conv_bf16x3_gw<128, MODE_POOL>(p, s);
-    return launch_conv_bf16x3_gw<128, MODE_MEANW>(p, s);
-  } else {
-    if (mode == MODE_FULL) return launch_conv_bf16x3_gw<64, MODE_FULL>(p, s);
-    if (mode == MODE_POOL) return launch_conv_bf16x3_gw<64, MODE_POOL>(p, s);
-    return launch_conv_bf16x3_gw<64, MODE_MEANW>(p, s);
+  if (prec == 0) {
+    if (BN == 128) {
+      if (getenv("AC_GW_WM1")) {
+        if (mode == MODE_FULL) return launch_conv_bf16x3_gw<128, MODE_FULL, 0, 1>(p, s);
+        if (mode == MODE_POOL) return launch_conv_bf16x3_gw<128, MODE_POOL, 0, 1>(p, s);
+        return launch_conv_bf16x3_gw<128, MODE_MEANW, 0, 1>(p, s);
+      }
+      if (mode == MODE_FULL) return launch_conv_bf16x3_gw<128, MODE_FULL>(p, s);
+      if (mode == MODE_POOL) return launch_conv_bf16x3_gw<128, MODE_POOL>(p, s);
+      return launch_conv_bf16x3_gw<128, MODE_MEANW>(p, s);
+    } else {
+      if (mode == MODE_FULL) return launch_conv_bf16x3_gw<64, MODE_FULL>(p, s);
+      if (mode == MODE_POOL) return launch_conv_bf16x3_gw<64, MODE_POOL>(p, s);
+      return launch_conv_bf16x3_gw<64, MODE_MEANW>(p, s);
+    }
   }
+  if (BN == 128) {
+    if (getenv("AC_GW_WM2")) {
+      if (mode == MODE_FULL) return launch_conv_bf16x3_gw<128, MODE_FULL, 1>(p, s);
+      if (mode == MODE_POOL) return launch_conv_bf16x3_gw<128, MODE_POOL, 1>(p, s);
+      return launch_conv_bf16x3_gw<128, MODE_MEANW, 1>(p, s);
+    }
+    if (mode == MODE_FULL) return launch_conv_bf16x3_gw<128, MODE_FULL, 1, 1>(p, s);
+    if (mode == MODE_POOL) return launch_conv_bf16x3_gw<128, MODE_POOL, 1, 1>(p, s);
+    return launch_conv_bf16x3_gw<128, MODE_MEANW, 1, 1>(p, s);
+  } else {
+    if (mode == MODE_FULL) return launch_conv_bf16x3_gw<64, MODE_FULL, 1>(p, s);
+    if (mode == MODE_POOL) return launch_conv_bf16x3_gw<64, MODE_POOL, 1>(p, s);
+    return launch_conv_bf16x3_gw<64, MODE_MEANW, 1>(p, s);
+  }
+}
+
+extern "C" int ac_conv3x3_bn_relu_bf16x3_gw(const float* in, const void* wfrag, const float* scale, const float* shift,
+                                            float* out, int B, int Hp, int H, int W, int Cin, int Cout, int mode,
+                                            int map_mode, void* stream) {
+  return conv_gw_dispatch(0, in, wfrag, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode, stream);
+}
+
+extern "C" int ac_conv3x3_bn_relu_f16x2_gw(const void* in, const void* wfrag, const float* scale, const float* shift,
+                                           void* out, int B, int Hp, int H, int W, int Cin, int Cout, int mode,
+                                           int map_mode, void* stream) {
+  return conv_gw_dispatch(1, (const float*)in, wfrag, scale, shift, (float*)out, B, Hp, H, W, Cin, Cout, mode, map_mode, stream);
 }
 
 extern "C" int ac_conv3x3_first(const float* in, const float* w, const float* scale, const float* shift,
@@ -815,6 +893,17 @@ extern "C" int ac_conv3x3_first(const float* in, const float* w, const float* sc
   p.in = in; p.w = w; p.scale = scale; p.shift = shift; p.out = out;
   p.rows_total = B * Hp; p.Hp = Hp; p.H = H; p.W = W;
   const unsigned grid = (unsigned)((p.rows_total + 3) / 4);
-  hipLaunchKernelGGL(conv_first_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(conv_first_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  return ac_check_launch();
+}
+
+extern "C" int ac_conv3x3_first_f16(const float* in, const float* w, const float* scale, const float* shift,
+                                    void* out, int B, int Hp, int H, int W, void* stream) {
+  if (!in || !w || !scale || !shift || !out || B <= 0 || Hp <= H || W != 64) return AC_ERR_ARG;
+  ConvFirstParams p;
+  p.in = in; p.w = w; p.scale = scale; p.shift = shift; p.out = (float*)out;
+  p.rows_total = B * Hp; p.Hp = Hp; p.H = H; p.W = W;
+  const unsigned grid = (unsigned)((p.rows_total + 3) / 4);
+  hipLaunchKernelGGL(conv_first_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   return ac_check_launch();
 }

@@ -38,7 +38,12 @@ def logmel(wav, tables, scale=None, shift=None, rows_per_clip=None, channels_las
 
 
 def conv3x3_first(x, w, scale, shift, out, B, Hp, H, W=64):
+    """``out`` float32, or float16 for the "f16x2" conv tier."""
     lib = _lib.load()
+    if out.dtype == torch.float16:
+        check(lib.ac_conv3x3_first_f16(ptr(x), ptr(w), ptr(scale), ptr(shift), ptr(out), B, Hp, H, W, stream()),
+              "ac_conv3x3_first_f16")
+        return out
     check(lib.ac_conv3x3_first(ptr(x), ptr(w), ptr(scale), ptr(shift), ptr(out), B, Hp, H, W, stream()),
           "ac_conv3x3_first")
     return out
@@ -112,6 +117,40 @@ def conv3x3_bn_relu_bf16x3_gw(x, wfrag, scale, shift, out, B, Hp, H, W, Cin, Cou
     if hook is not None:
         hook("post", info)
     return out
+
+
+def conv3x3_bn_relu_f16x2_gw(x, wfrag, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode=-1):
+    lib = _lib.load()
+    hook = CONV_LAUNCH_HOOK
+    if hook is not None:
+        info = {"B": B, "H": H, "Hp": Hp, "W": W, "Cin": Cin, "Cout": Cout, "mode": mode, "algo": "f16x2"}
+        hook("pre", info)
+    if x.dtype != torch.float16 or out.dtype != (torch.float32 if mode == 2 else torch.float16):
+        raise ValueError("f16x2 conv: fp16 activations in, fp16 out (f32 for mode 2)")
+    check(lib.ac_conv3x3_bn_relu_f16x2_gw(ptr(x), ptr(wfrag), ptr(scale), ptr(shift), ptr(out), B, Hp, H, W,
+                                          Cin, Cout, mode, map_mode, stream()), "ac_conv3x3_bn_relu_f16x2_gw")
+    if hook is not None:
+        hook("post", info)
+    return out
+
+
+def pack_conv_weight_f16x2_frag(w):
+    """OIHW f32 -> (fp16 hi + lo in the fragment order of pack_conv_weight_bf16x3_frag, inv_scale[Cout]).
+    Every output channel is first multiplied by the power of two that brings its largest |w| into [2^13, 2^14): the
+    lo parts (~2^-12 of the hi parts) are then normal fp16 numbers for every weight above 2^-15 of the channel maximum;
+    ``inv_scale`` (exact powers of two) goes into the BN scale of the epilogue."""
+    cout, cin = w.shape[0], w.shape[1]
+    amax = w.abs().amax(dim=(1, 2, 3)).clamp_min(1e-30)
+    e = 13 - torch.floor(torch.log2(amax))
+    ws = w * torch.exp2(e).view(-1, 1, 1, 1)
+    hi = ws.to(torch.float16)
+    lo = (ws - hi.float()).to(torch.float16)
+
+    def lay(t):
+        t = t.permute(1, 2, 3, 0).reshape(cin // 32, 2, 2, 8, 9, cout // 32, 32)
+        return t.permute(0, 4, 1, 5, 2, 6, 3).reshape(cin // 32, 9, 2, cout // 32, 64, 8)
+
+    return torch.stack([lay(hi), lay(lo)], dim=4).contiguous(), torch.exp2(-e).contiguous()
 
 
 def pack_conv_weight_bf16x3_frag(w):

@@ -332,7 +332,7 @@ def main():
     extra = {}
     if algo.startswith("bf16x3") and not args.no_f32_path:
         cnn = model.encoder.cnn
-        cnn.conv_algo, cnn._packed = "winograd", None
+        cnn.conv_algo = "winograd"
         run_steps(2)
         sync_all()
         f0 = time.perf_counter()

@@ -72,9 +72,22 @@ int ac_conv3x3_bn_relu_bf16x3(const float* in, const void* wpk, const float* sca
 int ac_conv3x3_bn_relu_bf16x3_gw(const float* in, const void* wfrag, const float* scale, const float* shift,
                                  float* out, int B, int Hp, int H, int W, int Cin, int Cout, int mode,
                                  int map_mode, void* stream);
+
+/* "f16x2" tier of the same kernel.  Activations live in HBM as fp16 (in: [B*Hp][W][Cin] fp16; out: fp16 for modes 0
+ * and 1, f32 for mode 2 = the attn_emb the rest of the path consumes), weights as fp16 hi + lo (2^-22) in the same
+ * fragment order, two fp16 MFMA products per f32 product, f32 accumulation, fp16 rounding (RNE, 2^-12 relative) once
+ * per stored activation.  The caller scales every output channel of the weights by a power of two before splitting
+ * (so the lo parts stay normal fp16 numbers) and multiplies `scale` by the inverse.  Same shape arguments and error
+ * codes as ac_conv3x3_bn_relu_bf16x3_gw.  Replaces the same reference code: ConvBlock.forward, cnn_encoder.py:318-338. */
+int ac_conv3x3_bn_relu_f16x2_gw(const void* in, const void* wfrag, const float* scale, const float* shift,
+                                void* out, int B, int Hp, int H, int W, int Cin, int Cout, int mode,
+                                int map_mode, void* stream);
 /* First conv (Cin = 1): in [B*Hp][64], w [64][9] (OIHW), out [B*Hp][64][64]. */
 int ac_conv3x3_first(const float* in, const float* w, const float* scale, const float* shift, float* out,
                      int B, int Hp, int H, int W, void* stream);
+/* The same with an fp16 output [B*Hp][64][64] (first layer of the "f16x2" tier). */
+int ac_conv3x3_first_f16(const float* in, const float* w, const float* scale, const float* shift, void* out,
+                         int B, int Hp, int H, int W, void* stream);
 
 /* ---- dense projection ---------------------------------------------------------------------------
  * Y[M,N] = act(X[M,K] W[N,K]^T + bias): every F.linear of the path (rnn_encoder.py:41 input

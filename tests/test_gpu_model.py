@@ -31,12 +31,12 @@ def _cnn_from_logmel(cnn, lms):
     x0 = torch.zeros(B, Hp[0], 64, device=lms.device)
     x0[:, :T] = lms.transpose(1, 2) * pk["bn0"][0] + pk["bn0"][1]
     x0 = x0.reshape(B * Hp[0], 64).contiguous()
-    full = torch.empty(B * Hp[0] * 64 * 64, device=lms.device)
-    pooled = torch.empty(B * Hp[1] * 32 * 64, device=lms.device)
+    act = torch.float16 if cnn.conv_algo == "f16x2" else torch.float32   # that tier keeps fp16 activations in HBM
+    full = torch.empty(B * Hp[0] * 64 * 64, device=lms.device, dtype=act)
+    pooled = torch.empty(B * Hp[1] * 32 * 64, device=lms.device, dtype=act)
     W = 64
-    from audiocaption_amd.cnn_encoder import CHANNELS
-    conv = {"winograd": K.conv3x3_bn_relu_winograd, "direct": K.conv3x3_bn_relu,
-            "bf16x3": K.conv3x3_bn_relu_bf16x3_gw, "bf16x3_lds": K.conv3x3_bn_relu_bf16x3}[cnn.conv_algo]
+    from audiocaption_amd.cnn_encoder import CHANNELS, conv_kernel
+    conv = conv_kernel(cnn.conv_algo)
     blocks = []
     for b in range(6):
         cin, cout = CHANNELS[b], CHANNELS[b + 1]
@@ -50,7 +50,7 @@ def _cnn_from_logmel(cnn, lms):
             conv(full, w2, s2, t2, pooled, B, Hp[b], H[b], W, cout, cout, 1)
             W //= 2
             blk = pooled[:B * Hp[b + 1] * W * cout].reshape(B, Hp[b + 1], W, cout)[:, :H[b + 1]]
-            blocks.append(blk.permute(0, 3, 1, 2).clone())  # (B, C, H, W) like the reference
+            blocks.append(blk.permute(0, 3, 1, 2).float().clone())  # (B, C, H, W) like the reference
         else:
             attn = torch.empty(B, H[5], cout, device=lms.device)
             conv(full, w2, s2, t2, attn, B, Hp[b], H[b], W, cout, cout, 2)
@@ -71,10 +71,11 @@ def test_g1_cnn14_vs_reference_golden(hip_model, golden_dir):
     assert _maxdiff("attn_emb", attn, g["attn_emb"]) < 2e-4
 
 
-@pytest.mark.parametrize("algo", ["direct", "winograd", "bf16x3", "bf16x3_lds"])
+@pytest.mark.parametrize("algo", ["direct", "winograd", "bf16x3", "bf16x3_lds", "f16x2"])
 def test_g1_cnn14_every_conv_algorithm(hip_model, golden_dir, algo):
     """Every conv kernel family against the reference's attn_emb (bar 2e-4 abs; f32 kernels land at ~5e-6,
-    the split-bf16 ones at ~2e-5)."""
+    the split-bf16 ones at ~2e-5; the fp16-activation tier "f16x2" has its own bar, 1e-3 = BASELINE.json's
+    bf16 tolerance, and lands at ~3e-4)."""
     from audiocaption_amd import procedural as P
     g = _load(golden_dir, "g1_cnn14.npz")
     cnn = hip_model.encoder.cnn
@@ -83,7 +84,7 @@ def test_g1_cnn14_every_conv_algorithm(hip_model, golden_dir, algo):
         cnn.conv_algo = algo
         lms = torch.from_numpy(P.synthetic_logmel(2, 1001)).cuda()
         attn, _ = _cnn_from_logmel(cnn, lms)
-        assert _maxdiff(f"attn_emb[{algo}]", attn, g["attn_emb"]) < 2e-4
+        assert _maxdiff(f"attn_emb[{algo}]", attn, g["attn_emb"]) < (1e-3 if algo == "f16x2" else 2e-4)
     finally:
         cnn.conv_algo = saved
         cnn._packed = None

@@ -53,11 +53,22 @@ def main():
             elif algo == "bf16x3":
                 wp = K.pack_conv_weight_bf16x3(w)
                 fn = lambda: K.conv3x3_bn_relu_bf16x3(x, wp, sc, sh, out, B, Hp, H, W, Cin, Cout, mode)
+            elif algo == "f16x2":
+                wp, inv = K.pack_conv_weight_f16x2_frag(w)
+                sc2 = (sc * inv).contiguous()
+                xh = x.half()
+                outh = out if mode == 2 else torch.empty_like(out, dtype=torch.float16)
+                fn = lambda: K.conv3x3_bn_relu_f16x2_gw(xh, wp, sc2, sh, outh, B, Hp, H, W, Cin, Cout, mode)
             else:
                 wp = K.pack_conv_weight_bf16x3_frag(w)
                 fn = lambda: K.conv3x3_bn_relu_bf16x3_gw(x, wp, sc, sh, out, B, Hp, H, W, Cin, Cout, mode)
             fn()
             torch.cuda.synchronize()
+            if algo == args.algos.split(",")[0]:
+                ref_out = out.clone()
+            else:
+                got = outh.float() if algo == "f16x2" else out
+                line += f" (maxdiff {float((got - ref_out).abs().max()):.1e})"
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             for _ in range(args.iters):
