@@ -477,11 +477,12 @@ __device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {
   return __builtin_bit_cast(unsigned, h);
 }
 
-template <int BN, int MODE, int PREC, int WM>
-__global__ __launch_bounds__(256, 3) void conv3x3_bf16x3_gw_kernel(ConvParams p) {
+template <int BN, int MODE, int PREC, int WM, int BM>
+__global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(ConvParams p) {
   // wave grid WM (pixel tiles) x WN (channel tiles); WM = 1 makes every wave walk all 128 pixels of the block for
   // 32 channels: half the weight-fragment bytes per MFMA (the L1/L2 stream that limits the two-product tier)
-  constexpr int WN = 4 / WM, MW = 4 / WM, NTW = (BN / 32) / WN;
+  // BM = pixels per block (128, or 256 for the wide early layers: MW doubles, the halo overhead shrinks)
+  constexpr int WN = 4 / WM, MW = (BM / 32) / WM, NTW = (BN / 32) / WN;
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm_raw[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -492,7 +493,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_bf16x3_gw_kernel(ConvParams p)
   int m_tile, n_tile;
   if (!conv_block_map(p, m_tile, n_tile)) return;
   const int TC = 1 << p.tc_log2;
-  const int TR = 128 >> p.tc_log2;
+  const int TR = BM >> p.tc_log2;
   const int PW = TC + 2, PH = TR + 2;
   const int NPIX = PW * PH;
   const int row0 = (m_tile / p.mt_cols) * TR;
@@ -544,7 +545,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_bf16x3_gw_kernel(ConvParams p)
     // 32-channel chunk and made the kernel's VALU time comparable to its MFMA time.
     // An item is 16 bytes of one pixel: 4 f32 channels (PREC 0) or 8 fp16 channels (PREC 1, copied as they are).
     constexpr int IPP = PREC == 0 ? 8 : 4;          // items per pixel and 32-channel chunk
-    constexpr int GW_MAXIT = PREC == 0 ? 9 : 5;     // >= ceil(MAX_NPIX * IPP / 256)
+    constexpr int GW_MAXIT = PREC == 0 ? 9 : (BM == 128 ? 5 : 6);   // >= ceil(max NPIX * IPP / 256); BM 256: TC = 16 only
     constexpr unsigned GW_NONE = 0xffffffffu, GW_OOB = 0x80000000u;
     unsigned goff[GW_MAXIT], loff[GW_MAXIT];
 #pragma unroll
@@ -580,6 +581,21 @@ __global__ __launch_bounds__(256, 3) void conv3x3_bf16x3_gw_kernel(ConvParams p)
         }
       }
     };
+    // PREC 1 has the registers to request the NEXT chunk's patch while the 9 taps of this one run (the fp16 items
+    // are copied as they are): the global-load latency leaves the two-barrier window between chunks.
+    u32x4 pre[PREC == 1 ? GW_MAXIT : 1];
+    auto patch_request = [&](int c) {
+#pragma unroll
+      for (int j = 0; j < GW_MAXIT; ++j) {
+        pre[j] = u32x4{0u, 0u, 0u, 0u};
+        if (loff[j] != GW_NONE && !(loff[j] & GW_OOB)) pre[j] = *(const u32x4*)((const _Float16*)p.in + (size_t)goff[j] + c * 32);
+      }
+    };
+    auto patch_commit = [&]() {
+#pragma unroll
+      for (int j = 0; j < GW_MAXIT; ++j)
+        if (loff[j] != GW_NONE) *(u32x4*)(sAh + (loff[j] & 0x7fffffffu)) = pre[j];
+    };
     const int total = nchunk * 9;
     bf16x8 wc[2][NTW][2], wnx[2][NTW][2];
     w_load(0, wc);
@@ -588,6 +604,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_bf16x3_gw_kernel(ConvParams p)
     int tap = 0, c = 0;
 #pragma unroll 1
     for (int it = 0; it < total; ++it) {
+      if (PREC == 1 && tap == 0 && c + 1 < nchunk) patch_request(c + 1);
       w_load(it + 1 < total ? it + 1 : it, wnx);
       const int ky = tap / 3, kx = tap - 3 * ky;
       const int aoff = ky * PITCH + kx * BROW;
@@ -624,7 +641,8 @@ __global__ __launch_bounds__(256, 3) void conv3x3_bf16x3_gw_kernel(ConvParams p)
         tap = 0;
         if (++c < nchunk) {
           __syncthreads();  // every wave is done with the patch of the previous chunk
-          stage_patch(c);
+          if (PREC == 1) patch_commit();
+          else stage_patch(c);
           __syncthreads();
         }
       }
@@ -633,16 +651,17 @@ __global__ __launch_bounds__(256, 3) void conv3x3_bf16x3_gw_kernel(ConvParams p)
   conv_epilogue<BN, MODE, MW, NTW, PREC == 1>(p, acc, n_tile, row0, col0, wm, wn, lane);
 }
 
-template <int BN, int MODE, int PREC = 0, int WM = 2>
-int launch_conv_bf16x3_gw(const ConvParams& p, hipStream_t s) {
+template <int BN, int MODE, int PREC = 0, int WM = 2, int BM = 128>
+int launch_conv_gw(ConvParams p, hipStream_t s) {
+  const int TC = 1 << p.tc_log2, TR = BM >> p.tc_log2;
+  p.MT = ((p.rows_total + TR - 1) / TR) * p.mt_cols;
   unsigned grid;
   if (p.map_mode == 2) grid = (unsigned)(((p.MT + 7) / 8) * 8 * p.NT);
   else if (p.map_mode == 3) grid = (unsigned)(((p.MT + 8 / p.NT - 1) / (8 / p.NT)) * 8);
   else grid = (unsigned)(p.MT * p.NT);
-  const int TC = 1 << p.tc_log2, TR = 128 >> p.tc_log2;
   const int pitch = (TC + 2) * BROW + patch_row_pad_slots(TC) * 8;
   const size_t lds = (size_t)(TR + 2) * pitch * 2 * (PREC == 0 ? 2 : 1);  // hi + lo planes (bf16) or one fp16 plane
-  hipLaunchKernelGGL((conv3x3_bf16x3_gw_kernel<BN, MODE, PREC, WM>), dim3(grid), dim3(256), lds, s, p);
+  hipLaunchKernelGGL((conv3x3_gw_kernel<BN, MODE, PREC, WM, BM>), dim3(grid), dim3(256), lds, s, p);
   return ac_check_launch();
 }
 
@@ -844,33 +863,32 @@ static int conv_gw_dispatch(int prec, const float* in, const void* wfrag, const 
   hipStream_t s = (hipStream_t)stream;
   if (prec == 0) {
     if (BN == 128) {
-      if (getenv("AC_GW_WM1")) {
-        if (mode == MODE_FULL) return launch_conv_bf16x3_gw<128, MODE_FULL, 0, 1>(p, s);
-        if (mode == MODE_POOL) return launch_conv_bf16x3_gw<128, MODE_POOL, 0, 1>(p, s);
-        return launch_conv_bf16x3_gw<128, MODE_MEANW, 0, 1>(p, s);
-      }
-      if (mode == MODE_FULL) return launch_conv_bf16x3_gw<128, MODE_FULL>(p, s);
-      if (mode == MODE_POOL) return launch_conv_bf16x3_gw<128, MODE_POOL>(p, s);
-      return launch_conv_bf16x3_gw<128, MODE_MEANW>(p, s);
+      if (mode == MODE_FULL) return launch_conv_gw<128, MODE_FULL>(p, s);
+      if (mode == MODE_POOL) return launch_conv_gw<128, MODE_POOL>(p, s);
+      return launch_conv_gw<128, MODE_MEANW>(p, s);
     } else {
-      if (mode == MODE_FULL) return launch_conv_bf16x3_gw<64, MODE_FULL>(p, s);
-      if (mode == MODE_POOL) return launch_conv_bf16x3_gw<64, MODE_POOL>(p, s);
-      return launch_conv_bf16x3_gw<64, MODE_MEANW>(p, s);
+      if (mode == MODE_FULL) return launch_conv_gw<64, MODE_FULL>(p, s);
+      if (mode == MODE_POOL) return launch_conv_gw<64, MODE_POOL>(p, s);
+      return launch_conv_gw<64, MODE_MEANW>(p, s);
     }
   }
+  static const int bm256 = getenv("AC_GW_BM256") ? atoi(getenv("AC_GW_BM256")) : 1;   // bit 0: Cout 64, bit 1: Cout >= 128
   if (BN == 128) {
-    if (getenv("AC_GW_WM2")) {
-      if (mode == MODE_FULL) return launch_conv_bf16x3_gw<128, MODE_FULL, 1>(p, s);
-      if (mode == MODE_POOL) return launch_conv_bf16x3_gw<128, MODE_POOL, 1>(p, s);
-      return launch_conv_bf16x3_gw<128, MODE_MEANW, 1>(p, s);
+    if (TC == 16 && (bm256 & 2)) {
+      if (mode == MODE_FULL) return launch_conv_gw<128, MODE_FULL, 1, 2, 256>(p, s);
+      if (mode == MODE_POOL) return launch_conv_gw<128, MODE_POOL, 1, 2, 256>(p, s);
     }
-    if (mode == MODE_FULL) return launch_conv_bf16x3_gw<128, MODE_FULL, 1, 1>(p, s);
-    if (mode == MODE_POOL) return launch_conv_bf16x3_gw<128, MODE_POOL, 1, 1>(p, s);
-    return launch_conv_bf16x3_gw<128, MODE_MEANW, 1, 1>(p, s);
+    if (mode == MODE_FULL) return launch_conv_gw<128, MODE_FULL, 1, 1>(p, s);
+    if (mode == MODE_POOL) return launch_conv_gw<128, MODE_POOL, 1, 1>(p, s);
+    return launch_conv_gw<128, MODE_MEANW, 1, 1>(p, s);
   } else {
-    if (mode == MODE_FULL) return launch_conv_bf16x3_gw<64, MODE_FULL, 1>(p, s);
-    if (mode == MODE_POOL) return launch_conv_bf16x3_gw<64, MODE_POOL, 1>(p, s);
-    return launch_conv_bf16x3_gw<64, MODE_MEANW, 1>(p, s);
+    if (TC == 16 && (bm256 & 1)) {
+      if (mode == MODE_FULL) return launch_conv_gw<64, MODE_FULL, 1, 2, 256>(p, s);
+      if (mode == MODE_POOL) return launch_conv_gw<64, MODE_POOL, 1, 2, 256>(p, s);
+    }
+    if (mode == MODE_FULL) return launch_conv_gw<64, MODE_FULL, 1>(p, s);
+    if (mode == MODE_POOL) return launch_conv_gw<64, MODE_POOL, 1>(p, s);
+    return launch_conv_gw<64, MODE_MEANW, 1>(p, s);
   }
 }
 

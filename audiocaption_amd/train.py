@@ -345,7 +345,7 @@ class TrainEngine:
             cnn_attn = st["cnn_attn_in"]
         else:
             cnn_attn = enc.cnn.encode(st["wav"], dropout=(p_cnn, OP_CNN_BLOCK, self._seed_ptr) if p_cnn > 0 else None,
-                                      specaug=st["specaug"])
+                                      specaug=st["specaug"], train=True)
         st["cnn_attn"] = cnn_attn
         Cin = cnn_attn.shape[2]
 
