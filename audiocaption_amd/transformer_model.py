@@ -131,7 +131,11 @@ class TransformerModel(CaptionModel):
             raise NotImplementedError("forward_async: greedy inference only; use model(input_dict) otherwise")
         dev = input_dict["wav"].device
         if self._streams is None or self._streams[0].device != dev:
-            self._streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+            import os
+            prio = int(os.environ.get("AUDIOCAPTION_DEC_PRIORITY", "-1"))
+            # the decode chain is latency-bound and tiny: on a high-priority queue its workgroups take the next free
+            # slots instead of queueing behind the thousands of conv workgroups of the following batch
+            self._streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev, priority=prio))
         enc_s, dec_s = self._streams
         cur = torch.cuda.current_stream(dev)
         enc_s.wait_stream(cur)  # inputs produced on the caller's stream
