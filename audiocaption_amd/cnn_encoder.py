@@ -173,30 +173,43 @@ class Cnn14Encoder(nn.Module):
         # the "f16x2" tier keeps its activations in HBM as fp16; the train-mode forward (dropout on f32 block outputs,
         # parity pinned by tests/golden/g8_train.npz) stays on the split-bf16 tier
         algo = "bf16x3" if (self.conv_algo == "f16x2" and (train or dropout is not None)) else self.conv_algo
-        act = torch.float16 if algo == "f16x2" else torch.float32
         pk = self._pack(dev, algo)
         B, L = wav.shape
         T, H, Hp = self.geometry(L)
         x0 = K.logmel(wav, self._tables, pk["bn0"][0], pk["bn0"][1], rows_per_clip=Hp[0], channels_last=True)
         if specaug is not None:
             K.specaug_(x0, specaug, pk["bn0"][1], B, Hp[0], T)
+        return self.conv_stack(x0, B, H, Hp, pk, algo, dropout)
+
+    def conv_stack(self, x0, B, H, Hp, pk, algo, dropout=None, blocks=None):
+        """The six conv blocks on a bn0-normalised log-mel x0 [B*Hp[0]][64] -> attn_emb (B, H[5], 2048).
+        ``blocks``: a list that receives a float32 (B, C, H, W) copy of every pooled block output (tests)."""
+        dev = x0.device
+        act = torch.float16 if algo == "f16x2" else torch.float32
         full = self._buf("full", B * Hp[0] * 64 * 64, dev, act)      # conv1 outputs (largest: level 1)
         pooled = self._buf("pooled", B * Hp[1] * 32 * 64, dev, act)  # block outputs (largest: block 1)
         W = 64
         conv = conv_kernel(algo)
+        fuse1 = algo == "f16x2" and os.environ.get("AUDIOCAPTION_FUSE_BLOCK1", "1") != "0"
         for b in range(6):
             cin, cout = CHANNELS[b], CHANNELS[b + 1]
             w1, s1, t1 = pk["convs"][2 * b]
             w2, s2, t2 = pk["convs"][2 * b + 1]
-            if b == 0:
+            if b == 0 and fuse1:   # conv1 is computed inside conv2's kernel: its 64-channel output never reaches HBM
+                K.conv3x3_block1_f16x2(x0, w1, s1, t1, w2, s2, t2, pooled, B, Hp[0], H[0], W)
+            elif b == 0:
                 K.conv3x3_first(x0, w1, s1, t1, full, B, Hp[0], H[0], W)
             else:
                 conv(pooled, w1, s1, t1, full, B, Hp[b], H[b], W, cin, cout, 0)
             if b < 5:
-                conv(full, w2, s2, t2, pooled, B, Hp[b], H[b], W, cout, cout, 1)
+                if not (b == 0 and fuse1):
+                    conv(full, w2, s2, t2, pooled, B, Hp[b], H[b], W, cout, cout, 1)
                 W //= 2
                 if dropout is not None:
                     K.dropout_(pooled, B * Hp[b + 1] * W * cout, dropout[0], dropout[1] + b, dropout[2])
+                if blocks is not None:
+                    blk = pooled[:B * Hp[b + 1] * W * cout].reshape(B, Hp[b + 1], W, cout)[:, :H[b + 1]]
+                    blocks.append(blk.permute(0, 3, 1, 2).float().clone())
             else:
                 attn = torch.empty(B, H[5], cout, device=dev, dtype=torch.float32)
                 if dropout is None:

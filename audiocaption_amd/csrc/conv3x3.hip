@@ -37,6 +37,11 @@ struct ConvParams {
   int tc_log2, mt_cols, MT, NT;
   int Hp_out, H_out, W_out;
   int map_mode;
+  // fused first layer (conv3x3_gw_kernel<..., FUSE1>): the 1-channel input and conv1's weights / folded BN
+  const float* in1;
+  const float* w1;
+  const float* sc1;
+  const float* sh1;
 };
 
 enum { MODE_FULL = 0, MODE_POOL = 1, MODE_MEANW = 2 };
@@ -477,8 +482,13 @@ __device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {
   return __builtin_bit_cast(unsigned, h);
 }
 
-template <int BN, int MODE, int PREC, int WM, int BM>
+template <int BN, int MODE, int PREC, int WM, int BM, bool FUSE1>
 __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(ConvParams p) {
+  // FUSE1 (block 1 of the f16x2 tier: Cin = Cout = 64, W = 64, 256-pixel blocks): the input of this convolution is
+  // itself conv1 + BN + ReLU of the 1-channel log-mel.  Instead of reading it from HBM (0.5 GB written by a separate
+  // kernel, 0.7 GB read back with the halo) the workgroup computes its 18x18x64 patch from a 20x20 patch of the
+  // log-mel: 81 FMAs per staged fp16 item on the vector ALUs, under the other workgroups' MFMAs.  Both 32-channel
+  // chunks are staged up front (two LDS planes), so the 18 tap iterations run without a barrier.
   // wave grid WM (pixel tiles) x WN (channel tiles); WM = 1 makes every wave walk all 128 pixels of the block for
   // 32 channels: half the weight-fragment bytes per MFMA (the L1/L2 stream that limits the two-product tier)
   // BM = pixels per block (128, or 256 for the wide early layers: MW doubles, the halo overhead shrinks)
@@ -501,7 +511,7 @@ __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(Conv
   const int PITCH = PW * BROW + patch_row_pad_slots(TC) * 8;
   const int PLANE = PH * PITCH;
   __bf16* sAh = (__bf16*)dsm_raw;
-  __bf16* sAl = sAh + PLANE;
+  __bf16* sAl = sAh + PLANE;   // PREC 0: the lo plane; FUSE1: the plane of the second channel chunk
 
   const int QR2 = 32 >> p.tc_log2;
   int pbase[MW];
@@ -557,8 +567,10 @@ __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(Conv
         const int pix = idx / IPP, ci = idx % IPP;
         const int pr = pix / PW, pc = pix - pr * PW;
         const int gr = row0 - 1 + pr, gc = col0 - 1 + pc;
-        const bool ok = gr >= 0 && gr < p.rows_total && gc >= 0 && gc < p.W;
+        bool ok = gr >= 0 && gr < p.rows_total && gc >= 0 && gc < p.W;
+        if (FUSE1) ok = ok && (gr % p.Hp) < p.H;   // conv1 writes zeros on the padding rows of a clip
         goff[j] = ok ? (unsigned)(((size_t)gr * p.W + gc) * p.Cin + ci * (32 / IPP)) : 0u;
+        if (FUSE1) goff[j] = (unsigned)(pr * 21 + pc);   // top-left of the pixel's 3x3 window in the log-mel patch
         loff[j] = (unsigned)(pr * PITCH + pc * BROW + ci * (32 / IPP)) | (ok ? 0u : GW_OOB);
       }
     }
@@ -599,15 +611,63 @@ __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(Conv
     const int total = nchunk * 9;
     bf16x8 wc[2][NTW][2], wnx[2][NTW][2];
     w_load(0, wc);
-    stage_patch(0);
+    if (FUSE1) {
+      float* s1 = (float*)(sAh + 2 * PLANE);   // [TR + 4][21]: log-mel rows row0-2.., columns col0-2..
+      const int S1W = TC + 4, S1H = TR + 4;
+      for (int idx = tid; idx < S1W * S1H; idx += 256) {
+        const int pr = idx / S1W, pc = idx - pr * S1W;
+        const int gr = row0 - 2 + pr, gc = col0 - 2 + pc;
+        float v = 0.f;
+        if (gr >= 0 && gr < p.rows_total && gc >= 0 && gc < p.W) v = p.in1[(size_t)gr * p.W + gc];
+        s1[pr * 21 + pc] = v;
+      }
+      __syncthreads();
+#pragma unroll 1
+      for (int c1 = 0; c1 < 2; ++c1) {
+        const int ch0 = c1 * 32 + (tid & 3) * 8;   // an item's channel octet is tid % 4 for every j (256 % IPP == 0)
+        float w1r[8][9], sc[8], sh[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          sc[e] = p.sc1[ch0 + e];
+          sh[e] = p.sh1[ch0 + e];
+#pragma unroll
+          for (int t = 0; t < 9; ++t) w1r[e][t] = p.w1[(ch0 + e) * 9 + t];
+        }
+#pragma unroll
+        for (int j = 0; j < GW_MAXIT; ++j) {
+          if (loff[j] == GW_NONE) continue;
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if (!(loff[j] & GW_OOB)) {
+            float x[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) x[t] = s1[goff[j] + (t / 3) * 21 + (t % 3)];
+            float y[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float a = 0.f;
+#pragma unroll
+              for (int t = 0; t < 9; ++t) a = fmaf(x[t], w1r[e][t], a);
+              y[e] = fmaxf(fmaf(a, sc[e], sh[e]), 0.f);
+            }
+            v[0] = cvt_pk_f16(y[0], y[1]);
+            v[1] = cvt_pk_f16(y[2], y[3]);
+            v[2] = cvt_pk_f16(y[4], y[5]);
+            v[3] = cvt_pk_f16(y[6], y[7]);
+          }
+          *(u32x4*)(sAh + c1 * PLANE + (loff[j] & 0x7fffffffu)) = v;
+        }
+      }
+    } else {
+      stage_patch(0);
+    }
     __syncthreads();
     int tap = 0, c = 0;
 #pragma unroll 1
     for (int it = 0; it < total; ++it) {
-      if (PREC == 1 && tap == 0 && c + 1 < nchunk) patch_request(c + 1);
+      if (PREC == 1 && !FUSE1 && tap == 0 && c + 1 < nchunk) patch_request(c + 1);
       w_load(it + 1 < total ? it + 1 : it, wnx);
       const int ky = tap / 3, kx = tap - 3 * ky;
-      const int aoff = ky * PITCH + kx * BROW;
+      const int aoff = ky * PITCH + kx * BROW + (FUSE1 ? c * PLANE : 0);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8 ah[MW], al[MW];
@@ -639,7 +699,7 @@ __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(Conv
           for (int pl = 0; pl < 2; ++pl) wc[ks][n][pl] = wnx[ks][n][pl];
       if (++tap == 9) {
         tap = 0;
-        if (++c < nchunk) {
+        if (++c < nchunk && !FUSE1) {
           __syncthreads();  // every wave is done with the patch of the previous chunk
           if (PREC == 1) patch_commit();
           else stage_patch(c);
@@ -651,7 +711,7 @@ __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(Conv
   conv_epilogue<BN, MODE, MW, NTW, PREC == 1>(p, acc, n_tile, row0, col0, wm, wn, lane);
 }
 
-template <int BN, int MODE, int PREC = 0, int WM = 2, int BM = 128>
+template <int BN, int MODE, int PREC = 0, int WM = 2, int BM = 128, bool FUSE1 = false>
 int launch_conv_gw(ConvParams p, hipStream_t s) {
   const int TC = 1 << p.tc_log2, TR = BM >> p.tc_log2;
   p.MT = ((p.rows_total + TR - 1) / TR) * p.mt_cols;
@@ -660,8 +720,9 @@ int launch_conv_gw(ConvParams p, hipStream_t s) {
   else if (p.map_mode == 3) grid = (unsigned)(((p.MT + 8 / p.NT - 1) / (8 / p.NT)) * 8);
   else grid = (unsigned)(p.MT * p.NT);
   const int pitch = (TC + 2) * BROW + patch_row_pad_slots(TC) * 8;
-  const size_t lds = (size_t)(TR + 2) * pitch * 2 * (PREC == 0 ? 2 : 1);  // hi + lo planes (bf16) or one fp16 plane
-  hipLaunchKernelGGL((conv3x3_gw_kernel<BN, MODE, PREC, WM, BM>), dim3(grid), dim3(256), lds, s, p);
+  // hi + lo planes (bf16), one fp16 plane, or (FUSE1) two fp16 planes + the log-mel patch
+  const size_t lds = (size_t)(TR + 2) * pitch * 2 * ((PREC == 0 || FUSE1) ? 2 : 1) + (FUSE1 ? (TR + 4) * 21 * 4 : 0);
+  hipLaunchKernelGGL((conv3x3_gw_kernel<BN, MODE, PREC, WM, BM, FUSE1>), dim3(grid), dim3(256), lds, s, p);
   return ac_check_launch();
 }
 
@@ -902,6 +963,26 @@ extern "C" int ac_conv3x3_bn_relu_f16x2_gw(const void* in, const void* wfrag, co
                                            void* out, int B, int Hp, int H, int W, int Cin, int Cout, int mode,
                                            int map_mode, void* stream) {
   return conv_gw_dispatch(1, (const float*)in, wfrag, scale, shift, (float*)out, B, Hp, H, W, Cin, Cout, mode, map_mode, stream);
+}
+
+// Block 1 of the f16x2 tier in one kernel: conv1 (Cin = 1) + BN + ReLU computed into the patch, conv2 + BN + ReLU +
+// 2x2 pool on the matrix cores.  in1 [B*Hp][64] f32 log-mel, out [B*Hp/2][32][64] fp16.
+extern "C" int ac_conv3x3_block1_f16x2(const float* in1, const float* w1, const float* scale1, const float* shift1,
+                                       const void* wfrag2, const float* scale2, const float* shift2, void* out,
+                                       int B, int Hp, int H, int W, void* stream) {
+  if (!in1 || !w1 || !scale1 || !shift1 || !wfrag2 || !scale2 || !shift2 || !out) return AC_ERR_ARG;
+  if (B <= 0 || Hp <= H || (Hp & 1) || W != 64) return AC_ERR_ARG;
+  ConvParams p;
+  p.in = nullptr; p.wpk = (const float*)wfrag2; p.scale = scale2; p.shift = shift2; p.out = (float*)out;
+  p.in1 = in1; p.w1 = w1; p.sc1 = scale1; p.sh1 = shift1;
+  p.rows_total = B * Hp; p.Hp = Hp; p.H = H; p.W = W; p.Cin = 64; p.Cout = 64;
+  p.tc_log2 = 4;
+  p.mt_cols = W / 16;
+  p.MT = 0;   // set by the launcher from the block height
+  p.NT = 1;
+  p.Hp_out = Hp / 2; p.H_out = H / 2; p.W_out = W / 2;
+  p.map_mode = 2;
+  return launch_conv_gw<64, MODE_POOL, 1, 2, 256, true>(p, (hipStream_t)stream);
 }
 
 extern "C" int ac_conv3x3_first(const float* in, const float* w, const float* scale, const float* shift,

@@ -49,6 +49,16 @@ def conv3x3_first(x, w, scale, shift, out, B, Hp, H, W=64):
     return out
 
 
+def conv3x3_block1_f16x2(x0, w1, scale1, shift1, wfrag2, scale2, shift2, out, B, Hp, H, W=64):
+    """conv_block1 of the "f16x2" tier in one launch (conv1 computed into conv2's patch); out fp16."""
+    lib = _lib.load()
+    if out.dtype != torch.float16:
+        raise ValueError("conv3x3_block1_f16x2 writes fp16")
+    check(lib.ac_conv3x3_block1_f16x2(ptr(x0), ptr(w1), ptr(scale1), ptr(shift1), ptr(wfrag2), ptr(scale2),
+                                      ptr(shift2), ptr(out), B, Hp, H, W, stream()), "ac_conv3x3_block1_f16x2")
+    return out
+
+
 # Optional per-launch observer used by bench.py to time the dominant kernel with HIP events on the
 # launch stream: called as hook(phase, info) with phase "pre"/"post" around every MFMA conv launch.
 CONV_LAUNCH_HOOK = None

@@ -82,6 +82,14 @@ int ac_conv3x3_bn_relu_bf16x3_gw(const float* in, const void* wfrag, const float
 int ac_conv3x3_bn_relu_f16x2_gw(const void* in, const void* wfrag, const float* scale, const float* shift,
                                 void* out, int B, int Hp, int H, int W, int Cin, int Cout, int mode,
                                 int map_mode, void* stream);
+/* Block 1 of the "f16x2" tier in one kernel: conv1 (Cin = 1) + BN + ReLU is computed straight into the LDS patch of
+ * conv2 (the 64-channel intermediate never exists in HBM), conv2 + BN + ReLU + 2x2 average pool on the matrix cores.
+ * in1 [B*Hp][64] f32 (log-mel after bn0), w1 [64][9], wfrag2 as for ac_conv3x3_bn_relu_f16x2_gw (Cin = Cout = 64),
+ * out [B*Hp/2][32][64] fp16.  Replaces ConvBlock.forward of conv_block1, cnn_encoder.py:318-338 / :431. */
+int ac_conv3x3_block1_f16x2(const float* in1, const float* w1, const float* scale1, const float* shift1,
+                            const void* wfrag2, const float* scale2, const float* shift2, void* out,
+                            int B, int Hp, int H, int W, void* stream);
+
 /* First conv (Cin = 1): in [B*Hp][64], w [64][9] (OIHW), out [B*Hp][64][64]. */
 int ac_conv3x3_first(const float* in, const float* w, const float* scale, const float* shift, float* out,
                      int B, int Hp, int H, int W, void* stream);

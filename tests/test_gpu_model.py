@@ -21,39 +21,18 @@ def _maxdiff(name, got, want):
 
 
 def _cnn_from_logmel(cnn, lms):
-    """Run the HIP conv stack from a given log-mel (B, 64, T): bn0 is applied here with torch so that the
-    golden (which starts downstream of the un-pinned mel front-end) can be checked in isolation."""
-    from audiocaption_amd import kernels as K
-    pk = cnn._pack(lms.device)
+    """Run the product's conv stack (Cnn14Encoder.conv_stack) from a given log-mel (B, 64, T): bn0 is applied here with
+    torch so that the golden (which starts downstream of the un-pinned mel front-end) can be checked in isolation."""
+    algo = cnn.conv_algo
+    pk = cnn._pack(lms.device, algo)
     B, _, T = lms.shape
     H = [T >> k for k in range(6)]
     Hp = cnn.geometry((T - 1) * cnn.hop_length)[2]
     x0 = torch.zeros(B, Hp[0], 64, device=lms.device)
     x0[:, :T] = lms.transpose(1, 2) * pk["bn0"][0] + pk["bn0"][1]
     x0 = x0.reshape(B * Hp[0], 64).contiguous()
-    act = torch.float16 if cnn.conv_algo == "f16x2" else torch.float32   # that tier keeps fp16 activations in HBM
-    full = torch.empty(B * Hp[0] * 64 * 64, device=lms.device, dtype=act)
-    pooled = torch.empty(B * Hp[1] * 32 * 64, device=lms.device, dtype=act)
-    W = 64
-    from audiocaption_amd.cnn_encoder import CHANNELS, conv_kernel
-    conv = conv_kernel(cnn.conv_algo)
     blocks = []
-    for b in range(6):
-        cin, cout = CHANNELS[b], CHANNELS[b + 1]
-        w1, s1, t1 = pk["convs"][2 * b]
-        w2, s2, t2 = pk["convs"][2 * b + 1]
-        if b == 0:
-            K.conv3x3_first(x0, w1, s1, t1, full, B, Hp[0], H[0], W)
-        else:
-            conv(pooled, w1, s1, t1, full, B, Hp[b], H[b], W, cin, cout, 0)
-        if b < 5:
-            conv(full, w2, s2, t2, pooled, B, Hp[b], H[b], W, cout, cout, 1)
-            W //= 2
-            blk = pooled[:B * Hp[b + 1] * W * cout].reshape(B, Hp[b + 1], W, cout)[:, :H[b + 1]]
-            blocks.append(blk.permute(0, 3, 1, 2).float().clone())  # (B, C, H, W) like the reference
-        else:
-            attn = torch.empty(B, H[5], cout, device=lms.device)
-            conv(full, w2, s2, t2, attn, B, Hp[b], H[b], W, cout, cout, 2)
+    attn = cnn.conv_stack(x0, B, H, Hp, pk, algo, blocks=blocks)
     return attn, blocks
 
 
@@ -94,6 +73,26 @@ def test_g1_cnn14_vs_reference_golden(hip_model, golden_dir, conv_tier):
     assert _maxdiff("attn_emb", attn, g["attn_emb"]) < tol["attn_golden"]
 
 
+def test_f16x2_fused_block1_equals_two_kernels(hip_model, monkeypatch):
+    """The fused first block (conv1 computed inside conv2's kernel) against conv_first + conv2 as two launches: the same
+    fp16 roundings in the same places, so only the f32 summation order of conv1 may differ (it does not: both are the
+    same 9-term fmaf chain) - bit-identical pooled output, ragged rows included."""
+    from audiocaption_amd import procedural as P
+    cnn = hip_model.encoder.cnn
+    saved = cnn.conv_algo
+    cnn.conv_algo = "f16x2"
+    try:
+        lms = torch.from_numpy(P.synthetic_logmel(3, 701)).cuda()
+        monkeypatch.setenv("AUDIOCAPTION_FUSE_BLOCK1", "1")
+        attn_f, blocks_f = _cnn_from_logmel(cnn, lms)
+        monkeypatch.setenv("AUDIOCAPTION_FUSE_BLOCK1", "0")
+        attn_2, blocks_2 = _cnn_from_logmel(cnn, lms)
+        assert torch.equal(blocks_f[0], blocks_2[0])
+        assert torch.equal(attn_f, attn_2)
+    finally:
+        cnn.conv_algo = saved
+
+
 @pytest.mark.parametrize("algo", ["direct", "winograd", "bf16x3", "bf16x3_lds", "f16x2"])
 def test_g1_cnn14_every_conv_algorithm(hip_model, golden_dir, algo):
     """Every conv kernel family against the reference's attn_emb (bar 2e-4 abs; f32 kernels land at ~5e-6,
@@ -110,7 +109,6 @@ def test_g1_cnn14_every_conv_algorithm(hip_model, golden_dir, algo):
         assert _maxdiff(f"attn_emb[{algo}]", attn, g["attn_emb"]) < (1e-3 if algo == "f16x2" else 2e-4)
     finally:
         cnn.conv_algo = saved
-        cnn._packed = None
 
 
 def test_g2_gru_vs_reference_golden(hip_model, golden_dir):
