@@ -145,6 +145,39 @@ def test_pack_conv_weight_layout():
     assert p[1, 5, 77, 3] == w[77, 35, 1, 2]  # chunk 1, tap ky=1,kx=2, cout 77, cin 32+3
 
 
+def test_pack_conv_weight_fragment_layouts_and_fp16_split():
+    """Host side of the two half-precision conv tiers: the MFMA fragment order (lane = cout % 32 + 32 * ((cin % 16)
+    // 8), element = cin % 8) and the fp16 hi + lo split with its per-channel power-of-two scale."""
+    from audiocaption_amd.kernels import pack_conv_weight_bf16x3_frag, pack_conv_weight_f16x2_frag
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(128, 64, 3, 3, generator=g) * torch.logspace(-4, 0, 128).view(-1, 1, 1, 1)   # channel scales 1e-4..1
+    pb = pack_conv_weight_bf16x3_frag(w)
+    pf, inv = pack_conv_weight_f16x2_frag(w)
+    assert pb.shape == pf.shape == (2, 9, 2, 4, 2, 64, 8) and pb.dtype == torch.bfloat16 and pf.dtype == torch.float16
+    for (c, tap, ks, nt, lane, e) in [(0, 0, 0, 0, 0, 0), (1, 5, 1, 3, 45, 6), (1, 8, 0, 2, 63, 7), (0, 4, 1, 1, 31, 3)]:
+        cout, cin = nt * 32 + lane % 32, c * 32 + ks * 16 + (lane // 32) * 8 + e
+        ref = w[cout, cin, tap // 3, tap % 3]
+        assert float(pb[c, tap, ks, nt, 0, lane, e].float() + pb[c, tap, ks, nt, 1, lane, e].float()) == \
+            pytest.approx(float(ref), rel=2 ** -15)
+        got = (pf[c, tap, ks, nt, 0, lane, e].double() + pf[c, tap, ks, nt, 1, lane, e].double()) * inv[cout].double()
+        assert float(got) == pytest.approx(float(ref), rel=0, abs=float(w[cout].abs().max()) * 2 ** -21)
+    # the scales are exact powers of two that bring every channel's largest weight into [2^13, 2^14)
+    m, ex = torch.frexp(inv)
+    assert torch.all(m == 0.5)
+    top = (w.abs().amax(dim=(1, 2, 3)) / inv)
+    assert torch.all(top >= 2 ** 13) and torch.all(top < 2 ** 14)
+    # no lo part is flushed: every weight above 2^-9 of its channel maximum keeps >= 20 significant bits
+    full = (pf[..., 0, :, :].double() + pf[..., 1, :, :].double())
+    assert torch.isfinite(full).all() and float(pf[..., 0, :, :].abs().max()) < 65504
+
+
+def test_f16x2_argument_validation_without_gpu(lib_path):
+    lib = _lib.load()
+    assert lib.ac_conv3x3_bn_relu_f16x2_gw(None, None, None, None, None, 1, 8, 4, 16, 32, 64, 0, -1, None) == -1
+    assert lib.ac_conv3x3_first_f16(None, None, None, None, None, 1, 8, 4, 64, None) == -1
+    assert lib.ac_conv3x3_block1_f16x2(None, None, None, None, None, None, None, None, 1, 8, 4, 64, None) == -1
+
+
 def test_compat_install_resolves_reference_dotted_paths():
     import importlib
     import sys
