@@ -15,6 +15,8 @@ call per step (the reference loops over clips, base.py:266) with the reference's
 device->host copy per step.
 """
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 
@@ -99,17 +101,22 @@ class PendingCaption:
     """Handle of a batch submitted with ``TransformerModel.forward_async``: ``result()`` blocks until the
     batch's token ids have reached the host and returns the same dict ``model(input_dict)`` would."""
 
-    def __init__(self, done_event, host_seq, host_logprob, output):
-        self._done, self._seq, self._lp, self._out = done_event, host_seq, host_logprob, output
+    def __init__(self, model=None):
+        self._model = model
+        self._done = self._seq = self._lp = self._out = self._release = None
+
+    def _fill(self, done_event, host_seq, host_logprob, output, release):
+        self._done, self._seq, self._lp, self._out, self._release = done_event, host_seq, host_logprob, output, release
 
     def result(self):
+        if self._done is None:          # still waiting for a partner batch (pair decode): decode it on its own now
+            self._model._flush_held()
         self._done.synchronize()
         out = dict(self._out)
         out["seq"] = self._seq.clone()
         out["sampled_logprob"] = self._lp.clone()
-        release = getattr(self, "_release", None)
-        if release is not None:  # hand the pinned staging buffers back to the pool
-            release()
+        if self._release is not None:  # hand the pinned staging buffers back to the pool
+            self._release()
             self._release = None
         return out
 
@@ -120,22 +127,26 @@ class TransformerModel(CaptionModel):
         super().__init__(encoder, decoder, **kwargs)
         self._streams = None
         self._pinned = {}
+        self._held = None   # forward_async: a submitted batch whose decode waits for a partner batch
 
     # ---- throughput mode: encoder of batch i+1 overlaps the (latency-bound) decode of batch i ---------
-    def forward_async(self, input_dict):
+    def forward_async(self, input_dict, pair=None):
         """Submit one greedy-decoding batch without waiting for it.  The encoder runs on one HIP stream, the
         decoder (a chain of ~370 tiny latency-bound kernels) on another, so consecutive submissions overlap:
         the decode of batch i fills the gaps of the matrix-bound encoder of batch i+1.  Results are identical
-        to ``model(input_dict)``; only the schedule differs.  Returns a ``PendingCaption``."""
+        to ``model(input_dict)``; only the schedule differs.  Returns a ``PendingCaption``.
+
+        ``pair`` (default: AUDIOCAPTION_PAIR_DECODE, on): the decode chain costs the same for 128 rows as for 64 - it
+        is a latency chain - and while it runs it takes workgroup slots from the encoder.  So a batch waits for the
+        next submission of the same shape and the two are decoded as ONE chain (rows are independent: same tokens,
+        same logits); a batch without a partner is decoded on its own as soon as its ``result()`` is asked for."""
         if input_dict.get("mode") != "inference" or input_dict.get("sample_method", "greedy") != "greedy":
             raise NotImplementedError("forward_async: greedy inference only; use model(input_dict) otherwise")
+        if pair is None:
+            pair = os.environ.get("AUDIOCAPTION_PAIR_DECODE", "1") != "0"
         dev = input_dict["wav"].device
         if self._streams is None or self._streams[0].device != dev:
-            import os
-            prio = int(os.environ.get("AUDIOCAPTION_DEC_PRIORITY", "-1"))
-            # the decode chain is latency-bound and tiny: on a high-priority queue its workgroups take the next free
-            # slots instead of queueing behind the thousands of conv workgroups of the following batch
-            self._streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev, priority=prio))
+            self._streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
         enc_s, dec_s = self._streams
         cur = torch.cuda.current_stream(dev)
         enc_s.wait_stream(cur)  # inputs produced on the caller's stream
@@ -144,29 +155,68 @@ class TransformerModel(CaptionModel):
             enc_done = torch.cuda.Event()
             enc_done.record(enc_s)
         max_length = int(input_dict.get("max_length", self.max_length))
-        B = enc["attn_emb"].shape[0]
+        item = (PendingCaption(self), enc, enc_done, max_length)
+        held = self._held
+        if held is not None:
+            self._held = None
+            same = (held[3] == max_length and held[1]["attn_emb"].shape == enc["attn_emb"].shape
+                    and held[1]["attn_emb"].device == enc["attn_emb"].device)
+            if pair and same:
+                self._decode_group([held, item])
+                return item[0]
+            self._decode_group([held])
+        if pair:
+            self._held = item
+        else:
+            self._decode_group([item])
+        return item[0]
+
+    def _flush_held(self):
+        held, self._held = self._held, None
+        if held is not None:
+            self._decode_group([held])
+
+    def _decode_group(self, items):
+        """One greedy chain over the rows of all ``items`` (pending, enc, enc_done, max_length) on the decode stream."""
+        enc_s, dec_s = self._streams
+        max_length = items[0][3]
         with torch.cuda.stream(dec_s):
-            dec_s.wait_event(enc_done)
-            for t in enc.values():
-                if isinstance(t, torch.Tensor) and t.is_cuda:
-                    t.record_stream(dec_s)
-            res = self.decoder.greedy(enc["attn_emb"], enc["attn_emb_len"], max_length, self.start_idx,
-                                      self.end_idx, self.pad_idx)
-            key = (B, max_length)
-            pool = self._pinned.setdefault(key, [])
-            if not pool:
-                pool.append((torch.empty(B, max_length, dtype=torch.int64).pin_memory(),
-                             torch.empty(B, max_length, dtype=torch.float32).pin_memory()))
-            host_seq, host_lp = pool.pop()
-            host_seq.copy_(res["seq"], non_blocking=True)
-            host_lp.copy_(res["sampled_logprob"], non_blocking=True)
+            for _, enc, ev, _ in items:
+                dec_s.wait_event(ev)
+                for t in enc.values():
+                    if isinstance(t, torch.Tensor) and t.is_cuda:
+                        t.record_stream(dec_s)
+            if len(items) == 1:
+                attn, lens = items[0][1]["attn_emb"], items[0][1]["attn_emb_len"]
+            else:
+                attn = torch.cat([it[1]["attn_emb"] for it in items], 0)
+                lens = torch.cat([torch.as_tensor(it[1]["attn_emb_len"]).cpu() for it in items], 0)
+            res = self.decoder.greedy(attn, lens, max_length, self.start_idx, self.end_idx, self.pad_idx)
+            r0 = 0
+            staged = []
+            for pending, enc, _, _ in items:
+                B = enc["attn_emb"].shape[0]
+                rows = slice(r0, r0 + B)
+                r0 += B
+                pool = self._pinned.setdefault((B, max_length), [])
+                if not pool:
+                    pool.append((torch.empty(B, max_length, dtype=torch.int64).pin_memory(),
+                                 torch.empty(B, max_length, dtype=torch.float32).pin_memory()))
+                host_seq, host_lp = pool.pop()
+                host_seq.copy_(res["seq"][rows], non_blocking=True)
+                host_lp.copy_(res["sampled_logprob"][rows], non_blocking=True)
+                if len(items) == 1:
+                    cnt = res["unfinished_cnt"]
+                else:   # rows still unfinished after step t: finished rows hold end_idx (csrc/decoder.hip greedy_pick)
+                    cnt = (res["seq"][rows] != self.end_idx).sum(0).to(torch.int32)
+                out = {"logit": res["logit"][rows], "embed": res["embed"][rows], "unfinished_cnt": cnt}
+                out.update(enc)
+                staged.append((pending, host_seq, host_lp, out, pool))
             done = torch.cuda.Event()
             done.record(dec_s)
-        out = {"logit": res["logit"], "embed": res["embed"], "unfinished_cnt": res["unfinished_cnt"]}
-        out.update(enc)
-        pending = PendingCaption(done, host_seq, host_lp, out)
-        pending._release = lambda: pool.append((host_seq, host_lp))
-        return pending
+        for pending, host_seq, host_lp, out, pool in staged:
+            pending._fill(done, host_seq, host_lp, out,
+                          (lambda pool=pool, a=host_seq, b=host_lp: pool.append((a, b))))
 
     # ---- greedy (base.py:152-218) -----------------------------------------------------------------
     def greedy_search(self, input_dict):

@@ -282,6 +282,13 @@ def main():
             last = p_.result()
         return last
 
+    # One-time setup, not a warm-up step: the decode chain is replayed from a HIP graph that is captured on the SECOND
+    # use of a shape (audiocaption_amd/transformer_decoder.py).  Both shapes the schedule can produce (a pair of
+    # batches, and a single batch when K is odd) are used twice here, so that neither the W warm-up steps nor the K
+    # timed steps contain a graph capture - the same role as loading the weights.
+    if not args.sync_steps:
+        for n_prime in (4, 1, 1):
+            run_steps(n_prime)
     out = run_steps(args.warmup) if args.warmup else None
     # ---- timed region: exactly K steps, HIP events around every launch of the dominant kernel ----
     events = []
@@ -411,7 +418,8 @@ def main():
                        "decode_steps_reference_would_run": ref_steps, "conv_algo": algo,
                        "sharding": f"clips sharded over {world} rank(s), no data-path collective",
                        "schedule": "blocking model() per step" if args.sync_steps else
-                                   "forward_async: encoder of step i+1 overlaps decode of step i (2 HIP streams)"},
+                                   ("forward_async: encoders on one HIP stream, decode on a second one under the following encoders; "
+                                    "the decode chains of two consecutive steps run as one 128-row chain (pair decode)")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
                          "kernel": kname + " (conv2+BN+ReLU+pool of blocks 2-5)",
