@@ -487,8 +487,7 @@ __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(Conv
   // FUSE1 (block 1 of the f16x2 tier: Cin = Cout = 64, W = 64, 256-pixel blocks): the input of this convolution is
   // itself conv1 + BN + ReLU of the 1-channel log-mel.  Instead of reading it from HBM (0.5 GB written by a separate
   // kernel, 0.7 GB read back with the halo) the workgroup computes its 18x18x64 patch from a 20x20 patch of the
-  // log-mel: 81 FMAs per staged fp16 item on the vector ALUs, under the other workgroups' MFMAs.  Both 32-channel
-  // chunks are staged up front (two LDS planes), so the 18 tap iterations run without a barrier.
+  // log-mel: 72 FMAs (36 packed) per staged fp16 item on the vector ALUs, under the other workgroups' MFMAs.
   // wave grid WM (pixel tiles) x WN (channel tiles); WM = 1 makes every wave walk all 128 pixels of the block for
   // 32 channels: half the weight-fragment bytes per MFMA (the L1/L2 stream that limits the two-product tier)
   // BM = pixels per block (128, or 256 for the wide early layers: MW doubles, the halo overhead shrinks)
@@ -511,7 +510,7 @@ __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(Conv
   const int PITCH = PW * BROW + patch_row_pad_slots(TC) * 8;
   const int PLANE = PH * PITCH;
   __bf16* sAh = (__bf16*)dsm_raw;
-  __bf16* sAl = sAh + PLANE;   // PREC 0: the lo plane; FUSE1: the plane of the second channel chunk
+  __bf16* sAl = sAh + PLANE;   // PREC 0: the lo plane
 
   const int QR2 = 32 >> p.tc_log2;
   int pbase[MW];
@@ -560,7 +559,7 @@ __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(Conv
     unsigned goff[GW_MAXIT], loff[GW_MAXIT];
 #pragma unroll
     for (int j = 0; j < GW_MAXIT; ++j) {
-      const int idx = tid + j * 256;
+      const int idx = FUSE1 ? ((tid & 63) + j * 64) * IPP + (tid >> 6) : tid + j * 256;   // FUSE1: octet = wave
       loff[j] = GW_NONE;
       goff[j] = 0;
       if (idx < NPIX * IPP) {
@@ -611,8 +610,48 @@ __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(Conv
     const int total = nchunk * 9;
     bf16x8 wc[2][NTW][2], wnx[2][NTW][2];
     w_load(0, wc);
+    float* s1 = (float*)(sAh + PLANE);   // FUSE1: [TR + 4][21] log-mel rows row0-2.., columns col0-2..
+    // conv1 + BN + ReLU of channel chunk c1 for this thread's patch items.  With FUSE1 an item is (pixel = lane + 64 j,
+    // channel octet = wave), so the 72 weights and 16 BN terms of an octet are wave-uniform: they sit in SGPRs and the
+    // multiply-adds take them as scalar operands (the same 9-term fmaf chain per channel as conv_first_kernel).
+    auto conv1_patch = [&](int c1) {
+      const int ch0 = c1 * 32 + __builtin_amdgcn_readfirstlane(tid >> 6) * 8;
+      const float* __restrict__ w1 = p.w1 + ch0 * 9;
+      const float* __restrict__ sc1 = p.sc1 + ch0;
+      const float* __restrict__ sh1 = p.sh1 + ch0;
+      float w1r[8][9], sc[8], sh[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        sc[e] = sc1[e];
+        sh[e] = sh1[e];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) w1r[e][t] = w1[e * 9 + t];
+      }
+#pragma unroll
+      for (int j = 0; j < GW_MAXIT; ++j) {
+        if (loff[j] == GW_NONE) continue;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (!(loff[j] & GW_OOB)) {
+          float x[9];
+#pragma unroll
+          for (int t = 0; t < 9; ++t) x[t] = s1[goff[j] + (t / 3) * 21 + (t % 3)];
+          float y[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float a = 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) a = fmaf(x[t], w1r[e][t], a);
+            y[e] = fmaxf(fmaf(a, sc[e], sh[e]), 0.f);
+          }
+          v[0] = cvt_pk_f16(y[0], y[1]);
+          v[1] = cvt_pk_f16(y[2], y[3]);
+          v[2] = cvt_pk_f16(y[4], y[5]);
+          v[3] = cvt_pk_f16(y[6], y[7]);
+        }
+        *(u32x4*)(sAh + (loff[j] & 0x7fffffffu)) = v;
+      }
+    };
     if (FUSE1) {
-      float* s1 = (float*)(sAh + 2 * PLANE);   // [TR + 4][21]: log-mel rows row0-2.., columns col0-2..
       const int S1W = TC + 4, S1H = TR + 4;
       for (int idx = tid; idx < S1W * S1H; idx += 256) {
         const int pr = idx / S1W, pc = idx - pr * S1W;
@@ -622,41 +661,7 @@ __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(Conv
         s1[pr * 21 + pc] = v;
       }
       __syncthreads();
-#pragma unroll 1
-      for (int c1 = 0; c1 < 2; ++c1) {
-        const int ch0 = c1 * 32 + (tid & 3) * 8;   // an item's channel octet is tid % 4 for every j (256 % IPP == 0)
-        float w1r[8][9], sc[8], sh[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          sc[e] = p.sc1[ch0 + e];
-          sh[e] = p.sh1[ch0 + e];
-#pragma unroll
-          for (int t = 0; t < 9; ++t) w1r[e][t] = p.w1[(ch0 + e) * 9 + t];
-        }
-#pragma unroll
-        for (int j = 0; j < GW_MAXIT; ++j) {
-          if (loff[j] == GW_NONE) continue;
-          u32x4 v = {0u, 0u, 0u, 0u};
-          if (!(loff[j] & GW_OOB)) {
-            float x[9];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) x[t] = s1[goff[j] + (t / 3) * 21 + (t % 3)];
-            float y[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              float a = 0.f;
-#pragma unroll
-              for (int t = 0; t < 9; ++t) a = fmaf(x[t], w1r[e][t], a);
-              y[e] = fmaxf(fmaf(a, sc[e], sh[e]), 0.f);
-            }
-            v[0] = cvt_pk_f16(y[0], y[1]);
-            v[1] = cvt_pk_f16(y[2], y[3]);
-            v[2] = cvt_pk_f16(y[4], y[5]);
-            v[3] = cvt_pk_f16(y[6], y[7]);
-          }
-          *(u32x4*)(sAh + c1 * PLANE + (loff[j] & 0x7fffffffu)) = v;
-        }
-      }
+      conv1_patch(0);
     } else {
       stage_patch(0);
     }
@@ -667,7 +672,7 @@ __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(Conv
       if (PREC == 1 && !FUSE1 && tap == 0 && c + 1 < nchunk) patch_request(c + 1);
       w_load(it + 1 < total ? it + 1 : it, wnx);
       const int ky = tap / 3, kx = tap - 3 * ky;
-      const int aoff = ky * PITCH + kx * BROW + (FUSE1 ? c * PLANE : 0);
+      const int aoff = ky * PITCH + kx * BROW;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8 ah[MW], al[MW];
@@ -699,9 +704,10 @@ __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(Conv
           for (int pl = 0; pl < 2; ++pl) wc[ks][n][pl] = wnx[ks][n][pl];
       if (++tap == 9) {
         tap = 0;
-        if (++c < nchunk && !FUSE1) {
+        if (++c < nchunk) {
           __syncthreads();  // every wave is done with the patch of the previous chunk
-          if (PREC == 1) patch_commit();
+          if (FUSE1) conv1_patch(c);
+          else if (PREC == 1) patch_commit();
           else stage_patch(c);
           __syncthreads();
         }
@@ -720,8 +726,8 @@ int launch_conv_gw(ConvParams p, hipStream_t s) {
   else if (p.map_mode == 3) grid = (unsigned)(((p.MT + 8 / p.NT - 1) / (8 / p.NT)) * 8);
   else grid = (unsigned)(p.MT * p.NT);
   const int pitch = (TC + 2) * BROW + patch_row_pad_slots(TC) * 8;
-  // hi + lo planes (bf16), one fp16 plane, or (FUSE1) two fp16 planes + the log-mel patch
-  const size_t lds = (size_t)(TR + 2) * pitch * 2 * ((PREC == 0 || FUSE1) ? 2 : 1) + (FUSE1 ? (TR + 4) * 21 * 4 : 0);
+  // hi + lo planes (bf16) or one fp16 plane (+ the log-mel patch of the fused first layer)
+  const size_t lds = (size_t)(TR + 2) * pitch * 2 * (PREC == 0 ? 2 : 1) + (FUSE1 ? (TR + 4) * 21 * 4 : 0);
   hipLaunchKernelGGL((conv3x3_gw_kernel<BN, MODE, PREC, WM, BM, FUSE1>), dim3(grid), dim3(256), lds, s, p);
   return ac_check_launch();
 }
