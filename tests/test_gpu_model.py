@@ -219,6 +219,30 @@ def test_forward_async_equals_blocking_forward(hip_model):
         assert torch.equal(w["sampled_logprob"], g["sampled_logprob"])
 
 
+def test_forward_async_pair_decode_mixed_shapes(hip_model):
+    """Pair decode only joins consecutive submissions of the same shape; anything else is decoded on its own - in every
+    case with the results of the blocking call, whatever order result() is asked in."""
+    from audiocaption_amd import procedural as P
+
+    def make(n, L, seed, lens):
+        w = torch.from_numpy(P.synthetic_wav(n, L, seed=seed, varied=True)).cuda()
+        return {"mode": "inference", "wav": w, "wav_len": lens, "specaug": False, "sample_method": "greedy",
+                "max_length": 8}
+    inputs = [make(3, 48000, 1, [48000, 40000, 33000]), make(3, 64000, 2, [64000, 50000, 33000]),
+              make(3, 64000, 3, [64000, 64000, 64000]), make(2, 64000, 4, [64000, 41000]),
+              make(3, 48000, 5, [48000, 48000, 20000])]
+    want = [hip_model(dict(i)) for i in inputs]
+    for pair in (True, False):
+        pend = [hip_model.forward_async(dict(i), pair=pair) for i in inputs]
+        for k in (4, 0, 2, 1, 3):   # out of order
+            g, w = pend[k].result(), want[k]
+            assert torch.equal(w["seq"], g["seq"]) and torch.equal(w["logit"], g["logit"])
+            assert torch.equal(w["sampled_logprob"], g["sampled_logprob"])
+            assert torch.equal(w["unfinished_cnt"].cpu(), g["unfinished_cnt"].cpu())
+            assert torch.equal(w["attn_emb_len"], g["attn_emb_len"])
+    assert hip_model._held is None
+
+
 def test_g9_transformer_encoder_vs_reference_golden(golden_dir):
     """TransformerEncoder (row A7) on the HIP path against the reference's outputs; the length tensor is incremented
     in place like the reference does (transformer_encoder.py:105)."""

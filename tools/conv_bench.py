@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--algos", default="direct,winograd")
     ap.add_argument("--layers", default="")
+    ap.add_argument("--force-mode", type=int, default=-1, help="run every selected layer with this epilogue mode (0/1)")
     args = ap.parse_args()
     build.build()
     B = args.batch
@@ -31,6 +32,8 @@ def main():
     for name, H, Hp, W, Cin, Cout, mode in LAYERS:
         if args.layers and name not in args.layers.split(","):
             continue
+        if args.force_mode >= 0 and mode != 2:
+            mode = args.force_mode
         x = torch.randn(B * Hp, W, Cin, device=dev)
         x.view(B, Hp, W, Cin)[:, H:] = 0
         w = torch.randn(Cout, Cin, 3, 3, device=dev) * (2.0 / (9 * Cin)) ** 0.5
