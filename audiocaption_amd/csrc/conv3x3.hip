@@ -44,7 +44,7 @@ struct ConvParams {
   const float* sh1;
 };
 
-enum { MODE_FULL = 0, MODE_POOL = 1, MODE_MEANW = 2 };
+enum { MODE_FULL = 0, MODE_POOL = 1, MODE_MEANW = 2, MODE_LINEAR = 3 };  // LINEAR: FULL without the ReLU (1-tap GEMM use)
 
 // ---- block -> (m_tile, n_tile); block b runs on XCD b % 8 (speed only, never correctness) ----
 __device__ __forceinline__ bool conv_block_map(const ConvParams& p, int& m_tile, int& n_tile) {
@@ -104,8 +104,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 
         const int wx = col0 + 2 * qc;
         float y[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = fmaxf(fmaf(acc[m][n][4 * rq + e], sc, sh), 0.f);
-        if (MODE == MODE_FULL) {
+        for (int e = 0; e < 4; ++e) {
+          y[e] = fmaf(acc[m][n][4 * rq + e], sc, sh);
+          if (MODE != MODE_LINEAR) y[e] = fmaxf(y[e], 0.f);
+        }
+        if (MODE == MODE_FULL || MODE == MODE_LINEAR) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int gr = wy + (e >> 1), gc = wx + (e & 1);
@@ -482,8 +485,13 @@ __device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {
   return __builtin_bit_cast(unsigned, h);
 }
 
-template <int BN, int MODE, int PREC, int WM, int BM, bool FUSE1>
+template <int BN, int MODE, int PREC, int WM, int BM, bool FUSE1, int TAPS>
 __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(ConvParams p) {
+  // TAPS = 9: the 3x3 convolution.  TAPS = 1 (PREC 0 only): a plain GEMM - rows are the "pixels" of a 2-wide image, no
+  // halo - through the same staging / fragment / epilogue machinery: the big f32 linear layers of the path
+  // (ac_linear_bf16x3).  With one tap a chunk is only 12-24 MFMAs per wave, so the next chunk's rows are requested
+  // into registers before the MFMAs of the current one (the 9-tap kernels hide that latency behind 216 MFMAs).
+  constexpr int HALO = TAPS == 9 ? 1 : 0;
   // FUSE1 (block 1 of the f16x2 tier: Cin = Cout = 64, W = 64, 256-pixel blocks): the input of this convolution is
   // itself conv1 + BN + ReLU of the 1-channel log-mel.  Instead of reading it from HBM (0.5 GB written by a separate
   // kernel, 0.7 GB read back with the halo) the workgroup computes its 18x18x64 patch from a 20x20 patch of the
@@ -503,7 +511,7 @@ __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(Conv
   if (!conv_block_map(p, m_tile, n_tile)) return;
   const int TC = 1 << p.tc_log2;
   const int TR = BM >> p.tc_log2;
-  const int PW = TC + 2, PH = TR + 2;
+  const int PW = TC + 2 * HALO, PH = TR + 2 * HALO;
   const int NPIX = PW * PH;
   const int row0 = (m_tile / p.mt_cols) * TR;
   const int col0 = (m_tile % p.mt_cols) * TC;
@@ -565,7 +573,7 @@ __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(Conv
       if (idx < NPIX * IPP) {
         const int pix = idx / IPP, ci = idx % IPP;
         const int pr = pix / PW, pc = pix - pr * PW;
-        const int gr = row0 - 1 + pr, gc = col0 - 1 + pc;
+        const int gr = row0 - HALO + pr, gc = col0 - HALO + pc;
         bool ok = gr >= 0 && gr < p.rows_total && gc >= 0 && gc < p.W;
         if (FUSE1) ok = ok && (gr % p.Hp) < p.H;   // conv1 writes zeros on the padding rows of a clip
         goff[j] = ok ? (unsigned)(((size_t)gr * p.W + gc) * p.Cin + ci * (32 / IPP)) : 0u;
@@ -607,7 +615,28 @@ __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(Conv
       for (int j = 0; j < GW_MAXIT; ++j)
         if (loff[j] != GW_NONE) *(u32x4*)(sAh + (loff[j] & 0x7fffffffu)) = pre[j];
     };
-    const int total = nchunk * 9;
+    // TAPS 1: the next chunk's f32 rows wait in registers while this chunk's MFMAs run
+    constexpr int PRE1 = (TAPS == 1 && PREC == 0) ? 4 : 1;   // 128 rows x 8 items / 256 threads
+    f32x4 pre1[PRE1];
+    auto rows_request = [&](int c) {
+#pragma unroll
+      for (int j = 0; j < PRE1; ++j) {
+        pre1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (loff[j] != GW_NONE && !(loff[j] & GW_OOB)) pre1[j] = *(const f32x4*)(p.in + (size_t)goff[j] + c * 32);
+      }
+    };
+    auto rows_commit = [&]() {
+#pragma unroll
+      for (int j = 0; j < PRE1; ++j) {
+        if (loff[j] == GW_NONE) continue;
+        u32x2 hi, lo;
+        split_bf16x4(pre1[j], hi, lo);
+        const unsigned lo_off = loff[j] & 0x7fffffffu;
+        *(u32x2*)(sAh + lo_off) = hi;
+        *(u32x2*)(sAl + lo_off) = lo;
+      }
+    };
+    const int total = nchunk * TAPS;
     bf16x8 wc[2][NTW][2], wnx[2][NTW][2];
     w_load(0, wc);
     float* s1 = (float*)(sAh + PLANE);   // FUSE1: [TR + 4][21] log-mel rows row0-2.., columns col0-2..
@@ -670,9 +699,10 @@ __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(Conv
 #pragma unroll 1
     for (int it = 0; it < total; ++it) {
       if (PREC == 1 && !FUSE1 && tap == 0 && c + 1 < nchunk) patch_request(c + 1);
+      if (TAPS == 1 && PREC == 0 && c + 1 < nchunk) rows_request(c + 1);
       w_load(it + 1 < total ? it + 1 : it, wnx);
       const int ky = tap / 3, kx = tap - 3 * ky;
-      const int aoff = ky * PITCH + kx * BROW;
+      const int aoff = TAPS == 9 ? ky * PITCH + kx * BROW : 0;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8 ah[MW], al[MW];
@@ -702,11 +732,12 @@ __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(Conv
         for (int n = 0; n < NTW; ++n)
 #pragma unroll
           for (int pl = 0; pl < 2; ++pl) wc[ks][n][pl] = wnx[ks][n][pl];
-      if (++tap == 9) {
+      if (++tap == TAPS) {
         tap = 0;
         if (++c < nchunk) {
           __syncthreads();  // every wave is done with the patch of the previous chunk
           if (FUSE1) conv1_patch(c);
+          else if (TAPS == 1 && PREC == 0) rows_commit();
           else if (PREC == 1) patch_commit();
           else stage_patch(c);
           __syncthreads();
@@ -717,7 +748,7 @@ __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(Conv
   conv_epilogue<BN, MODE, MW, NTW, PREC == 1>(p, acc, n_tile, row0, col0, wm, wn, lane);
 }
 
-template <int BN, int MODE, int PREC = 0, int WM = 2, int BM = 128, bool FUSE1 = false>
+template <int BN, int MODE, int PREC = 0, int WM = 2, int BM = 128, bool FUSE1 = false, int TAPS = 9>
 int launch_conv_gw(ConvParams p, hipStream_t s) {
   const int TC = 1 << p.tc_log2, TR = BM >> p.tc_log2;
   p.MT = ((p.rows_total + TR - 1) / TR) * p.mt_cols;
@@ -725,10 +756,11 @@ int launch_conv_gw(ConvParams p, hipStream_t s) {
   if (p.map_mode == 2) grid = (unsigned)(((p.MT + 7) / 8) * 8 * p.NT);
   else if (p.map_mode == 3) grid = (unsigned)(((p.MT + 8 / p.NT - 1) / (8 / p.NT)) * 8);
   else grid = (unsigned)(p.MT * p.NT);
-  const int pitch = (TC + 2) * BROW + patch_row_pad_slots(TC) * 8;
+  constexpr int HALO = TAPS == 9 ? 1 : 0;
+  const int pitch = (TC + 2 * HALO) * BROW + patch_row_pad_slots(TC) * 8;
   // hi + lo planes (bf16) or one fp16 plane (+ the log-mel patch of the fused first layer)
-  const size_t lds = (size_t)(TR + 2) * pitch * 2 * (PREC == 0 ? 2 : 1) + (FUSE1 ? (TR + 4) * 21 * 4 : 0);
-  hipLaunchKernelGGL((conv3x3_gw_kernel<BN, MODE, PREC, WM, BM, FUSE1>), dim3(grid), dim3(256), lds, s, p);
+  const size_t lds = (size_t)(TR + 2 * HALO) * pitch * 2 * (PREC == 0 ? 2 : 1) + (FUSE1 ? (TR + 4) * 21 * 4 : 0);
+  hipLaunchKernelGGL((conv3x3_gw_kernel<BN, MODE, PREC, WM, BM, FUSE1, TAPS>), dim3(grid), dim3(256), lds, s, p);
   return ac_check_launch();
 }
 
@@ -989,6 +1021,28 @@ extern "C" int ac_conv3x3_block1_f16x2(const float* in1, const float* w1, const 
   p.Hp_out = Hp / 2; p.H_out = H / 2; p.W_out = W / 2;
   p.map_mode = 2;
   return launch_conv_gw<64, MODE_POOL, 1, 2, 256, true>(p, (hipStream_t)stream);
+}
+
+// Y[M][N] = act(X[M][K] W^T + bias) on the split-bf16 matrix path: the 1-tap instance of the kernel above over a
+// 2-pixel-wide "image" of M/2 rows, 64-channel column tiles (more workgroups: M is only a few thousand rows).
+// wfrag = W split and packed like the conv weights with one tap.
+extern "C" int ac_linear_bf16x3(const float* X, const void* wfrag, const float* ones, const float* bias, float* Y,
+                                int M, int N, int K, int relu, void* stream) {
+  if (!X || !wfrag || !ones || !bias || !Y) return AC_ERR_ARG;
+  if (M <= 0 || (M & 1) || K % 32 || N % 64) return AC_ERR_ARG;
+  ConvParams p;
+  p.in = X; p.wpk = (const float*)wfrag; p.scale = ones; p.shift = bias; p.out = Y;
+  p.in1 = nullptr; p.w1 = nullptr; p.sc1 = nullptr; p.sh1 = nullptr;
+  p.rows_total = M / 2; p.Hp = M / 2 + 1; p.H = M / 2; p.W = 2; p.Cin = K; p.Cout = N;
+  p.tc_log2 = 1;
+  p.mt_cols = 1;
+  p.MT = 0;   // set by the launcher
+  p.NT = N / 64;
+  p.Hp_out = 1; p.H_out = 1; p.W_out = 1;
+  p.map_mode = (p.NT % 8 == 0) ? 1 : 2;
+  hipStream_t s = (hipStream_t)stream;
+  return relu ? launch_conv_gw<64, MODE_FULL, 0, 2, 128, false, 1>(p, s)
+              : launch_conv_gw<64, MODE_LINEAR, 0, 2, 128, false, 1>(p, s);
 }
 
 extern "C" int ac_conv3x3_first(const float* in, const float* w, const float* scale, const float* shift,

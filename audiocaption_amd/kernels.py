@@ -4,6 +4,8 @@ Each function takes/returns torch tensors that live on the ROCm device, passes r
 current stream to libaudiocaption_hip.so and raises on any failure.  No function here computes
 anything on the host and none has a fallback.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -170,10 +172,12 @@ def pack_conv_weight_bf16x3_frag(w):
     hi = w.to(torch.bfloat16)
     lo = (w - hi.float()).to(torch.bfloat16)
 
+    taps = w.shape[2] * w.shape[3]   # 9, or 1 for the linear layers
+
     def lay(t):
         # (cout, cin, 3, 3) -> (cin, tap, cout) -> [c][ks][h][e][tap][nt][r] -> [c][tap][ks][nt][h][r][e]
-        t = t.permute(1, 2, 3, 0).reshape(cin // 32, 2, 2, 8, 9, cout // 32, 32)
-        return t.permute(0, 4, 1, 5, 2, 6, 3).reshape(cin // 32, 9, 2, cout // 32, 64, 8)
+        t = t.permute(1, 2, 3, 0).reshape(cin // 32, 2, 2, 8, taps, cout // 32, 32)
+        return t.permute(0, 4, 1, 5, 2, 6, 3).reshape(cin // 32, taps, 2, cout // 32, 64, 8)
 
     return torch.stack([lay(hi), lay(lo)], dim=4).contiguous()
 
@@ -204,6 +208,35 @@ def fold_bn(bn_weight, bn_bias, mean, var, eps):
     return scale.contiguous(), (bn_bias - mean * scale).contiguous()
 
 
+# Large f32 linear layers (the GRU input projections, the decoder's memory projection) run on the split-bf16 matrix
+# path (2^-16 relative operand error, f32 accumulate: the "bf16x3" arithmetic of the conv tier); "f32" keeps the exact
+# f32 MFMA GEMM everywhere.
+LINEAR_ALGO = os.environ.get("AUDIOCAPTION_LINEAR_ALGO", "bf16x3")
+_LINEAR_PACKS = {}   # id(weight tensor) -> (weakref, version, generation, packed weight, ones, zeros)
+
+
+def pack_linear_weight_bf16x3_frag(w):
+    """(N, K) f32 -> split bf16 in the one-tap fragment order of the "gw" kernel: [K/32][1][2 ks][N/32][2][64][8]."""
+    n, k = w.shape
+    return pack_conv_weight_bf16x3_frag(w.reshape(n, k, 1, 1))
+
+
+def _linear_pack(w):
+    """Packed copy of a weight, cached per live tensor OBJECT (a weak reference guards against a freed tensor's
+    address being reused) and invalidated by in-place updates (``_version``) and checkpoint loads."""
+    import weakref
+    hit = _LINEAR_PACKS.get(id(w))
+    if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2] == _lib.param_generation():
+        return hit[3:]
+    for k in [k for k, v in _LINEAR_PACKS.items() if v[0]() is None]:
+        del _LINEAR_PACKS[k]
+    with torch.no_grad():
+        pack = (pack_linear_weight_bf16x3_frag(w.detach().float()), torch.ones(w.shape[0], device=w.device),
+                torch.zeros(w.shape[0], device=w.device))
+    _LINEAR_PACKS[id(w)] = (weakref.ref(w), w._version, _lib.param_generation()) + pack
+    return pack
+
+
 def linear(x, w, b=None, relu=False, out=None):
     """y = act(x @ w.T + b); x (M, K) row-major (stride(0) may exceed K), w (N, K)."""
     lib = _lib.load()
@@ -211,6 +244,13 @@ def linear(x, w, b=None, relu=False, out=None):
     N = w.shape[0]
     if out is None:
         out = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    # worth it from ~2 GFLOP (1984 x 1536 x 512: 39 -> 26 us; x 2048: 144 -> 77 us; smaller layers are latency chains)
+    if (LINEAR_ALGO == "bf16x3" and M * N * K >= (1 << 30) and M % 2 == 0 and K % 32 == 0 and N % 64 == 0 and x.stride(0) == K
+            and out.stride(0) == N and w.is_contiguous()):
+        wfrag, ones, zeros = _linear_pack(w)
+        check(lib.ac_linear_bf16x3(ptr(x), ptr(wfrag), ptr(ones), ptr(b if b is not None else zeros), ptr(out), M, N, K,
+                                   1 if relu else 0, stream()), "ac_linear_bf16x3")
+        return out
     check(lib.ac_linear(ptr(x), ptr(w), ptr(b), ptr(out), M, N, K, x.stride(0), w.stride(0), out.stride(0),
                         1 if relu else 0, stream()), "ac_linear")
     return out

@@ -347,8 +347,10 @@ def main():
         tiers = [("f32_path", "winograd", "f32")]
         if algo == "f16x2":   # the split-bf16 tier (f32-grade parity: logits within 3e-5) beside the default
             tiers.append(("split_bf16_path", "bf16x3", "bf16x3"))
+        linear_algo = K.LINEAR_ALGO
         for key, tier, dt in tiers:
             cnn.conv_algo = tier
+            K.LINEAR_ALGO = "f32" if tier == "winograd" else linear_algo   # the exact-f32 tier: f32 GEMMs as well
             run_steps(2)
             sync_all()
             f0 = time.perf_counter()
@@ -358,6 +360,7 @@ def main():
             extra[key] = {"conv_algo": tier, "dtype": dt, "steps": nsec, "ms_per_step": fdt / nsec * 1e3,
                           "value": world * B * nsec / fdt, "unit": "clips/s"}
         cnn.conv_algo = algo
+        K.LINEAR_ALGO = linear_algo
     # the log-mel kernel on its own: HBM-bound (1.54 MB per 10 s clip: waveform in, log-mel out)
     m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     cnn = model.encoder.cnn

@@ -52,6 +52,39 @@ def test_linear(K, M, N, K_, relu):
     assert _report(f"linear {M}x{N}x{K_}", got, want) < 2e-5 * max(1.0, math.sqrt(K_ / 256))
 
 
+@pytest.mark.parametrize("M,N,K_,relu,bias", [(1984, 1536, 2048, False, True), (1984, 1536, 512, False, True),
+                                               (4096, 512, 512, True, True), (32770, 64, 512, False, False),
+                                               (5462, 192, 1056, True, False)])
+def test_linear_split_bf16_path(K, M, N, K_, relu, bias):
+    """The large linear layers run as the one-tap instance of the split-bf16 conv kernel (ac_linear_bf16x3): against
+    float64, with the bar of the exact-f32 GEMM plus the 2^-16 operand error."""
+    g = torch.Generator().manual_seed(M + 7 * N + K_)
+    x = torch.randn(M, K_, generator=g)
+    w = torch.randn(N, K_, generator=g) / math.sqrt(K_)
+    b = torch.randn(N, generator=g) if bias else None
+    want = torch.nn.functional.linear(x.double(), w.double(), b.double() if bias else None)
+    if relu:
+        want = want.relu()
+    assert K.LINEAR_ALGO == "bf16x3"
+    xd, wd, bd = x.cuda(), w.cuda(), (b.cuda() if bias else None)
+    got = K.linear(xd, wd, bd, relu=relu)
+    assert _report(f"linear bf16x3 {M}x{N}x{K_}", got, want.float()) < 4e-5 * max(1.0, math.sqrt(K_ / 256))
+    # the exact-f32 GEMM on the same inputs shows which path ran above (it differs in the last bits)
+    saved, K.LINEAR_ALGO = K.LINEAR_ALGO, "f32"
+    try:
+        f32 = K.linear(xd, wd, bd, relu=relu)
+    finally:
+        K.LINEAR_ALGO = saved
+    assert _report("f32 GEMM", f32, want.float()) < 2e-5 * max(1.0, math.sqrt(K_ / 256))
+    assert not torch.equal(f32, got)
+    # a second weight that reuses the first one's storage address must not hit the packed-weight cache
+    del wd
+    w2 = (torch.randn(N, K_, generator=g) / math.sqrt(K_)).cuda()
+    got2 = K.linear(xd, w2, bd, relu=relu)
+    want2 = torch.nn.functional.linear(x.double(), w2.cpu().double(), b.double() if bias else None)
+    assert _report("second weight", got2, (want2.relu() if relu else want2).float()) < 4e-5 * max(1.0, math.sqrt(K_ / 256))
+
+
 def test_linear_asymmetric_identity(K):
     """transpose-detecting check: X = I gives Y = W^T rows, with an asymmetric W."""
     n = 64

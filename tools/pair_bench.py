@@ -32,7 +32,7 @@ def run(nsteps, group):
     torch.cuda.synchronize()
     return outs
 
-for group in (1, 2, 4, 1, 2):
+for group in (2, 4, 8, 24, 2, 24):
     run(4, group)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     o = run(24, group)
