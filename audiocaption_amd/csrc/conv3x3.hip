@@ -38,6 +38,7 @@ struct ConvParams {
   int Hp_out, H_out, W_out;
   int map_mode;
   // fused first layer (conv3x3_gw_kernel<..., FUSE1>): the 1-channel input and conv1's weights / folded BN
+  int m_valid;   // one-tap GEMM use: number of valid "pixels" (rows of the GEMM), 0 = all
   const float* in1;
   const float* w1;
   const float* sc1;
@@ -112,7 +113,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int gr = wy + (e >> 1), gc = wx + (e & 1);
-            if (gr < p.rows_total) {
+            if (gr < p.rows_total && (p.m_valid == 0 || gr * p.W + gc < p.m_valid)) {
               const bool valid = (gr % p.Hp) < p.H;
               const size_t o = ((size_t)gr * p.W + gc) * p.Cout + ch;
               if (OUT16) ((_Float16*)p.out)[o] = (_Float16)(valid ? y[e] : 0.f);
@@ -576,6 +577,7 @@ __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(Conv
         const int gr = row0 - HALO + pr, gc = col0 - HALO + pc;
         bool ok = gr >= 0 && gr < p.rows_total && gc >= 0 && gc < p.W;
         if (FUSE1) ok = ok && (gr % p.Hp) < p.H;   // conv1 writes zeros on the padding rows of a clip
+        if (TAPS == 1) ok = ok && gr * p.W + gc < p.m_valid;
         goff[j] = ok ? (unsigned)(((size_t)gr * p.W + gc) * p.Cin + ci * (32 / IPP)) : 0u;
         if (FUSE1) goff[j] = (unsigned)(pr * 21 + pc);   // top-left of the pixel's 3x3 window in the log-mel patch
         loff[j] = (unsigned)(pr * PITCH + pc * BROW + ci * (32 / IPP)) | (ok ? 0u : GW_OOB);
@@ -871,6 +873,7 @@ extern "C" int ac_conv3x3_bn_relu(const float* in, const float* wpk, const float
   if (mode == MODE_POOL && (Hp & 1)) return AC_ERR_ARG;
   if (mode == MODE_MEANW && W != 2) return AC_ERR_ARG;
   ConvParams p;
+  p.m_valid = 0;
   p.in = in; p.wpk = wpk; p.scale = scale; p.shift = shift; p.out = out;
   p.rows_total = B * Hp; p.Hp = Hp; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   const int TC = W < 16 ? W : 16;
@@ -907,6 +910,7 @@ extern "C" int ac_conv3x3_bn_relu_bf16x3(const float* in, const void* wpk, const
   if (mode == MODE_POOL && (Hp & 1)) return AC_ERR_ARG;
   if (mode == MODE_MEANW && W != 2) return AC_ERR_ARG;
   ConvParams p;
+  p.m_valid = 0;
   p.in = in; p.wpk = (const float*)wpk; p.scale = scale; p.shift = shift; p.out = out;
   p.rows_total = B * Hp; p.Hp = Hp; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   const int TC = W < 16 ? W : 16;
@@ -943,6 +947,7 @@ static int conv_gw_dispatch(int prec, const float* in, const void* wfrag, const 
   if (mode == MODE_POOL && (Hp & 1)) return AC_ERR_ARG;
   if (mode == MODE_MEANW && W != 2) return AC_ERR_ARG;
   ConvParams p;
+  p.m_valid = 0;
   p.in = in; p.wpk = (const float*)wfrag; p.scale = scale; p.shift = shift; p.out = out;
   p.rows_total = B * Hp; p.Hp = Hp; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   const int TC = W < 16 ? W : 16;
@@ -1011,6 +1016,7 @@ extern "C" int ac_conv3x3_block1_f16x2(const float* in1, const float* w1, const 
   if (!in1 || !w1 || !scale1 || !shift1 || !wfrag2 || !scale2 || !shift2 || !out) return AC_ERR_ARG;
   if (B <= 0 || Hp <= H || (Hp & 1) || W != 64) return AC_ERR_ARG;
   ConvParams p;
+  p.m_valid = 0;
   p.in = nullptr; p.wpk = (const float*)wfrag2; p.scale = scale2; p.shift = shift2; p.out = (float*)out;
   p.in1 = in1; p.w1 = w1; p.sc1 = scale1; p.sh1 = shift1;
   p.rows_total = B * Hp; p.Hp = Hp; p.H = H; p.W = W; p.Cin = 64; p.Cout = 64;
@@ -1029,11 +1035,13 @@ extern "C" int ac_conv3x3_block1_f16x2(const float* in1, const float* w1, const 
 extern "C" int ac_linear_bf16x3(const float* X, const void* wfrag, const float* ones, const float* bias, float* Y,
                                 int M, int N, int K, int relu, void* stream) {
   if (!X || !wfrag || !ones || !bias || !Y) return AC_ERR_ARG;
-  if (M <= 0 || (M & 1) || K % 32 || N % 64) return AC_ERR_ARG;
+  if (M <= 0 || K % 32 || N % 64) return AC_ERR_ARG;
   ConvParams p;
+  p.m_valid = 0;
   p.in = X; p.wpk = (const float*)wfrag; p.scale = ones; p.shift = bias; p.out = Y;
   p.in1 = nullptr; p.w1 = nullptr; p.sc1 = nullptr; p.sh1 = nullptr;
-  p.rows_total = M / 2; p.Hp = M / 2 + 1; p.H = M / 2; p.W = 2; p.Cin = K; p.Cout = N;
+  p.rows_total = (M + 1) / 2; p.Hp = p.rows_total + 1; p.H = p.rows_total; p.W = 2; p.Cin = K; p.Cout = N;
+  p.m_valid = M;
   p.tc_log2 = 1;
   p.mt_cols = 1;
   p.MT = 0;   // set by the launcher

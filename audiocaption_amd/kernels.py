@@ -244,8 +244,9 @@ def linear(x, w, b=None, relu=False, out=None):
     N = w.shape[0]
     if out is None:
         out = torch.empty(M, N, device=x.device, dtype=torch.float32)
-    # worth it from ~2 GFLOP (1984 x 1536 x 512: 39 -> 26 us; x 2048: 144 -> 77 us; smaller layers are latency chains)
-    if (LINEAR_ALGO == "bf16x3" and M * N * K >= (1 << 30) and M % 2 == 0 and K % 32 == 0 and N % 64 == 0 and x.stride(0) == K
+    # Chosen by the LAYER (its weight matrix), never by the batch: a clip gets the same numbers in a batch of 1 and of
+    # 64.  From 1536 x 512 weights up the split path wins at the bench's 1984 rows (39 -> 26 us; K = 2048: 144 -> 77 us).
+    if (LINEAR_ALGO == "bf16x3" and N * K >= 1536 * 512 and K % 32 == 0 and N % 64 == 0 and x.stride(0) == K
             and out.stride(0) == N and w.is_contiguous()):
         wfrag, ones, zeros = _linear_pack(w)
         check(lib.ac_linear_bf16x3(ptr(x), ptr(wfrag), ptr(ones), ptr(b if b is not None else zeros), ptr(out), M, N, K,

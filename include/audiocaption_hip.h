@@ -92,7 +92,7 @@ int ac_conv3x3_block1_f16x2(const float* in1, const float* w1, const float* scal
 
 /* Y[M][N] = act(X[M][K] W[N][K]^T + bias) on the split-bf16 matrix path (2^-16 relative operand error, f32
  * accumulation): the one-tap instance of the "gw" convolution kernel.  X, Y dense row-major f32; wfrag = W split into
- * bf16 hi + lo in fragment order [K/32][1][2 k-steps][N/32][2][64 lanes][8]; ones = N floats of 1.0; M even,
+ * bf16 hi + lo in fragment order [K/32][1][2 k-steps][N/32][2][64 lanes][8]; ones = N floats of 1.0;
  * K % 32 == 0, N % 64 == 0.  Replaces the same reference code as ac_linear (nn.Linear / the nn.GRU input projections,
  * rnn_encoder.py:34-49) for the large layers. */
 int ac_linear_bf16x3(const float* X, const void* wfrag, const float* ones, const float* bias, float* Y,
