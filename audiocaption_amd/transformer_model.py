@@ -103,12 +103,14 @@ class PendingCaption:
 
     def __init__(self, model=None):
         self._model = model
-        self._done = self._seq = self._lp = self._out = self._release = None
+        self._done = self._seq = self._lp = self._out = self._release = self._result = None
 
     def _fill(self, done_event, host_seq, host_logprob, output, release):
         self._done, self._seq, self._lp, self._out, self._release = done_event, host_seq, host_logprob, output, release
 
     def result(self):
+        if self._result is not None:    # asked again: the staging buffers have gone back to the pool, return the copy
+            return dict(self._result)
         if self._done is None:          # still waiting for a partner batch (pair decode): decode it on its own now
             self._model._flush_held()
         self._done.synchronize()
@@ -118,7 +120,9 @@ class PendingCaption:
         if self._release is not None:  # hand the pinned staging buffers back to the pool
             self._release()
             self._release = None
-        return out
+        self._result = out
+        self._seq = self._lp = None
+        return dict(out)
 
 
 class TransformerModel(CaptionModel):

@@ -241,6 +241,8 @@ def test_forward_async_pair_decode_mixed_shapes(hip_model):
             assert torch.equal(w["unfinished_cnt"].cpu(), g["unfinished_cnt"].cpu())
             assert torch.equal(w["attn_emb_len"], g["attn_emb_len"])
     assert hip_model._held is None
+    again = pend[0].result()   # a second result() returns the same tensors, not the recycled staging buffers
+    assert torch.equal(again["seq"], want[0]["seq"])
 
 
 def test_g9_transformer_encoder_vs_reference_golden(golden_dir):
