@@ -233,7 +233,7 @@ class Cnn14Encoder(nn.Module):
         out = {"attn_emb": attn_emb, "attn_emb_len": feat_length}
         if not skip_fc:
             # Cnn14's own clip embedding (cnn_encoder.py:451-456); CrnnEncoder discards it.
-            lens = feat_length.to(device=wav.device, dtype=torch.int32)
+            lens = K.upload(feat_length, wav.device, torch.int32)
             pooled = K.mean_with_lens(attn_emb, lens, add_max=True)
             out["fc_emb"] = K.linear(pooled, self.fc1.weight.float(), self.fc1.bias.float(), relu=True)
         return out

@@ -12,6 +12,21 @@ from . import _lib
 from ._lib import check, f32c, ptr, stream
 
 
+def upload(t, device, dtype=None):
+    """Host tensor / list -> device WITHOUT blocking the host.  A plain ``.to(device)`` of pageable memory makes the host
+    wait until the stream has executed everything submitted before it (the whole conv stack, when the lengths are
+    uploaded between the encoder's kernels), so nothing can be queued ahead; a pinned staging tensor (kept alive by
+    torch's caching host allocator until the copy has run) does not."""
+    t = torch.as_tensor(t)
+    if t.is_cuda:
+        return t.to(device=device, dtype=dtype)
+    if dtype is not None:
+        t = t.to(dtype)
+    pin = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    pin.copy_(t)
+    return pin.to(device, non_blocking=True)
+
+
 def _dev(t):
     if not t.is_cuda:
         raise _lib.HipLibraryError("the HIP path needs tensors on a ROCm device; there is no CPU fallback")

@@ -66,7 +66,7 @@ class RnnEncoder(nn.Module):
         B, T, _ = x.shape
         if int(lens.min()) < 1 or int(lens.max()) > T:
             raise ValueError("attn_len must lie in [1, attn.size(1)]")
-        lens_dev = lens.to(device=x.device, dtype=torch.int32)
+        lens_dev = K.upload(lens, x.device, torch.int32)
         h = K.f32c(x).reshape(B * T, -1)
         for (w_ih, b_ih, whhT, bhh) in self._pack():
             gx = K.linear(h, w_ih, b_ih)                       # (B*T, 2*3H): all steps, both directions

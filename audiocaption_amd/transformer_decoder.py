@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from . import kernels as K
 from ._lib import check, f32c, ptr, stream
 
 
@@ -171,7 +172,7 @@ class TransformerDecoder(BaseDecoder):
         word = input_dict["word"].to(dev)
         N, T = word.shape
         Tm = attn_emb.shape[1]
-        mem_len = torch.as_tensor(input_dict["attn_emb_len"]).to(device=dev, dtype=torch.int32)
+        mem_len = K.upload(input_dict["attn_emb_len"], dev, torch.int32)
         mask = input_dict.get("cap_padding_mask")
         mask_u8 = None if mask is None else mask.to(dev).to(torch.uint8).contiguous()
         memkv = self.memory(attn_emb)
@@ -230,7 +231,7 @@ class TransformerDecoder(BaseDecoder):
             states.pop(next(iter(states)))
         st["uses"] += 1
         st["attn_emb"].copy_(attn_emb)
-        st["mem_len"].copy_(torch.as_tensor(attn_emb_len).to(device=dev, dtype=torch.int32))
+        st["mem_len"].copy_(K.upload(attn_emb_len, dev, torch.int32))
         if not use_graph or st["uses"] < 2:
             # first batch of this shape: plain launches (also the warm-up a capture needs); a shape that never comes
             # back is never captured

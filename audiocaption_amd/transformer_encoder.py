@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from . import kernels as K
 from ._lib import check, f32c, ptr, stream
 
 
@@ -72,7 +73,7 @@ class TransformerEncoder(nn.Module):
         rows = N * L
         row0 = (torch.arange(N, dtype=torch.int32) * L).to(dev)
         qlen = torch.full((N,), L, dtype=torch.int32, device=dev)
-        valid = lens.to(device=dev, dtype=torch.int32)
+        valid = K.upload(lens, dev, torch.int32)
         qkv = torch.empty(rows, 3 * d, **f32)
         ctx = torch.empty(rows, d, **f32)
         sub = torch.empty(rows, d, **f32)

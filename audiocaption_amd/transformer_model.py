@@ -21,6 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from . import kernels as K
 from ._lib import check, ptr, stream
 from .transformer_decoder import TransformerDecoder
 
@@ -109,6 +110,8 @@ class PendingCaption:
         self._done, self._seq, self._lp, self._out, self._release = done_event, host_seq, host_logprob, output, release
 
     def result(self):
+        if getattr(self, "_lazy", None) is not None:   # beam search: the host-driven loop runs now, on the decode stream
+            self._model._run_lazy(self)
         if self._result is not None:    # asked again: the staging buffers have gone back to the pool, return the copy
             return dict(self._result)
         if self._done is None:          # still waiting for a partner batch (pair decode): decode it on its own now
@@ -144,8 +147,11 @@ class TransformerModel(CaptionModel):
         is a latency chain - and while it runs it takes workgroup slots from the encoder.  So a batch waits for the
         next submission of the same shape and the two are decoded as ONE chain (rows are independent: same tokens,
         same logits); a batch without a partner is decoded on its own as soon as its ``result()`` is asked for."""
-        if input_dict.get("mode") != "inference" or input_dict.get("sample_method", "greedy") != "greedy":
-            raise NotImplementedError("forward_async: greedy inference only; use model(input_dict) otherwise")
+        method = input_dict.get("sample_method", "greedy")
+        if input_dict.get("mode") != "inference" or method not in ("greedy", "beam"):
+            raise NotImplementedError("forward_async: greedy or beam inference only; use model(input_dict) otherwise")
+        if method == "beam":
+            return self._forward_async_beam(input_dict)
         if pair is None:
             pair = os.environ.get("AUDIOCAPTION_PAIR_DECODE", "1") != "0"
         dev = input_dict["wav"].device
@@ -174,6 +180,36 @@ class TransformerModel(CaptionModel):
         else:
             self._decode_group([item])
         return item[0]
+
+    def _forward_async_beam(self, input_dict):
+        """Beam search is a host-driven loop (it asks the device now and then whether any clip is still searching), so
+        only the ENCODER is submitted here, on the encoder stream; the search itself runs on the decode stream when
+        ``result()`` is called - under the encoders of the batches submitted after this one."""
+        dev = input_dict["wav"].device
+        if self._streams is None or self._streams[0].device != dev:
+            self._streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+        enc_s, dec_s = self._streams
+        enc_s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(enc_s):
+            enc = self.encoder(input_dict)
+            enc_done = torch.cuda.Event()
+            enc_done.record(enc_s)
+        pending = PendingCaption(self)
+        pending._lazy = (dict(input_dict), enc, enc_done)
+        return pending
+
+    def _run_lazy(self, pending):
+        input_dict, enc, enc_done = pending._lazy
+        pending._lazy = None
+        enc_s, dec_s = self._streams
+        with torch.cuda.stream(dec_s):
+            dec_s.wait_event(enc_done)
+            for t in enc.values():
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(dec_s)
+            out = self.forward_decoder(input_dict, enc)
+            dec_s.synchronize()
+        pending._result = out
 
     def _flush_held(self):
         held, self._held = self._held, None
@@ -249,7 +285,7 @@ class TransformerModel(CaptionModel):
         n_best_size = int(input_dict.get("n_best_size", beam))
         V = self.vocab_size
         R = B * beam
-        mem_len = torch.as_tensor(input_dict["attn_emb_len"]).to(device=dev, dtype=torch.int32)
+        mem_len = K.upload(input_dict["attn_emb_len"], dev, torch.int32)
         memkv = dec.memory(attn_emb)
         ws = dec.workspace(R, max_length, dev)
 

@@ -120,12 +120,24 @@ def bench_effb2(args, world, rank, dev, dist, steps, warmup):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(warmup):
-        model(dict(inp))
+    def run_steps(n):
+        """Throughput mode: every encoder is submitted up front on the encoder stream; the (host-driven) beam searches
+        run one after the other on the decode stream underneath them.  --sync-steps: one blocking call per step."""
+        if getattr(args, "sync_steps", False):
+            last = None
+            for _ in range(n):
+                last = model(dict(inp))
+            return last
+        pend = [model.forward_async(dict(inp)) for _ in range(n)]
+        last = None
+        for p_ in pend:
+            last = p_.result()
+        return last
+
+    run_steps(max(warmup, 2))
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        out = model(dict(inp))
+    out = run_steps(steps)
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -162,7 +174,10 @@ def bench_effb2(args, world, rank, dev, dist, steps, warmup):
                                  "--seconds 30 --beam 4 --gpus 8)",
                    "global_batch": world * B, "parity": "unpinned (efficientnet_pytorch / torchaudio are not vendored by "
                    "the reference): checked against oracle/effb2_path.py",
-                   "sharding": f"clips sharded over {world} rank(s), no data-path collective"},
+                   "sharding": f"clips sharded over {world} rank(s), no data-path collective",
+                   "schedule": "blocking model() per step" if getattr(args, "sync_steps", False) else
+                               "forward_async: encoders on one HIP stream, the beam searches on a second one under the "
+                               "following encoders"},
     }
 
 

@@ -245,6 +245,22 @@ def test_forward_async_pair_decode_mixed_shapes(hip_model):
     assert torch.equal(again["seq"], want[0]["seq"])
 
 
+def test_forward_async_beam_equals_blocking(hip_model):
+    """Beam search through forward_async (encoders submitted up front, the host-driven searches run at result() on the
+    decode stream) returns what the blocking call returns."""
+    from audiocaption_amd import procedural as P
+    inputs = []
+    for s_, lens in ((11, [48000, 40000, 33000]), (12, [48000, 48000, 21000]), (13, [30000, 48000, 47000])):
+        w = torch.from_numpy(P.synthetic_wav(3, 48000, seed=s_, varied=True)).cuda()
+        inputs.append({"mode": "inference", "wav": w, "wav_len": lens, "specaug": False, "sample_method": "beam",
+                       "beam_size": 3, "max_length": 8})
+    want = [hip_model(dict(i)) for i in inputs]
+    pend = [hip_model.forward_async(dict(i)) for i in inputs]
+    for k in (1, 0, 2):
+        g = pend[k].result()
+        assert torch.equal(g["seq"], want[k]["seq"]) and torch.equal(g["attn_emb"], want[k]["attn_emb"])
+
+
 def test_g9_transformer_encoder_vs_reference_golden(golden_dir):
     """TransformerEncoder (row A7) on the HIP path against the reference's outputs; the length tensor is incremented
     in place like the reference does (transformer_encoder.py:105)."""
