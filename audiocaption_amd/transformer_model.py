@@ -143,17 +143,18 @@ class TransformerModel(CaptionModel):
         the decode of batch i fills the gaps of the matrix-bound encoder of batch i+1.  Results are identical
         to ``model(input_dict)``; only the schedule differs.  Returns a ``PendingCaption``.
 
-        ``pair`` (default: AUDIOCAPTION_PAIR_DECODE, on): the decode chain costs the same for 128 rows as for 64 - it
-        is a latency chain - and while it runs it takes workgroup slots from the encoder.  So a batch waits for the
-        next submission of the same shape and the two are decoded as ONE chain (rows are independent: same tokens,
-        same logits); a batch without a partner is decoded on its own as soon as its ``result()`` is asked for."""
+        ``pair`` (default: AUDIOCAPTION_PAIR_DECODE, off): a batch waits for the next submission of the same shape and
+        the two are decoded as ONE chain (rows are independent: same tokens, same logits; the chain is latency-bound, so
+        128 rows cost what 64 do); a batch without a partner is decoded on its own as soon as its ``result()`` is asked
+        for.  It paid off only while the host was held back by blocking length uploads; with the host
+        running ahead of the device it is neutral, so results are not delayed by default."""
         method = input_dict.get("sample_method", "greedy")
         if input_dict.get("mode") != "inference" or method not in ("greedy", "beam"):
             raise NotImplementedError("forward_async: greedy or beam inference only; use model(input_dict) otherwise")
         if method == "beam":
             return self._forward_async_beam(input_dict)
         if pair is None:
-            pair = os.environ.get("AUDIOCAPTION_PAIR_DECODE", "1") != "0"
+            pair = os.environ.get("AUDIOCAPTION_PAIR_DECODE", "0") != "0"
         dev = input_dict["wav"].device
         if self._streams is None or self._streams[0].device != dev:
             self._streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))

@@ -504,8 +504,8 @@ def main():
                        "decode_steps_reference_would_run": ref_steps, "conv_algo": algo,
                        "sharding": f"clips sharded over {world} rank(s), no data-path collective",
                        "schedule": "blocking model() per step" if args.sync_steps else
-                                   ("forward_async: encoders on one HIP stream, decode on a second one under the following encoders; "
-                                    "the decode chains of two consecutive steps run as one 128-row chain (pair decode)")},
+                                   "forward_async: encoders on one HIP stream, the decode chain of step i on a second one under "
+                                   "the encoder of step i+1"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
                          "kernel": kname + " (conv2+BN+ReLU+pool of blocks 2-5)",
