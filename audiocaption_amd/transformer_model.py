@@ -98,6 +98,13 @@ class CaptionModel(nn.Module, CaptionMetaMixin):
             "(dbs / gumbel / top-k / top-p sampling are out of scope, SURVEY.md §2.1 row 7)")
 
 
+def _make_streams(dev):
+    """(encoder stream, decode stream) of the throughput mode.  AUDIOCAPTION_STREAM_PRIORITIES="enc,dec" sets their HIP
+    priorities (lower = more urgent; default 0,0)."""
+    pe, pd = (int(v) for v in os.environ.get("AUDIOCAPTION_STREAM_PRIORITIES", "0,0").split(","))
+    return torch.cuda.Stream(dev, priority=pe), torch.cuda.Stream(dev, priority=pd)
+
+
 class PendingCaption:
     """Handle of a batch submitted with ``TransformerModel.forward_async``: ``result()`` blocks until the
     batch's token ids have reached the host and returns the same dict ``model(input_dict)`` would."""
@@ -157,7 +164,7 @@ class TransformerModel(CaptionModel):
             pair = os.environ.get("AUDIOCAPTION_PAIR_DECODE", "0") != "0"
         dev = input_dict["wav"].device
         if self._streams is None or self._streams[0].device != dev:
-            self._streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+            self._streams = _make_streams(dev)
         enc_s, dec_s = self._streams
         cur = torch.cuda.current_stream(dev)
         enc_s.wait_stream(cur)  # inputs produced on the caller's stream
@@ -188,7 +195,7 @@ class TransformerModel(CaptionModel):
         ``result()`` is called - under the encoders of the batches submitted after this one."""
         dev = input_dict["wav"].device
         if self._streams is None or self._streams[0].device != dev:
-            self._streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+            self._streams = _make_streams(dev)
         enc_s, dec_s = self._streams
         enc_s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(enc_s):
