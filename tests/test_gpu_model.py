@@ -93,6 +93,30 @@ def test_f16x2_fused_block1_equals_two_kernels(hip_model, monkeypatch):
         cnn.conv_algo = saved
 
 
+@pytest.mark.parametrize("B,T", [(1, 33), (3, 64), (5, 97), (2, 1000), (7, 257), (1, 3001)])
+def test_f16x2_tier_odd_geometries(hip_model, monkeypatch, B, T):
+    """Ragged geometries (clip counts and frame counts that leave partial row tiles, 256-row blocks of block 1 that
+    straddle clips, the 30 s maximum): the fp16-activation tier against the exact-f32 Winograd tier on the same log-mel,
+    and the fused first block against the two-launch one (bit-identical)."""
+    from audiocaption_amd import procedural as P
+    cnn = hip_model.encoder.cnn
+    saved = cnn.conv_algo
+    lms = torch.from_numpy(P.synthetic_logmel(B, T)).cuda()
+    try:
+        cnn.conv_algo = "winograd"
+        want, _ = _cnn_from_logmel(cnn, lms)
+        cnn.conv_algo = "f16x2"
+        monkeypatch.setenv("AUDIOCAPTION_FUSE_BLOCK1", "1")
+        got, blocks = _cnn_from_logmel(cnn, lms)
+        monkeypatch.setenv("AUDIOCAPTION_FUSE_BLOCK1", "0")
+        got2, blocks2 = _cnn_from_logmel(cnn, lms)
+    finally:
+        cnn.conv_algo = saved
+    assert got.shape == want.shape == (B, T // 32, 2048)
+    assert torch.equal(got, got2) and torch.equal(blocks[0], blocks2[0])
+    assert _maxdiff(f"attn_emb f16x2 vs f32 B={B} T={T}", got, want) < 1e-3 * max(1.0, float(want.abs().max()))
+
+
 @pytest.mark.parametrize("algo", ["direct", "winograd", "bf16x3", "bf16x3_lds", "f16x2"])
 def test_g1_cnn14_every_conv_algorithm(hip_model, golden_dir, algo):
     """Every conv kernel family against the reference's attn_emb (bar 2e-4 abs; f32 kernels land at ~5e-6,

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--algos", default="direct,winograd")
     ap.add_argument("--layers", default="")
+    ap.add_argument("--map-mode", type=int, default=-1, help="block -> tile mapping of the gw kernels (-1: default)")
     ap.add_argument("--force-mode", type=int, default=-1, help="run every selected layer with this epilogue mode (0/1)")
     args = ap.parse_args()
     build.build()
@@ -61,7 +62,7 @@ def main():
                 sc2 = (sc * inv).contiguous()
                 xh = x.half()
                 outh = out if mode == 2 else torch.empty_like(out, dtype=torch.float16)
-                fn = lambda: K.conv3x3_bn_relu_f16x2_gw(xh, wp, sc2, sh, outh, B, Hp, H, W, Cin, Cout, mode)
+                fn = lambda: K.conv3x3_bn_relu_f16x2_gw(xh, wp, sc2, sh, outh, B, Hp, H, W, Cin, Cout, mode, args.map_mode)
             else:
                 wp = K.pack_conv_weight_bf16x3_frag(w)
                 fn = lambda: K.conv3x3_bn_relu_bf16x3_gw(x, wp, sc, sh, out, B, Hp, H, W, Cin, Cout, mode)
