@@ -70,6 +70,7 @@ class Cnn14Encoder(nn.Module):
         # "winograd": F(2x2,3x3) on the f32 MFMA, exact f32.  "direct": 9-tap f32 implicit GEMM.  "bf16x3_lds": bf16x3
         # with an LDS weight ring (kept for ablations).  The train-mode forward always uses "bf16x3" or an f32 tier.
         self.conv_algo = os.environ.get("AUDIOCAPTION_CONV_ALGO", "f16x2")
+        self.f16x2_min_frames = int(os.environ.get("AUDIOCAPTION_F16X2_MIN_FRAMES", "8"))
         self._tables = None
         self._packed = {}   # conv tier -> (key of the tensors it was packed from, packed weights)
         self._bufs = {}
@@ -155,7 +156,7 @@ class Cnn14Encoder(nn.Module):
         Hp = [hp6 << (5 - k) for k in range(6)]
         return T, H, Hp
 
-    def encode(self, wav, dropout=None, specaug=None, train=False):
+    def encode(self, wav, dropout=None, specaug=None, train=False, min_frames=None):
         """wav (B, L) on the ROCm device -> attn_emb (B, T // 32, 2048).
 
         ``dropout = (p, op_code, seed_dev_ptr)``: the train-mode forward of the frozen network, F.dropout(p) after
@@ -163,7 +164,11 @@ class Cnn14Encoder(nn.Module):
         op_code + b (+ the device-side step seed) over the block's output buffer.
         ``specaug``: int32 device tensor (B, 4, 2) of (begin, length) stripes - 2 over time, 2 over mel - masked on the
         log-mel as the reference's SpecAugmentation does in train mode (cnn_encoder.py:423-425).
-        ``train``: this is the forward of a training step (TrainEngine), with or without dropout."""
+        ``train``: this is the forward of a training step (TrainEngine), with or without dropout.
+        ``min_frames``: output frames of the shortest clip of the batch (``forward`` passes it).  The "f16x2" tier's
+        logit error grows as clips get shorter (fewer frames for the decoder's attention to average the fp16 rounding
+        over: 3e-4 at 10 s, 6e-4 at 3 s, up to 1.7e-3 at 1 s - DESIGN.md section 4), so a batch that contains a clip of
+        fewer than ``f16x2_min_frames`` (8, = 2.6 s) frames runs on the split-bf16 tier (3e-5 at any length)."""
         if wav.dim() != 2:
             raise ValueError("wav must be (batch, samples)")
         dev = wav.device
@@ -173,6 +178,8 @@ class Cnn14Encoder(nn.Module):
         # the "f16x2" tier keeps its activations in HBM as fp16; the train-mode forward (dropout on f32 block outputs,
         # parity pinned by tests/golden/g8_train.npz) stays on the split-bf16 tier
         algo = "bf16x3" if (self.conv_algo == "f16x2" and (train or dropout is not None)) else self.conv_algo
+        if algo == "f16x2" and min_frames is not None and min_frames < self.f16x2_min_frames:
+            algo = "bf16x3"
         pk = self._pack(dev, algo)
         B, L = wav.shape
         T, H, Hp = self.geometry(L)
@@ -228,8 +235,8 @@ class Cnn14Encoder(nn.Module):
                 "step (audiocaption_amd.train.TrainEngine); SpecAugment and the backward through the convolutions "
                 "are not built")
         wav = input_dict["wav"]
-        attn_emb = self.encode(wav)
         feat_length = cnn14_feat_len(input_dict["wav_len"], self.hop_length, self.downsample_ratio)
+        attn_emb = self.encode(wav, min_frames=int(feat_length.min()))
         out = {"attn_emb": attn_emb, "attn_emb_len": feat_length}
         if not skip_fc:
             # Cnn14's own clip embedding (cnn_encoder.py:451-456); CrnnEncoder discards it.

@@ -228,6 +228,38 @@ def test_cnn14_standalone_fc_emb(hip_model, state4981, conv_tier):
     assert _maxdiff("cnn fc_emb", out["fc_emb"], fc) < tol
 
 
+def test_short_clips_leave_the_fp16_activation_tier(hip_model, state4981):
+    """A batch that contains a clip of fewer than 8 output frames (2.6 s) runs on the split-bf16 tier: with so few frames
+    the fp16 rounding of the default tier is not averaged out (logit error up to 1.7e-3 at 1 s).  1 s clips must
+    therefore be within the f32-grade bar even though the default tier is "f16x2"."""
+    from audiocaption_amd import procedural as P
+    from oracle import cpu_path as O
+    cnn = hip_model.encoder.cnn
+    saved = cnn.conv_algo
+    cnn.conv_algo = "f16x2"
+    try:
+        wav_len = [32000, 20000]
+        wav = P.synthetic_wav(2, 32000, seed=9, varied=True)
+        wav[1, 20000:] = 0
+        wav = torch.from_numpy(wav)
+        want = O.caption_forward(state4981, wav, wav_len, "greedy", max_length=8)
+        out = hip_model({"mode": "inference", "wav": wav.cuda(), "wav_len": wav_len, "specaug": False,
+                         "sample_method": "greedy", "max_length": 8})
+        st = want["steps"]
+        assert torch.equal(out["seq"][:, :st], want["seq"][:, :st])
+        assert _maxdiff("1 s clips logit", out["logit"][:, :st], want["logit"][:, :st]) < 1e-4
+        # and the rule is what made it so: forced onto the fp16 tier the same clips are outside that bar
+        cnn.f16x2_min_frames, keep = 0, cnn.f16x2_min_frames
+        try:
+            forced = hip_model({"mode": "inference", "wav": wav.cuda(), "wav_len": wav_len, "specaug": False,
+                                "sample_method": "greedy", "max_length": 8})
+        finally:
+            cnn.f16x2_min_frames = keep
+        assert _maxdiff("1 s clips logit, fp16 tier forced", forced["logit"][:, :st], want["logit"][:, :st]) > 1e-4
+    finally:
+        cnn.conv_algo = saved
+
+
 def test_forward_async_equals_blocking_forward(hip_model):
     """Throughput mode (two streams, overlapped steps) returns exactly what the blocking call returns."""
     from audiocaption_amd import procedural as P
