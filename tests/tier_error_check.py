@@ -1,10 +1,10 @@
-"""Development tool: logit error of the conv tiers against the CPU oracle as a function of the clip length."""
+"""Checker script (lives under tests/ because it uses the oracle): logit error of the conv tiers against the CPU oracle as a function of the clip length."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import audiocaption_amd as A
 from audiocaption_amd import procedural as P
-from oracle import cpu_path as O   # checker (this is a development tool, not product code)
+from oracle import cpu_path as O   # checker
 vocab = 4368
 state = P.to_torch(P.cnn14rnn_trm_state(vocab))
 model = A.init_model_from_config(A.cnn14rnn_trm_config(vocab), print_fn=lambda s: None)
