@@ -280,6 +280,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(ConvParams p) {
 // ------------------------------------------------------------------------------------------------
 // pad (in 16-byte slots) that brings a patch row of (TC + 2) pixels x 5 slots to a pitch of 8 mod 16 (TC >= 8),
 // 4 mod 8 (TC = 4) or 2 mod 4 (TC = 2)
+// Column tiles (COLT kernels, W = 2 or 4): 32 consecutive rows of ONE column form an MFMA tile, so a ds_read_b128 walks the
+// patch at a stride of one patch row; an odd number of 16-byte slots per row spreads 16 lanes over the 16 bank slots.
+__host__ __device__ __forceinline__ int colt_row_pad_slots(int TC) { return (((TC + 2) * 5) & 1) ? 0 : 1; }
+
 __host__ __device__ __forceinline__ int patch_row_pad_slots(int TC) {
   const int base = (TC + 2) * 5;
   return TC >= 8 ? ((8 - base) & 15) : (TC == 4 ? ((4 - base) & 7) : ((2 - base) & 3));
@@ -465,6 +469,65 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16x3_kernel(ConvParams p) {
   conv_epilogue<BN, MODE>(p, acc, n_tile, row0, col0, wm, wn, lane);
 }
 
+// ---- epilogue of the column-tile kernels: m-tile mt = (row group mt / TC, column mt % TC) holds 32 consecutive rows
+// of one column; lane l owns channel l % 32 and rows 8 (r / 4) + 4 (l / 32) + r % 4 of the tile (MFMA output layout),
+// so vertically adjacent pixels are adjacent registers and horizontally adjacent ones are the same register of the
+// neighbouring m-tile: 2x2 pooling and the mean over the two mel columns stay in registers.  fp16 outputs (f32 for
+// MEANW), WM = 1 (a wave owns all four m-tiles of the block).
+template <int BN, int MODE, int TC>
+__device__ __forceinline__ void conv_epilogue_cols(const ConvParams& p, const f32x16 (&acc)[4][1], int n_tile, int row0,
+                                                   int wn, int lane) {
+  const int half = lane >> 5;
+  const int ch = n_tile * BN + wn * 32 + (lane & 31);
+  const float sc = p.scale[ch], sh = p.shift[ch];
+  _Float16* out16 = (_Float16*)p.out;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = 8 * (r >> 2) + 4 * half + (r & 3);
+    float y[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) y[m] = fmaxf(fmaf(acc[m][0][r], sc, sh), 0.f);
+    if (MODE == MODE_FULL) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int gr = row0 + (m / TC) * 32 + row, gc = m % TC;
+        if (gr < p.rows_total) {
+          const bool valid = (gr % p.Hp) < p.H;
+          out16[((size_t)gr * p.W + gc) * p.Cout + ch] = (_Float16)(valid ? y[m] : 0.f);
+        }
+      }
+    } else if (MODE == MODE_MEANW) {   // TC == 2: m = 2 rg + column
+#pragma unroll
+      for (int rg = 0; rg < 2; ++rg) {
+        const int gr = row0 + rg * 32 + row;
+        if (gr < p.rows_total) {
+          const int b = gr / p.Hp, h = gr - b * p.Hp;
+          if (h < p.H) p.out[((size_t)b * p.H + h) * p.Cout + ch] = 0.5f * (y[2 * rg] + y[2 * rg + 1]);
+        }
+      }
+    }
+  }
+  if (MODE == MODE_POOL) {   // TC == 4: m = column, one row group; windows = rows (2j, 2j+1) x columns (2 oc, 2 oc + 1)
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const int row = 8 * (r >> 2) + 4 * half + (r & 3);
+      const int gr = row0 + row;
+      if (gr >= p.rows_total) continue;
+      const int orow = gr >> 1;
+      const bool valid = (orow % p.Hp_out) < p.H_out;
+#pragma unroll
+      for (int oc = 0; oc < 2; ++oc) {
+        float o = 0.f;
+#pragma unroll
+        for (int dm = 0; dm < 2; ++dm)
+#pragma unroll
+          for (int dr = 0; dr < 2; ++dr) o += fmaxf(fmaf(acc[2 * oc + dm][0][r + dr], sc, sh), 0.f);
+        out16[((size_t)orow * p.W_out + oc) * p.Cout + ch] = (_Float16)(valid ? 0.25f * o : 0.f);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // bf16x3, weights straight from L2 ("gw"): the B fragments never touch LDS.  Weights are pre-packed in MFMA
 // fragment order, [Cin/32][9 taps][2 k-steps][Cout/32][hi, lo][64 lanes][8 bf16], so a wave's fragment is
@@ -486,8 +549,12 @@ __device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {
   return __builtin_bit_cast(unsigned, h);
 }
 
-template <int BN, int MODE, int PREC, int WM, int BM, bool FUSE1, int TAPS>
+template <int BN, int MODE, int PREC, int WM, int BM, bool FUSE1, int TAPS, int COLT>
 __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(ConvParams p) {
+  // COLT = 2 or 4 (the layers with W = 2 / 4 mel columns, PREC 1, WM 1): COLUMN tiles - an MFMA tile is 32 consecutive
+  // rows of one column instead of 2x2 windows over all columns.  With so few columns a third (W = 2) or a sixth (W = 4)
+  // of the window tiles' products multiply the zero padding left and right of the image; a column tile knows which
+  // taps fall outside (kx = 0 for the first column, kx = 2 for the last) and skips their MFMAs and fragment reads.
   // TAPS = 9: the 3x3 convolution.  TAPS = 1 (PREC 0 only): a plain GEMM - rows are the "pixels" of a 2-wide image, no
   // halo - through the same staging / fragment / epilogue machinery: the big f32 linear layers of the path
   // (ac_linear_bf16x3).  With one tap a chunk is only 12-24 MFMAs per wave, so the next chunk's rows are requested
@@ -516,7 +583,7 @@ __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(Conv
   const int NPIX = PW * PH;
   const int row0 = (m_tile / p.mt_cols) * TR;
   const int col0 = (m_tile % p.mt_cols) * TC;
-  const int PITCH = PW * BROW + patch_row_pad_slots(TC) * 8;
+  const int PITCH = PW * BROW + (COLT ? colt_row_pad_slots(TC) : patch_row_pad_slots(TC)) * 8;
   const int PLANE = PH * PITCH;
   __bf16* sAh = (__bf16*)dsm_raw;
   __bf16* sAl = sAh + PLANE;   // PREC 0: the lo plane
@@ -530,7 +597,8 @@ __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(Conv
     const int qr = q >> (p.tc_log2 - 1);
 #pragma unroll
     for (int m = 0; m < MW; ++m)
-      pbase[m] = ((MW * wm + m) * QR2 + 2 * qr + dy) * PITCH + (2 * qc + dx) * BROW + half * 8;
+      pbase[m] = COLT ? ((m / (COLT ? COLT : 1)) * 32 + i) * PITCH + (m % (COLT ? COLT : 1)) * BROW + half * 8
+                      : ((MW * wm + m) * QR2 + 2 * qr + dy) * PITCH + (2 * qc + dx) * BROW + half * 8;
   }
 
   f32x16 acc[MW][NTW];
@@ -710,11 +778,14 @@ __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(Conv
         bf16x8 ah[MW], al[MW];
 #pragma unroll
         for (int m = 0; m < MW; ++m) {
+          if (COLT && ((kx == 0 && m % (COLT ? COLT : 1) == 0) || (kx == 2 && m % (COLT ? COLT : 1) == COLT - 1))) continue;
           ah[m] = *(const bf16x8*)(sAh + aoff + pbase[m] + ks * 16);
           if (PREC == 0) al[m] = *(const bf16x8*)(sAl + aoff + pbase[m] + ks * 16);
         }
 #pragma unroll
-        for (int m = 0; m < MW; ++m)
+        for (int m = 0; m < MW; ++m) {
+          // column tile whose tap reads the zero padding beside the image: nothing to add
+          if (COLT && ((kx == 0 && m % (COLT ? COLT : 1) == 0) || (kx == 2 && m % (COLT ? COLT : 1) == COLT - 1))) continue;
 #pragma unroll
           for (int n = 0; n < NTW; ++n) {
             if (PREC == 0) {
@@ -727,6 +798,7 @@ __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(Conv
               acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(f16x8, wc[ks][n][0]), acc[m][n], 0, 0, 0);
             }
           }
+        }
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -747,10 +819,11 @@ __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(Conv
       }
     }
   }
-  conv_epilogue<BN, MODE, MW, NTW, PREC == 1>(p, acc, n_tile, row0, col0, wm, wn, lane);
+  if constexpr (COLT != 0) conv_epilogue_cols<BN, MODE, COLT>(p, acc, n_tile, row0, wn, lane);
+  else conv_epilogue<BN, MODE, MW, NTW, PREC == 1>(p, acc, n_tile, row0, col0, wm, wn, lane);
 }
 
-template <int BN, int MODE, int PREC = 0, int WM = 2, int BM = 128, bool FUSE1 = false, int TAPS = 9>
+template <int BN, int MODE, int PREC = 0, int WM = 2, int BM = 128, bool FUSE1 = false, int TAPS = 9, int COLT = 0>
 int launch_conv_gw(ConvParams p, hipStream_t s) {
   const int TC = 1 << p.tc_log2, TR = BM >> p.tc_log2;
   p.MT = ((p.rows_total + TR - 1) / TR) * p.mt_cols;
@@ -759,10 +832,10 @@ int launch_conv_gw(ConvParams p, hipStream_t s) {
   else if (p.map_mode == 3) grid = (unsigned)(((p.MT + 8 / p.NT - 1) / (8 / p.NT)) * 8);
   else grid = (unsigned)(p.MT * p.NT);
   constexpr int HALO = TAPS == 9 ? 1 : 0;
-  const int pitch = (TC + 2 * HALO) * BROW + patch_row_pad_slots(TC) * 8;
+  const int pitch = (TC + 2 * HALO) * BROW + (COLT ? colt_row_pad_slots(TC) : patch_row_pad_slots(TC)) * 8;
   // hi + lo planes (bf16) or one fp16 plane (+ the log-mel patch of the fused first layer)
   const size_t lds = (size_t)(TR + 2 * HALO) * pitch * 2 * (PREC == 0 ? 2 : 1) + (FUSE1 ? (TR + 4) * 21 * 4 : 0);
-  hipLaunchKernelGGL((conv3x3_gw_kernel<BN, MODE, PREC, WM, BM, FUSE1, TAPS>), dim3(grid), dim3(256), lds, s, p);
+  hipLaunchKernelGGL((conv3x3_gw_kernel<BN, MODE, PREC, WM, BM, FUSE1, TAPS, COLT>), dim3(grid), dim3(256), lds, s, p);
   return ac_check_launch();
 }
 
@@ -981,6 +1054,15 @@ static int conv_gw_dispatch(int prec, const float* in, const void* wfrag, const 
     if (TC == 16 && (bm256 & 2)) {
       if (mode == MODE_FULL) return launch_conv_gw<128, MODE_FULL, 1, 2, 256>(p, s);
       if (mode == MODE_POOL) return launch_conv_gw<128, MODE_POOL, 1, 2, 256>(p, s);
+    }
+    static const bool colt = getenv("AC_GW_NO_COLT") == nullptr;   // column tiles for the 2- and 4-column layers
+    if (colt && TC == 2) {
+      if (mode == MODE_FULL) return launch_conv_gw<128, MODE_FULL, 1, 1, 128, false, 9, 2>(p, s);
+      if (mode == MODE_MEANW) return launch_conv_gw<128, MODE_MEANW, 1, 1, 128, false, 9, 2>(p, s);
+    }
+    if (colt && TC == 4) {
+      if (mode == MODE_FULL) return launch_conv_gw<128, MODE_FULL, 1, 1, 128, false, 9, 4>(p, s);
+      if (mode == MODE_POOL) return launch_conv_gw<128, MODE_POOL, 1, 1, 128, false, 9, 4>(p, s);
     }
     if (mode == MODE_FULL) return launch_conv_gw<128, MODE_FULL, 1, 1>(p, s);
     if (mode == MODE_POOL) return launch_conv_gw<128, MODE_POOL, 1, 1>(p, s);
