@@ -663,6 +663,11 @@ class TrainEngine:
         else:
             gkey = (smoothing, _lib.param_generation_flat(self), st["ws"].gen)
             if st["graph"] is None or st["graph_key"] != gkey:
+                # weight repacks (host uploads, float64 transforms of the Winograd tier) must not land inside the
+                # capture: pack the frozen Cnn14 for the tier the train-mode forward uses now
+                cnn = getattr(self.model.encoder, "cnn", None)
+                if cnn is not None and hasattr(cnn, "_pack"):
+                    cnn._pack(st["cap"].device, "bf16x3" if cnn.conv_algo == "f16x2" else cnn.conv_algo)
                 torch.cuda.synchronize(st["cap"].device)
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
