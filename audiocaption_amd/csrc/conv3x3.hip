@@ -78,6 +78,23 @@ __device__ __forceinline__ bool conv_block_map(const ConvParams& p, int& m_tile,
 // (2x8, 4x4 or 8x2 pixels), which a suitable patch row pitch then spreads over all 16 bank slots.
 __device__ __forceinline__ int window_pos(int q) { return (0x73261540 >> (4 * q)) & 7; }  // [0,4,5,1,6,2,3,7]
 
+// x mod d (and x / d) for 0 <= x < 2^23 with a reciprocal computed once per wave: the epilogues need the row inside the
+// clip of 16-64 output rows per wave, and an integer division by the run-time Hp costs ~25 instructions each.
+struct FastDiv {
+  int d;
+  float inv;
+  __device__ __forceinline__ explicit FastDiv(int d_) : d(d_), inv(1.0f / (float)d_) {}
+  __device__ __forceinline__ int div(int x, int& rem) const {
+    int q = (int)((float)x * inv);
+    int r = x - q * d;
+    if (r < 0) { r += d; --q; }
+    if (r >= d) { r -= d; ++q; }
+    rem = r;
+    return q;
+  }
+  __device__ __forceinline__ int mod(int x) const { int r; div(x, r); return r; }
+};
+
 // ---- epilogue: BN scale/shift, ReLU, pooling, zero rows; lanes 0..31 store 32 consecutive channels ----
 // acc[m][n] = 32x32 tile (m-th pixel tile, n-th channel tile of this wave), MFMA row i = 4*window + 2*dy + dx
 // A wave owns MW pixel tiles (wm * MW + m of the block's four) and NTW channel tiles (wn * NTW + n).
@@ -89,6 +106,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 
   const int half = lane >> 5;
   const int TC = 1 << p.tc_log2;
   const int QR2 = 32 >> p.tc_log2;
+  const FastDiv by_hp(p.Hp), by_hp_out(MODE == MODE_POOL ? p.Hp_out : 1);
 #pragma unroll
   for (int n = 0; n < NTW; ++n) {
     const int ch = n_tile * BN + (wn * NTW + n) * 32 + (lane & 31);
@@ -114,7 +132,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 
           for (int e = 0; e < 4; ++e) {
             const int gr = wy + (e >> 1), gc = wx + (e & 1);
             if (gr < p.rows_total && (p.m_valid == 0 || gr * p.W + gc < p.m_valid)) {
-              const bool valid = (gr % p.Hp) < p.H;
+              const bool valid = by_hp.mod(gr) < p.H;
               const size_t o = ((size_t)gr * p.W + gc) * p.Cout + ch;
               if (OUT16) ((_Float16*)p.out)[o] = (_Float16)(valid ? y[e] : 0.f);
               else p.out[o] = valid ? y[e] : 0.f;
@@ -123,7 +141,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 
         } else if (MODE == MODE_POOL) {
           const int orow = wy >> 1, ocol = wx >> 1;
           if (wy < p.rows_total) {
-            const bool valid = (orow % p.Hp_out) < p.H_out;
+            const bool valid = by_hp_out.mod(orow) < p.H_out;
             const float o = 0.25f * ((y[0] + y[1]) + (y[2] + y[3]));
             const size_t oi = ((size_t)orow * p.W_out + ocol) * p.Cout + ch;
             if (OUT16) ((_Float16*)p.out)[oi] = (_Float16)(valid ? o : 0.f);
@@ -134,7 +152,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 
           for (int dy = 0; dy < 2; ++dy) {
             const int gr = wy + dy;
             if (gr < p.rows_total) {
-              const int b = gr / p.Hp, h = gr - b * p.Hp;
+              int h;
+              const int b = by_hp.div(gr, h);
               if (h < p.H) p.out[((size_t)b * p.H + h) * p.Cout + ch] = 0.5f * (y[2 * dy] + y[2 * dy + 1]);
             }
           }
@@ -481,6 +500,7 @@ __device__ __forceinline__ void conv_epilogue_cols(const ConvParams& p, const f3
   const int ch = n_tile * BN + wn * 32 + (lane & 31);
   const float sc = p.scale[ch], sh = p.shift[ch];
   _Float16* out16 = (_Float16*)p.out;
+  const FastDiv by_hp(p.Hp), by_hp_out(MODE == MODE_POOL ? p.Hp_out : 1);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = 8 * (r >> 2) + 4 * half + (r & 3);
@@ -492,7 +512,7 @@ __device__ __forceinline__ void conv_epilogue_cols(const ConvParams& p, const f3
       for (int m = 0; m < 4; ++m) {
         const int gr = row0 + (m / TC) * 32 + row, gc = m % TC;
         if (gr < p.rows_total) {
-          const bool valid = (gr % p.Hp) < p.H;
+          const bool valid = by_hp.mod(gr) < p.H;
           out16[((size_t)gr * p.W + gc) * p.Cout + ch] = (_Float16)(valid ? y[m] : 0.f);
         }
       }
@@ -501,7 +521,8 @@ __device__ __forceinline__ void conv_epilogue_cols(const ConvParams& p, const f3
       for (int rg = 0; rg < 2; ++rg) {
         const int gr = row0 + rg * 32 + row;
         if (gr < p.rows_total) {
-          const int b = gr / p.Hp, h = gr - b * p.Hp;
+          int h;
+          const int b = by_hp.div(gr, h);
           if (h < p.H) p.out[((size_t)b * p.H + h) * p.Cout + ch] = 0.5f * (y[2 * rg] + y[2 * rg + 1]);
         }
       }
@@ -514,7 +535,7 @@ __device__ __forceinline__ void conv_epilogue_cols(const ConvParams& p, const f3
       const int gr = row0 + row;
       if (gr >= p.rows_total) continue;
       const int orow = gr >> 1;
-      const bool valid = (orow % p.Hp_out) < p.H_out;
+      const bool valid = by_hp_out.mod(orow) < p.H_out;
 #pragma unroll
       for (int oc = 0; oc < 2; ++oc) {
         float o = 0.f;
