@@ -562,6 +562,14 @@ __device__ __forceinline__ void conv_epilogue_cols(const ConvParams& p, const f3
 //   folds the inverse into the BN scale), two products per f32 product on v_mfma_f32_32x32x16_f16, f32
 //   accumulation.  One LDS plane instead of two.  More accurate than the TF32 convolutions (2^-11 on BOTH operands)
 //   the reference itself runs with on its GPUs (torch.backends.cudnn.allow_tf32 defaults to True).
+//
+// Instances in use (the other template parameters are explained at the top of the kernel body):
+//   <128|64, MODE, 0, 2, 128, false, 9, 0>   split-bf16 tier, 2x2 waves                    (ac_conv3x3_bn_relu_bf16x3_gw)
+//   <128,    MODE, 1, 1, 128, false, 9, 0>   fp16 tier, 1x4 waves: blocks 2-4               (ac_conv3x3_bn_relu_f16x2_gw)
+//   <128,    MODE, 1, 1, 128, false, 9, 4|2> fp16 tier, column tiles: blocks 5 and 6        (same entry, W = 4 / 2)
+//   <64,     POOL, 1, 2, 256, true,  9, 0>   fp16 tier, block 1 with conv1 fused            (ac_conv3x3_block1_f16x2)
+//   <64,     MODE, 1, 2, 256|128, false, 9, 0> fp16 tier, Cout = 64 without the fusion
+//   <64,     FULL|LINEAR, 0, 2, 128, false, 1, 0> one-tap GEMM: large linear layers          (ac_linear_bf16x3)
 // ------------------------------------------------------------------------------------------------
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
@@ -584,7 +592,7 @@ __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(Conv
   // FUSE1 (block 1 of the f16x2 tier: Cin = Cout = 64, W = 64, 256-pixel blocks): the input of this convolution is
   // itself conv1 + BN + ReLU of the 1-channel log-mel.  Instead of reading it from HBM (0.5 GB written by a separate
   // kernel, 0.7 GB read back with the halo) the workgroup computes its 18x18x64 patch from a 20x20 patch of the
-  // log-mel: 72 FMAs (36 packed) per staged fp16 item on the vector ALUs, under the other workgroups' MFMAs.
+  // log-mel: 72 FMAs with wave-uniform (scalar-register) weights per staged fp16 item on the vector ALUs, under the other workgroups' MFMAs.
   // wave grid WM (pixel tiles) x WN (channel tiles); WM = 1 makes every wave walk all 128 pixels of the block for
   // 32 channels: half the weight-fragment bytes per MFMA (the L1/L2 stream that limits the two-product tier)
   // BM = pixels per block (128, or 256 for the wide early layers: MW doubles, the halo overhead shrinks)
