@@ -493,9 +493,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16x3_kernel(ConvParams p) {
 // so vertically adjacent pixels are adjacent registers and horizontally adjacent ones are the same register of the
 // neighbouring m-tile: 2x2 pooling and the mean over the two mel columns stay in registers.  fp16 outputs (f32 for
 // MEANW), WM = 1 (a wave owns all four m-tiles of the block).
-template <int BN, int MODE, int TC>
-__device__ __forceinline__ void conv_epilogue_cols(const ConvParams& p, const f32x16 (&acc)[4][1], int n_tile, int row0,
-                                                   int wn, int lane) {
+template <int BN, int MODE, int TC, int MW>
+__device__ __forceinline__ void conv_epilogue_cols(const ConvParams& p, const f32x16 (&acc)[MW][1], int n_tile, int row0,
+                                                   int col0, int wn, int lane) {
   const int half = lane >> 5;
   const int ch = n_tile * BN + wn * 32 + (lane & 31);
   const float sc = p.scale[ch], sh = p.shift[ch];
@@ -504,13 +504,13 @@ __device__ __forceinline__ void conv_epilogue_cols(const ConvParams& p, const f3
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = 8 * (r >> 2) + 4 * half + (r & 3);
-    float y[4];
+    float y[MW];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) y[m] = fmaxf(fmaf(acc[m][0][r], sc, sh), 0.f);
+    for (int m = 0; m < MW; ++m) y[m] = fmaxf(fmaf(acc[m][0][r], sc, sh), 0.f);
     if (MODE == MODE_FULL) {
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int gr = row0 + (m / TC) * 32 + row, gc = m % TC;
+      for (int m = 0; m < MW; ++m) {
+        const int gr = row0 + (m / TC) * 32 + row, gc = col0 + m % TC;
         if (gr < p.rows_total) {
           const bool valid = by_hp.mod(gr) < p.H;
           out16[((size_t)gr * p.W + gc) * p.Cout + ch] = (_Float16)(valid ? y[m] : 0.f);
@@ -518,7 +518,7 @@ __device__ __forceinline__ void conv_epilogue_cols(const ConvParams& p, const f3
       }
     } else if (MODE == MODE_MEANW) {   // TC == 2: m = 2 rg + column
 #pragma unroll
-      for (int rg = 0; rg < 2; ++rg) {
+      for (int rg = 0; rg < MW / 2; ++rg) {
         const int gr = row0 + rg * 32 + row;
         if (gr < p.rows_total) {
           int h;
@@ -528,22 +528,25 @@ __device__ __forceinline__ void conv_epilogue_cols(const ConvParams& p, const f3
       }
     }
   }
-  if (MODE == MODE_POOL) {   // TC == 4: m = column, one row group; windows = rows (2j, 2j+1) x columns (2 oc, 2 oc + 1)
+  if (MODE == MODE_POOL) {   // m = TC rg + column; windows = rows (2j, 2j+1) x columns (2 oc, 2 oc + 1)
 #pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-      const int row = 8 * (r >> 2) + 4 * half + (r & 3);
-      const int gr = row0 + row;
-      if (gr >= p.rows_total) continue;
-      const int orow = gr >> 1;
-      const bool valid = by_hp_out.mod(orow) < p.H_out;
+    for (int rg = 0; rg < MW / TC; ++rg) {
 #pragma unroll
-      for (int oc = 0; oc < 2; ++oc) {
-        float o = 0.f;
+      for (int r = 0; r < 16; r += 2) {
+        const int row = 8 * (r >> 2) + 4 * half + (r & 3);
+        const int gr = row0 + rg * 32 + row;
+        if (gr >= p.rows_total) continue;
+        const int orow = gr >> 1;
+        const bool valid = by_hp_out.mod(orow) < p.H_out;
 #pragma unroll
-        for (int dm = 0; dm < 2; ++dm)
+        for (int oc = 0; oc < TC / 2; ++oc) {
+          float o = 0.f;
 #pragma unroll
-          for (int dr = 0; dr < 2; ++dr) o += fmaxf(fmaf(acc[2 * oc + dm][0][r + dr], sc, sh), 0.f);
-        out16[((size_t)orow * p.W_out + oc) * p.Cout + ch] = (_Float16)(valid ? 0.25f * o : 0.f);
+          for (int dm = 0; dm < 2; ++dm)
+#pragma unroll
+            for (int dr = 0; dr < 2; ++dr) o += fmaxf(fmaf(acc[rg * TC + 2 * oc + dm][0][r + dr], sc, sh), 0.f);
+          out16[((size_t)orow * p.W_out + (col0 >> 1) + oc) * p.Cout + ch] = (_Float16)(valid ? 0.25f * o : 0.f);
+        }
       }
     }
   }
@@ -565,8 +568,9 @@ __device__ __forceinline__ void conv_epilogue_cols(const ConvParams& p, const f3
 //
 // Instances in use (the other template parameters are explained at the top of the kernel body):
 //   <128|64, MODE, 0, 2, 128, false, 9, 0>   split-bf16 tier, 2x2 waves                    (ac_conv3x3_bn_relu_bf16x3_gw)
-//   <128,    MODE, 1, 1, 128, false, 9, 0>   fp16 tier, 1x4 waves: blocks 2-4               (ac_conv3x3_bn_relu_f16x2_gw)
-//   <128,    MODE, 1, 1, 128, false, 9, 4|2> fp16 tier, column tiles: blocks 5 and 6        (same entry, W = 4 / 2)
+//   <128,    MODE, 1, 1, 256, false, 9, 8|4> fp16 tier, column tiles, 256-pixel blocks: W >= 8 / W = 4 (blocks 2-5)
+//   <128,    MODE, 1, 1, 128, false, 9, 2>   fp16 tier, column tiles: W = 2 (block 6)       (ac_conv3x3_bn_relu_f16x2_gw)
+//   <128,    MODE, 1, 1, 128, false, 9, 0>   fp16 tier, 2x2-window tiles, 1x4 waves (AC_GW_COLT8=0 / AC_GW_NO_COLT)
 //   <64,     POOL, 1, 2, 256, true,  9, 0>   fp16 tier, block 1 with conv1 fused            (ac_conv3x3_block1_f16x2)
 //   <64,     MODE, 1, 2, 256|128, false, 9, 0> fp16 tier, Cout = 64 without the fusion
 //   <64,     FULL|LINEAR, 0, 2, 128, false, 1, 0> one-tap GEMM: large linear layers          (ac_linear_bf16x3)
@@ -612,6 +616,7 @@ __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(Conv
   const int NPIX = PW * PH;
   const int row0 = (m_tile / p.mt_cols) * TR;
   const int col0 = (m_tile % p.mt_cols) * TC;
+  const bool at_left = col0 == 0, at_right = col0 + TC == p.W;   // column tiles: which edge columns touch the padding
   const int PITCH = PW * BROW + (COLT ? colt_row_pad_slots(TC) : patch_row_pad_slots(TC)) * 8;
   const int PLANE = PH * PITCH;
   __bf16* sAh = (__bf16*)dsm_raw;
@@ -660,7 +665,8 @@ __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(Conv
     // 32-channel chunk and made the kernel's VALU time comparable to its MFMA time.
     // An item is 16 bytes of one pixel: 4 f32 channels (PREC 0) or 8 fp16 channels (PREC 1, copied as they are).
     constexpr int IPP = PREC == 0 ? 8 : 4;          // items per pixel and 32-channel chunk
-    constexpr int GW_MAXIT = PREC == 0 ? 9 : (BM == 128 ? 5 : 6);   // >= ceil(max NPIX * IPP / 256); BM 256: TC = 16 only
+    // >= ceil(NPIX * IPP / 256); 256-pixel blocks: TC = 16 -> 324 pixels, 8 -> 340, 4 -> 396, 2 -> 520
+    constexpr int GW_MAXIT = PREC == 0 ? 9 : (BM == 128 ? 5 : (COLT == 2 ? 9 : 7));
     constexpr unsigned GW_NONE = 0xffffffffu, GW_OOB = 0x80000000u;
     unsigned goff[GW_MAXIT], loff[GW_MAXIT];
 #pragma unroll
@@ -807,14 +813,16 @@ __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(Conv
         bf16x8 ah[MW], al[MW];
 #pragma unroll
         for (int m = 0; m < MW; ++m) {
-          if (COLT && ((kx == 0 && m % (COLT ? COLT : 1) == 0) || (kx == 2 && m % (COLT ? COLT : 1) == COLT - 1))) continue;
+          if (COLT && ((kx == 0 && m % (COLT ? COLT : 1) == 0 && at_left) ||
+                       (kx == 2 && m % (COLT ? COLT : 1) == COLT - 1 && at_right))) continue;
           ah[m] = *(const bf16x8*)(sAh + aoff + pbase[m] + ks * 16);
           if (PREC == 0) al[m] = *(const bf16x8*)(sAl + aoff + pbase[m] + ks * 16);
         }
 #pragma unroll
         for (int m = 0; m < MW; ++m) {
           // column tile whose tap reads the zero padding beside the image: nothing to add
-          if (COLT && ((kx == 0 && m % (COLT ? COLT : 1) == 0) || (kx == 2 && m % (COLT ? COLT : 1) == COLT - 1))) continue;
+          if (COLT && ((kx == 0 && m % (COLT ? COLT : 1) == 0 && at_left) ||
+                       (kx == 2 && m % (COLT ? COLT : 1) == COLT - 1 && at_right))) continue;
 #pragma unroll
           for (int n = 0; n < NTW; ++n) {
             if (PREC == 0) {
@@ -848,7 +856,7 @@ __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(Conv
       }
     }
   }
-  if constexpr (COLT != 0) conv_epilogue_cols<BN, MODE, COLT>(p, acc, n_tile, row0, wn, lane);
+  if constexpr (COLT != 0) conv_epilogue_cols<BN, MODE, COLT, MW>(p, acc, n_tile, row0, col0, wn, lane);
   else conv_epilogue<BN, MODE, MW, NTW, PREC == 1>(p, acc, n_tile, row0, col0, wm, wn, lane);
 }
 
@@ -1088,6 +1096,31 @@ static int conv_gw_dispatch(int prec, const float* in, const void* wfrag, const 
     if (colt && TC == 2) {
       if (mode == MODE_FULL) return launch_conv_gw<128, MODE_FULL, 1, 1, 128, false, 9, 2>(p, s);
       if (mode == MODE_MEANW) return launch_conv_gw<128, MODE_MEANW, 1, 1, 128, false, 9, 2>(p, s);
+    }
+    static const bool wide1 = getenv("AC_GW_BM256W1") != nullptr;   // 256-pixel blocks, 1x4 waves, window tiles (W >= 16)
+    if (wide1 && TC == 16) {
+      if (mode == MODE_FULL) return launch_conv_gw<128, MODE_FULL, 1, 1, 256>(p, s);
+      if (mode == MODE_POOL) return launch_conv_gw<128, MODE_POOL, 1, 1, 256>(p, s);
+    }
+    // Layers of 8 and more columns (up to AC_GW_COLT8, default all; 0: off) run as 256-pixel column-tile blocks of
+    // 8 columns x 32 rows: a wave walks eight 32-row tiles per weight fragment - half the weight-fragment bytes per MFMA
+    // of the 128-pixel blocks, which is what those were waiting for (conv stack 4.60 -> 4.33 ms)
+    static const int colt8 = getenv("AC_GW_COLT8") ? atoi(getenv("AC_GW_COLT8")) : 64;
+    if (colt8 > 0 && W >= 8 && W <= colt8 && mode != MODE_MEANW) {
+      p.tc_log2 = 3;
+      p.mt_cols = W / 8;
+      if (mode == MODE_FULL) return launch_conv_gw<128, MODE_FULL, 1, 1, 256, false, 9, 8>(p, s);
+      return launch_conv_gw<128, MODE_POOL, 1, 1, 256, false, 9, 8>(p, s);
+    }
+    static const bool colt2_256 = getenv("AC_GW_COLT2_256") != nullptr;
+    if (colt && TC == 2 && colt2_256) {
+      if (mode == MODE_FULL) return launch_conv_gw<128, MODE_FULL, 1, 1, 256, false, 9, 2>(p, s);
+      if (mode == MODE_MEANW) return launch_conv_gw<128, MODE_MEANW, 1, 1, 256, false, 9, 2>(p, s);
+    }
+    static const bool colt4_256 = getenv("AC_GW_COLT4_128") == nullptr;   // 4-column layers: 256-pixel blocks (64 rows)
+    if (colt && TC == 4 && colt4_256) {
+      if (mode == MODE_FULL) return launch_conv_gw<128, MODE_FULL, 1, 1, 256, false, 9, 4>(p, s);
+      if (mode == MODE_POOL) return launch_conv_gw<128, MODE_POOL, 1, 1, 256, false, 9, 4>(p, s);
     }
     if (colt && TC == 4) {
       if (mode == MODE_FULL) return launch_conv_gw<128, MODE_FULL, 1, 1, 128, false, 9, 4>(p, s);
