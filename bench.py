@@ -400,7 +400,7 @@ def main():
     kname = {"winograd": "conv3x3_wino_kernel<POOL>", "direct": "conv3x3_mfma_kernel<128, POOL>",
              "bf16x3": "conv3x3_gw_kernel<128, POOL, PREC 0 (split bf16), 2x2 waves, 128 px>",
              "bf16x3_lds": "conv3x3_bf16x3_kernel<128, POOL>",
-             "f16x2": "conv3x3_gw_kernel<128, POOL, PREC 1 (fp16 x 2), 1x4 waves, 128 px>"}[algo]
+             "f16x2": "conv3x3_gw_kernel<128, POOL, PREC 1 (fp16 x 2), 1x4 waves, 256-pixel column-tile blocks>"}[algo]
 
     # dominant kernel: conv3x3_mfma_kernel<128, POOL> (conv2 of blocks 2-5)
     flops = sum(2.0 * 9 * i["Cin"] * i["Cout"] * i["H"] * i["W"] * i["B"] for _, _, i in events)
