@@ -488,6 +488,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16x3_kernel(ConvParams p) {
   conv_epilogue<BN, MODE>(p, acc, n_tile, row0, col0, wm, wn, lane);
 }
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {
+  const f16x2v h = {(_Float16)a, (_Float16)b};
+  return __builtin_bit_cast(unsigned, h);
+}
+
 // ---- epilogue of the column-tile kernels: m-tile mt = (row group mt / TC, column mt % TC) holds 32 consecutive rows
 // of one column; lane l owns channel l % 32 and rows 8 (r / 4) + 4 (l / 32) + r % 4 of the tile (MFMA output layout),
 // so vertically adjacent pixels are adjacent registers and horizontally adjacent ones are the same register of the
@@ -508,12 +515,22 @@ __device__ __forceinline__ void conv_epilogue_cols(const ConvParams& p, const f3
 #pragma unroll
     for (int m = 0; m < MW; ++m) y[m] = fmaxf(fmaf(acc[m][0][r], sc, sh), 0.f);
     if (MODE == MODE_FULL) {
+      // Lane pairs (channels 2j, 2j+1) trade values so that every lane stores ONE 4-byte word: the even lane both
+      // channels of row r, the odd lane both channels of row r + 1 (r even: the rows are adjacent registers) - half the
+      // store instructions of one 2-byte store per value.
+      if (r & 1) continue;
+      const bool odd = lane & 1;
+      const int myrow = row + (odd ? 1 : 0);
 #pragma unroll
       for (int m = 0; m < MW; ++m) {
-        const int gr = row0 + (m / TC) * 32 + row, gc = col0 + m % TC;
+        const float a = y[m], b = fmaxf(fmaf(acc[m][0][r + 1], sc, sh), 0.f);
+        const float pa = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0xB1, 0xF, 0xF, true));
+        const float pb = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0xB1, 0xF, 0xF, true));
+        const int gr = row0 + (m / TC) * 32 + myrow, gc = col0 + m % TC;
         if (gr < p.rows_total) {
           const bool valid = by_hp.mod(gr) < p.H;
-          out16[((size_t)gr * p.W + gc) * p.Cout + ch] = (_Float16)(valid ? y[m] : 0.f);
+          const unsigned word = valid ? cvt_pk_f16(odd ? pb : a, odd ? b : pa) : 0u;
+          *(unsigned*)(out16 + ((size_t)gr * p.W + gc) * p.Cout + (ch & ~1)) = word;
         }
       }
     } else if (MODE == MODE_MEANW) {   // TC == 2: m = 2 rg + column
@@ -575,13 +592,6 @@ __device__ __forceinline__ void conv_epilogue_cols(const ConvParams& p, const f3
 //   <64,     MODE, 1, 2, 256|128, false, 9, 0> fp16 tier, Cout = 64 without the fusion
 //   <64,     FULL|LINEAR, 0, 2, 128, false, 1, 0> one-tap GEMM: large linear layers          (ac_linear_bf16x3)
 // ------------------------------------------------------------------------------------------------
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {
-  const f16x2v h = {(_Float16)a, (_Float16)b};
-  return __builtin_bit_cast(unsigned, h);
-}
-
 template <int BN, int MODE, int PREC, int WM, int BM, bool FUSE1, int TAPS, int COLT>
 __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(ConvParams p) {
   // COLT = 2 or 4 (the layers with W = 2 / 4 mel columns, PREC 1, WM 1): COLUMN tiles - an MFMA tile is 32 consecutive
