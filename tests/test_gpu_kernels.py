@@ -167,7 +167,7 @@ def _to_rows(x_nchw, Hp):
     (2, 11, 16, 128, 256, 0), (2, 9, 8, 256, 512, 1), (3, 7, 4, 512, 1024, 0), (3, 6, 4, 1024, 1024, 1),
     (5, 3, 2, 1024, 2048, 0), (5, 3, 2, 2048, 2048, 2), (1, 31, 2, 64, 128, 2), (2, 30, 16, 32, 64, 1)])
 @pytest.mark.parametrize("map_mode", [-1, 0])
-@pytest.mark.parametrize("algo", ["direct", "winograd", "bf16x3", "bf16x3_gw"])
+@pytest.mark.parametrize("algo", ["direct", "winograd", "bf16x3", "bf16x3_gw", "f16x2"])
 def test_conv3x3_bn_relu(K, B, H, W, Cin, Cout, mode, map_mode, algo):
     """conv3x3+BN+ReLU(+pool / +mean over W) vs F.conv2d on the CPU.  Tolerance 1e-4 * sqrt(K/576) abs on
     O(1) activations (fp32 accumulation-order differences only)."""
@@ -176,6 +176,10 @@ def test_conv3x3_bn_relu(K, B, H, W, Cin, Cout, mode, map_mode, algo):
         pytest.skip("linear mapping only exercised on the small shapes")
     g = torch.Generator().manual_seed(B * 1000 + H * 10 + W + Cin)
     x = torch.randn(B, Cin, H, W, generator=g)
+    if algo == "f16x2":
+        # the tier's input format IS fp16: the reference convolves the same fp16-representable activations, so the
+        # test isolates the kernel (column tiles, tap skipping, fp16 hi+lo weights, packed fp16 stores)
+        x = x.half().float()
     w = torch.randn(Cout, Cin, 3, 3, generator=g) * math.sqrt(2.0 / (9 * Cin))
     sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
     y = F.relu(F.conv2d(x, w, padding=1) * sc[None, :, None, None] + sh[None, :, None, None])
@@ -200,12 +204,22 @@ def test_conv3x3_bn_relu(K, B, H, W, Cin, Cout, mode, map_mode, algo):
     elif algo == "bf16x3":
         K.conv3x3_bn_relu_bf16x3(_to_rows(x, Hp).cuda(), K.pack_conv_weight_bf16x3(w.cuda()), sc.cuda(),
                                  sh.cuda(), out, B, Hp, H, W, Cin, Cout, mode, map_mode)
+    elif algo == "f16x2":
+        wfrag, inv = K.pack_conv_weight_f16x2_frag(w.cuda())
+        out16 = out if mode == 2 else torch.full(out.shape, 7.0, dtype=torch.float16, device="cuda")
+        K.conv3x3_bn_relu_f16x2_gw(_to_rows(x, Hp).cuda().half(), wfrag, (sc.cuda() * inv).contiguous(), sh.cuda(), out16,
+                                   B, Hp, H, W, Cin, Cout, mode, map_mode)
+        out = out16.float()
+        if mode != 2:
+            want_rows = want_rows.half().float()   # fp16 storage of the output
     else:
         K.conv3x3_bn_relu_bf16x3_gw(_to_rows(x, Hp).cuda(), K.pack_conv_weight_bf16x3_frag(w.cuda()), sc.cuda(),
                                     sh.cuda(), out, B, Hp, H, W, Cin, Cout, mode, map_mode)
     tol = 1e-4 * max(1.0, math.sqrt(9 * Cin / 576))
     if algo.startswith("bf16x3"):
         tol *= 10  # split-bf16 tier: 2^-16 relative operand error (f32: 2^-24) on O(1..10) outputs
+    if algo == "f16x2" and mode != 2:
+        tol += 4e-3  # one fp16 ulp of an O(1..8) output (the reference value may round the other way)
     assert _report(f"conv[{algo}] {B}x{H}x{W} {Cin}->{Cout} mode{mode}", out.reshape(want_rows.shape), want_rows) < tol
 
 
