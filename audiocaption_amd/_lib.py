@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AUDIOCAPTION_HIP_LIB") or os.path.join(_HERE, "libaudiocaption_hip.so")  # env: development builds
 
 AC_MAX_LAYERS = 8
+ABI_VERSION = 2   # include/audiocaption_hip.h AC_ABI_VERSION
 
 c_float_p = ctypes.c_void_p
 c_int_p = ctypes.c_void_p
@@ -42,11 +43,11 @@ SIGNATURES = {
     "ac_conv3x3_bn_relu_winograd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ac_conv3x3_bn_relu_bf16x3": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ac_conv3x3_bn_relu_bf16x3_gw": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "ac_conv3x3_bn_relu_f16x2_gw": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "ac_conv3x3_block1_f16x2": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ac_conv3x3_bn_relu_f16x2_gw": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "ac_conv3x3_block1_f16x2": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "ac_linear_bf16x3": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ac_conv3x3_first": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "ac_conv3x3_first_f16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ac_conv3x3_first_f16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "ac_linear": (_I, [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _P]),
     "ac_gru_pack_whh": (_I, [_P, _P, _I, _P]),
     "ac_gru_layer": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
@@ -89,7 +90,8 @@ SIGNATURES = {
     "ac_grad_sumsq": (_I, [_P, _L, _P, _P]),
     "ac_clip_coef": (_I, [_P, _F, _F, _P]),
     "ac_scale_by_coef": (_I, [_P, _L, _P, _P]),
-    "ac_adam_step": (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _I, _P]),
+    "ac_adam_step": (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _I, _P, _P]),
+    "ac_adam_commit": (_I, [_P, _P, _P]),
     # EfficientNet-B2 encoder (csrc/effnet.hip)
     "ac_pointwise_conv": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _F, _P, _I, _P]),
     "ac_top_db_clamp": (_I, [_P, _L, _F, _P, _I, _P]),
@@ -107,13 +109,32 @@ _lib = None
 PARAM_GENERATION = 0
 
 
-def bump_param_generation():
+# Per-tensor counters for the same purpose, keyed by id(parameter) with a weak reference so that a recycled id is
+# never mistaken for the old tensor: the packed weights of a FROZEN sub-network (the Cnn14 under TrainEngine) must not
+# be invalidated by every optimiser step on the OTHER parameters - captured graphs hold raw addresses of those packs.
+_TENSOR_GENERATION = {}
+
+
+def bump_param_generation(params=None):
+    """``params``: the tensors a HIP kernel just rewrote in place (None: unknown - every cache keyed on the global
+    counter is rebuilt; caches keyed per tensor are rebuilt only for tensors named here)."""
     global PARAM_GENERATION
+    import weakref
     PARAM_GENERATION += 1
+    if params is not None:
+        for p_ in params:
+            hit = _TENSOR_GENERATION.get(id(p_))
+            n = hit[1] + 1 if (hit is not None and hit[0]() is p_) else 1
+            _TENSOR_GENERATION[id(p_)] = (weakref.ref(p_), n)
 
 
 def param_generation():
     return PARAM_GENERATION
+
+
+def tensor_generation(t):
+    hit = _TENSOR_GENERATION.get(id(t))
+    return hit[1] if (hit is not None and hit[0]() is t) else 0
 
 
 def param_generation_flat(engine):
@@ -139,7 +160,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.ac_abi_version() != 1:
+    if lib.ac_abi_version() != ABI_VERSION:
         raise HipLibraryError("libaudiocaption_hip.so ABI version mismatch; rebuild it")
     _lib = lib
     return lib

@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import kernels as K
-from .mel import MelTables
+from .mel import MelSpectrogramBuffers, MelTables
 
 CHANNELS = [1, 64, 128, 256, 512, 1024, 2048]
 
@@ -55,6 +55,8 @@ class Cnn14Encoder(nn.Module):
         self.n_fft = 32 * sample_rate // 1000
         self.hop_length = 10 * sample_rate // 1000
         self.f_min, self.f_max = 50.0, float(sr_to_fmax[sample_rate])
+        self.melspec_extractor = MelSpectrogramBuffers(sample_rate, self.n_fft, self.f_min, self.f_max, 64, "slaney",
+                                                       "slaney")
         self.bn0 = nn.BatchNorm2d(64)
         for b in range(6):
             setattr(self, f"conv_block{b + 1}", ConvBlock(CHANNELS[b], CHANNELS[b + 1]))
@@ -71,7 +73,12 @@ class Cnn14Encoder(nn.Module):
         # with an LDS weight ring (kept for ablations).  The train-mode forward always uses "bf16x3" or an f32 tier.
         self.conv_algo = os.environ.get("AUDIOCAPTION_CONV_ALGO", "f16x2")
         self.f16x2_min_frames = int(os.environ.get("AUDIOCAPTION_F16X2_MIN_FRAMES", "8"))
+        # The "f16x2" tier is MIXED: conv_block6 (K = 9216 / 18432, two pixels per frame to average over - half of the
+        # tier's logit error by the per-layer breakdown of DESIGN.md section 4) runs on the split-bf16 kernel with f32
+        # activations; block 5's pooled output is then written as f32.  "f16x2" here restores the pure fp16 tier.
+        self.f16x2_block6 = os.environ.get("AUDIOCAPTION_F16X2_BLOCK6", "bf16x3")
         self._tables = None
+        self._tables_key = None
         self._packed = {}   # conv tier -> (key of the tensors it was packed from, packed weights)
         self._bufs = {}
 
@@ -104,7 +111,11 @@ class Cnn14Encoder(nn.Module):
             blk = getattr(self, f"conv_block{b + 1}")
             for conv, bn in ((blk.conv1, blk.bn1), (blk.conv2, blk.bn2)):
                 tensors += [conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var]
-        key = tuple((t.data_ptr(), t._version) for t in tensors) + (algo, K._lib.param_generation())
+        # Keyed on the tensors themselves (address, torch version counter, and the per-tensor counter HIP optimisers
+        # bump), NOT on the global parameter generation: an optimiser step on the GRU / decoder must not repack the
+        # frozen Cnn14 - captured training graphs hold the addresses of this pack (and a repack costs ~0.3 s).
+        mixed = algo == "f16x2" and self.f16x2_block6 == "bf16x3"
+        key = tuple((t.data_ptr(), t._version, K._lib.tensor_generation(t)) for t in tensors) + (algo, mixed)
         if not isinstance(self._packed, dict):
             self._packed = {}
         hit = self._packed.get(algo)
@@ -127,15 +138,18 @@ class Cnn14Encoder(nn.Module):
                         wp = K.pack_conv_weight_bf16x3_frag(w)
                     elif algo == "bf16x3_lds":
                         wp = K.pack_conv_weight_bf16x3(w)
+                    elif algo == "f16x2" and mixed and b == 5:
+                        wp, inv = K.pack_conv_weight_bf16x3_frag(w), None
                     elif algo == "f16x2":
                         wp, inv = K.pack_conv_weight_f16x2_frag(w)
                     else:
                         raise ValueError(f"unknown conv_algo {algo!r}")
                     sc, sh = K.fold_bn(bn.weight.float(), bn.bias.float(), bn.running_mean.float(),
                                        bn.running_var.float(), bn.eps)
-                    if algo == "f16x2" and not (b == 0 and j == 0):
+                    if algo == "f16x2" and not (b == 0 and j == 0) and inv is not None:
                         sc = (sc * inv).contiguous()
                     pk["convs"].append((wp, sc, sh))
+            pk["mixed"] = mixed
         self._packed[algo] = (key, pk)
         return pk
 
@@ -145,6 +159,15 @@ class Cnn14Encoder(nn.Module):
             b = torch.empty(numel, device=device, dtype=dtype)
             self._bufs[(name, dtype)] = b
         return b
+
+    def capture_token(self, algo):
+        """(identity, references) of everything a captured graph of this encoder's launches addresses: the packed weights
+        of ``algo`` and the shared activation buffers.  A graph owner keeps the references for as long as the graph lives
+        and re-captures when the identity changes (a larger batch shape re-allocates the buffers)."""
+        hit = self._packed.get(algo)
+        ident = (id(hit[1]) if hit is not None else None,) + tuple(sorted((k[0], str(k[1]), b.data_ptr())
+                                                                           for k, b in self._bufs.items()))
+        return ident, (hit, dict(self._bufs), self._tables)
 
     def geometry(self, n_samples):
         """Valid (H) and physical (Hp) row counts of the 6 resolution levels for an L-sample batch."""
@@ -156,7 +179,7 @@ class Cnn14Encoder(nn.Module):
         Hp = [hp6 << (5 - k) for k in range(6)]
         return T, H, Hp
 
-    def encode(self, wav, dropout=None, specaug=None, train=False, min_frames=None):
+    def encode(self, wav, dropout=None, specaug=None, train=False, min_frames=None, algo=None, overflow=None):
         """wav (B, L) on the ROCm device -> attn_emb (B, T // 32, 2048).
 
         ``dropout = (p, op_code, seed_dev_ptr)``: the train-mode forward of the frozen network, F.dropout(p) after
@@ -168,27 +191,40 @@ class Cnn14Encoder(nn.Module):
         ``min_frames``: output frames of the shortest clip of the batch (``forward`` passes it).  The "f16x2" tier's
         logit error grows as clips get shorter (fewer frames for the decoder's attention to average the fp16 rounding
         over: 3e-4 at 10 s, 6e-4 at 3 s, up to 1.7e-3 at 1 s - DESIGN.md section 4), so a batch that contains a clip of
-        fewer than ``f16x2_min_frames`` (8, = 2.6 s) frames runs on the split-bf16 tier (3e-5 at any length)."""
+        fewer than ``f16x2_min_frames`` (8, = 2.6 s) frames runs on the split-bf16 tier (3e-5 at any length).
+        ``algo``: conv tier of this call (default ``self.conv_algo``).  ``overflow``: int32 device word the fp16 tier ORs
+        with 1 when an activation left the fp16 range (``forward`` returns it as ``f16_overflow``)."""
         if wav.dim() != 2:
             raise ValueError("wav must be (batch, samples)")
         dev = wav.device
-        if self._tables is None or self._tables.window.device != dev:
+        mkey = self.melspec_extractor.key()
+        if self._tables is None or self._tables.window.device != dev or self._tables_key != mkey:
             self._tables = MelTables(self.sample_rate, self.n_fft, self.hop_length, self.f_min, self.f_max, 64,
-                                     "slaney", "slaney", dev)
+                                     "slaney", "slaney", dev, window=self.melspec_extractor.spectrogram.window,
+                                     fb=self.melspec_extractor.mel_scale.fb)
+            self._tables_key = mkey
         # the "f16x2" tier keeps its activations in HBM as fp16; the train-mode forward (dropout on f32 block outputs,
         # parity pinned by tests/golden/g8_train.npz) stays on the split-bf16 tier
-        algo = "bf16x3" if (self.conv_algo == "f16x2" and (train or dropout is not None)) else self.conv_algo
-        if algo == "f16x2" and min_frames is not None and min_frames < self.f16x2_min_frames:
-            algo = "bf16x3"
+        algo = self.effective_algo(algo, train or dropout is not None, min_frames)
         pk = self._pack(dev, algo)
         B, L = wav.shape
         T, H, Hp = self.geometry(L)
         x0 = K.logmel(wav, self._tables, pk["bn0"][0], pk["bn0"][1], rows_per_clip=Hp[0], channels_last=True)
         if specaug is not None:
             K.specaug_(x0, specaug, pk["bn0"][1], B, Hp[0], T)
-        return self.conv_stack(x0, B, H, Hp, pk, algo, dropout)
+        return self.conv_stack(x0, B, H, Hp, pk, algo, dropout, overflow=overflow)
 
-    def conv_stack(self, x0, B, H, Hp, pk, algo, dropout=None, blocks=None):
+    def effective_algo(self, algo=None, train=False, min_frames=None):
+        """The conv tier a call runs on: the fp16-activation tier is left for the train-mode forward and for batches
+        that contain a very short clip (see ``encode``)."""
+        algo = algo or self.conv_algo
+        if algo == "f16x2" and train:
+            return "bf16x3"
+        if algo == "f16x2" and min_frames is not None and min_frames < self.f16x2_min_frames:
+            return "bf16x3"
+        return algo
+
+    def conv_stack(self, x0, B, H, Hp, pk, algo, dropout=None, blocks=None, overflow=None):
         """The six conv blocks on a bn0-normalised log-mel x0 [B*Hp[0]][64] -> attn_emb (B, H[5], 2048).
         ``blocks``: a list that receives a float32 (B, C, H, W) copy of every pooled block output (tests)."""
         dev = x0.device
@@ -197,15 +233,24 @@ class Cnn14Encoder(nn.Module):
         pooled = self._buf("pooled", B * Hp[1] * 32 * 64, dev, act)  # block outputs (largest: block 1)
         W = 64
         conv = conv_kernel(algo)
+        if algo == "f16x2":
+            import functools
+            conv = functools.partial(conv, overflow=overflow)
         fuse1 = algo == "f16x2" and os.environ.get("AUDIOCAPTION_FUSE_BLOCK1", "1") != "0"
+        mixed = algo == "f16x2" and pk.get("mixed", False)
         for b in range(6):
             cin, cout = CHANNELS[b], CHANNELS[b + 1]
             w1, s1, t1 = pk["convs"][2 * b]
             w2, s2, t2 = pk["convs"][2 * b + 1]
+            if mixed and b == 4:     # block 5 hands block 6 (split-bf16, f32 activations) an f32 pooled output
+                pooled = self._buf("pooled32", B * Hp[5] * 2 * CHANNELS[5], dev, torch.float32)
+            if mixed and b == 5:
+                conv = K.conv3x3_bn_relu_bf16x3_gw
+                full = self._buf("full32", B * Hp[5] * 2 * CHANNELS[6], dev, torch.float32)
             if b == 0 and fuse1:   # conv1 is computed inside conv2's kernel: its 64-channel output never reaches HBM
-                K.conv3x3_block1_f16x2(x0, w1, s1, t1, w2, s2, t2, pooled, B, Hp[0], H[0], W)
+                K.conv3x3_block1_f16x2(x0, w1, s1, t1, w2, s2, t2, pooled, B, Hp[0], H[0], W, overflow=overflow)
             elif b == 0:
-                K.conv3x3_first(x0, w1, s1, t1, full, B, Hp[0], H[0], W)
+                K.conv3x3_first(x0, w1, s1, t1, full, B, Hp[0], H[0], W, overflow=overflow)
             else:
                 conv(pooled, w1, s1, t1, full, B, Hp[b], H[b], W, cin, cout, 0)
             if b < 5:
@@ -236,8 +281,17 @@ class Cnn14Encoder(nn.Module):
                 "are not built")
         wav = input_dict["wav"]
         feat_length = cnn14_feat_len(input_dict["wav_len"], self.hop_length, self.downsample_ratio)
-        attn_emb = self.encode(wav, min_frames=int(feat_length.min()))
+        min_frames = int(feat_length.min())
+        # ``conv_algo`` in the input dict overrides the tier for this call (the model re-runs a batch whose fp16
+        # activations overflowed on the f32-activation tier)
+        algo = self.effective_algo(input_dict.get("conv_algo"), False, min_frames)
+        flag = torch.zeros(1, device=wav.device, dtype=torch.int32) if algo == "f16x2" else None
+        attn_emb = self.encode(wav, min_frames=min_frames, algo=algo, overflow=flag)
         out = {"attn_emb": attn_emb, "attn_emb_len": feat_length}
+        if flag is not None:
+            # non-zero: an activation exceeded the fp16 range (65504) and this result must not be used -
+            # TransformerModel re-runs such a batch on the split-bf16 tier; stand-alone callers check it themselves
+            out["f16_overflow"] = flag
         if not skip_fc:
             # Cnn14's own clip embedding (cnn_encoder.py:451-456); CrnnEncoder discards it.
             lens = K.upload(feat_length, wav.device, torch.int32)

@@ -5,7 +5,25 @@
 (eg_configs/clotho_v2/waveform/cnn14rnn_trm.yaml:9) although that class does not exist in the
 reference module (SURVEY.md "Key facts").
 """
+import inspect
+
 import torch.nn as nn
+
+
+def _accepts_skip_fc(cnn):
+    """Whether the CNN's forward takes ``skip_fc`` (this package's Cnn14Encoder does; any other plugin encoder is
+    called with the reference's plain ``forward(input_dict)``).  Decided once from the signature: a ``TypeError``
+    raised INSIDE the encoder must surface, not trigger a silent second run."""
+    try:
+        return "skip_fc" in inspect.signature(cnn.forward).parameters
+    except (TypeError, ValueError):
+        return False
+
+
+def _run_cnn(cnn, skip_fc, input_dict):
+    out = cnn(input_dict, skip_fc=True) if skip_fc else cnn(input_dict)
+    res = {"attn": out["attn_emb"], "attn_len": out["attn_emb_len"]}
+    return res, out.get("f16_overflow")
 
 
 class CrnnEncoder(nn.Module):
@@ -14,6 +32,7 @@ class CrnnEncoder(nn.Module):
         super().__init__()
         self.cnn = cnn
         self.rnn = rnn
+        self._skip_fc = _accepts_skip_fc(cnn)
         self.freeze_cnn_bn = False
         if freeze_cnn:
             for param in self.cnn.parameters():
@@ -30,11 +49,11 @@ class CrnnEncoder(nn.Module):
 
     def forward(self, input_dict):
         # Cnn14's own fc_emb is dead in this pipeline (the RNN recomputes it): skip its kernels.
-        try:
-            out = self.cnn(input_dict, skip_fc=True)
-        except TypeError:
-            out = self.cnn(input_dict)
-        return self.rnn({"attn": out["attn_emb"], "attn_len": out["attn_emb_len"]})
+        feats, overflow = _run_cnn(self.cnn, self._skip_fc, input_dict)
+        out = self.rnn(feats)
+        if overflow is not None:
+            out["f16_overflow"] = overflow   # fp16 range flag of the conv tier (see Cnn14Encoder.forward)
+        return out
 
 
 Cnn14RnnEncoder = CrnnEncoder
@@ -47,6 +66,7 @@ class Cnn14TransformerEncoder(nn.Module):
         super().__init__()
         self.cnn = cnn
         self.trm = transformer
+        self._skip_fc = _accepts_skip_fc(cnn)
         self.freeze_cnn_bn = False
         if freeze_cnn:
             for param in self.cnn.parameters():
@@ -62,8 +82,8 @@ class Cnn14TransformerEncoder(nn.Module):
         return self
 
     def forward(self, input_dict):
-        try:
-            out = self.cnn(input_dict, skip_fc=True)
-        except TypeError:
-            out = self.cnn(input_dict)
-        return self.trm({"attn": out["attn_emb"], "attn_len": out["attn_emb_len"]})
+        feats, overflow = _run_cnn(self.cnn, self._skip_fc, input_dict)
+        out = self.trm(feats)
+        if overflow is not None:
+            out["f16_overflow"] = overflow
+        return out

@@ -43,6 +43,20 @@ struct ConvParams {
   const float* w1;
   const float* sc1;
   const float* sh1;
+  // fp16 tier: *ovf is OR-ed with 1 when a value stored as fp16 exceeded the fp16 range (65504); may be null.
+  // out32: the POOL epilogue of the fp16 tier writes f32 (the block feeding a split-bf16 block of the mixed tier).
+  unsigned* ovf = nullptr;
+  int out32 = 0;
+};
+
+// fp16 range guard of the "f16x2" tier: every value about to be stored as fp16 goes through track(); one atomic per
+// wave at the end, and only when something overflowed (never on healthy activations).
+struct F16Guard {
+  float mx = 0.f;
+  __device__ __forceinline__ void track(float y) { mx = fmaxf(mx, y); }   // post-ReLU values: y >= 0
+  __device__ __forceinline__ void commit(unsigned* flag) const {
+    if (flag != nullptr && mx > 65504.f) atomicOr(flag, 1u);
+  }
 };
 
 enum { MODE_FULL = 0, MODE_POOL = 1, MODE_MEANW = 2, MODE_LINEAR = 3 };  // LINEAR: FULL without the ReLU (1-tap GEMM use)
@@ -107,6 +121,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 
   const int TC = 1 << p.tc_log2;
   const int QR2 = 32 >> p.tc_log2;
   const FastDiv by_hp(p.Hp), by_hp_out(MODE == MODE_POOL ? p.Hp_out : 1);
+  F16Guard guard;
 #pragma unroll
   for (int n = 0; n < NTW; ++n) {
     const int ch = n_tile * BN + (wn * NTW + n) * 32 + (lane & 31);
@@ -134,8 +149,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 
             if (gr < p.rows_total && (p.m_valid == 0 || gr * p.W + gc < p.m_valid)) {
               const bool valid = by_hp.mod(gr) < p.H;
               const size_t o = ((size_t)gr * p.W + gc) * p.Cout + ch;
-              if (OUT16) ((_Float16*)p.out)[o] = (_Float16)(valid ? y[e] : 0.f);
-              else p.out[o] = valid ? y[e] : 0.f;
+              if (OUT16) {
+                guard.track(y[e]);
+                ((_Float16*)p.out)[o] = (_Float16)(valid ? y[e] : 0.f);
+              } else p.out[o] = valid ? y[e] : 0.f;
             }
           }
         } else if (MODE == MODE_POOL) {
@@ -144,8 +161,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 
             const bool valid = by_hp_out.mod(orow) < p.H_out;
             const float o = 0.25f * ((y[0] + y[1]) + (y[2] + y[3]));
             const size_t oi = ((size_t)orow * p.W_out + ocol) * p.Cout + ch;
-            if (OUT16) ((_Float16*)p.out)[oi] = (_Float16)(valid ? o : 0.f);
-            else p.out[oi] = valid ? o : 0.f;
+            if (OUT16 && !p.out32) {
+              guard.track(o);
+              ((_Float16*)p.out)[oi] = (_Float16)(valid ? o : 0.f);
+            } else p.out[oi] = valid ? o : 0.f;
           }
         } else {  // MODE_MEANW: W == 2, mean over the two mel columns, dense (B, H, Cout) output
 #pragma unroll
@@ -161,6 +180,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 
       }
     }
   }
+  if (OUT16) guard.commit(p.ovf);
 }
 
 template <int BN, int MODE>
@@ -508,6 +528,7 @@ __device__ __forceinline__ void conv_epilogue_cols(const ConvParams& p, const f3
   const float sc = p.scale[ch], sh = p.shift[ch];
   _Float16* out16 = (_Float16*)p.out;
   const FastDiv by_hp(p.Hp), by_hp_out(MODE == MODE_POOL ? p.Hp_out : 1);
+  F16Guard guard;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = 8 * (r >> 2) + 4 * half + (r & 3);
@@ -524,6 +545,8 @@ __device__ __forceinline__ void conv_epilogue_cols(const ConvParams& p, const f3
 #pragma unroll
       for (int m = 0; m < MW; ++m) {
         const float a = y[m], b = fmaxf(fmaf(acc[m][0][r + 1], sc, sh), 0.f);
+        guard.track(a);
+        guard.track(b);
         const float pa = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0xB1, 0xF, 0xF, true));
         const float pb = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0xB1, 0xF, 0xF, true));
         const int gr = row0 + (m / TC) * 32 + myrow, gc = col0 + m % TC;
@@ -562,11 +585,19 @@ __device__ __forceinline__ void conv_epilogue_cols(const ConvParams& p, const f3
           for (int dm = 0; dm < 2; ++dm)
 #pragma unroll
             for (int dr = 0; dr < 2; ++dr) o += fmaxf(fmaf(acc[rg * TC + 2 * oc + dm][0][r + dr], sc, sh), 0.f);
-          out16[((size_t)orow * p.W_out + (col0 >> 1) + oc) * p.Cout + ch] = (_Float16)(valid ? 0.25f * o : 0.f);
+          const size_t oi = ((size_t)orow * p.W_out + (col0 >> 1) + oc) * p.Cout + ch;
+          o = valid ? 0.25f * o : 0.f;
+          if (p.out32) {
+            p.out[oi] = o;
+          } else {
+            guard.track(o);
+            out16[oi] = (_Float16)o;
+          }
         }
       }
     }
   }
+  if (MODE != MODE_MEANW) guard.commit(p.ovf);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -758,6 +789,7 @@ __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(Conv
     // conv1 + BN + ReLU of channel chunk c1 for this thread's patch items.  With FUSE1 an item is (pixel = lane + 64 j,
     // channel octet = wave), so the 72 weights and 16 BN terms of an octet are wave-uniform: they sit in SGPRs and the
     // multiply-adds take them as scalar operands (the same 9-term fmaf chain per channel as conv_first_kernel).
+    F16Guard guard1;
     auto conv1_patch = [&](int c1) {
       const int ch0 = c1 * 32 + __builtin_amdgcn_readfirstlane(tid >> 6) * 8;
       const float* __restrict__ w1 = p.w1 + ch0 * 9;
@@ -786,6 +818,7 @@ __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(Conv
 #pragma unroll
             for (int t = 0; t < 9; ++t) a = fmaf(x[t], w1r[e][t], a);
             y[e] = fmaxf(fmaf(a, sc[e], sh[e]), 0.f);
+            guard1.track(y[e]);
           }
           v[0] = cvt_pk_f16(y[0], y[1]);
           v[1] = cvt_pk_f16(y[2], y[3]);
@@ -865,6 +898,7 @@ __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(Conv
         }
       }
     }
+    if (FUSE1) guard1.commit(p.ovf);
   }
   if constexpr (COLT != 0) conv_epilogue_cols<BN, MODE, COLT, MW>(p, acc, n_tile, row0, col0, wn, lane);
   else conv_epilogue<BN, MODE, MW, NTW, PREC == 1>(p, acc, n_tile, row0, col0, wm, wn, lane);
@@ -916,6 +950,7 @@ struct ConvFirstParams {
   const float* shift;
   float* out;         // [rows_total][W][64]
   int rows_total, Hp, H, W;
+  unsigned* ovf = nullptr;   // fp16 output: range guard flag (see F16Guard), may be null
 };
 
 template <bool OUT16>
@@ -941,6 +976,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(ConvFirstParams p) {
     for (int t = 0; t < 9; ++t) w[j][t] = p.w[(cg * 4 + j) * 9 + t];
   }
   __syncthreads();
+  F16Guard guard;
   for (int px = ps; px < RT * p.W; px += 16) {
     const int r = px / p.W, c = px - r * p.W;
     const int gr = row0 + r;
@@ -957,6 +993,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(ConvFirstParams p) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) s = fmaf(x[t], w[j][t], s);
         a[j] = fmaxf(fmaf(s, sc[j], sh[j]), 0.f);
+        if (OUT16) guard.track(a[j]);
       }
       o = make_float4(a[0], a[1], a[2], a[3]);
     }
@@ -970,6 +1007,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(ConvFirstParams p) {
       *(float4*)(p.out + oi) = o;
     }
   }
+  if (OUT16) guard.commit(p.ovf);
 }
 
 template <int BN, int MODE>
@@ -1060,13 +1098,18 @@ extern "C" int ac_conv3x3_bn_relu_bf16x3(const float* in, const void* wpk, const
 
 static int conv_gw_dispatch(int prec, const float* in, const void* wfrag, const float* scale, const float* shift,
                             float* out, int B, int Hp, int H, int W, int Cin, int Cout, int mode, int map_mode,
-                            void* stream) {
+                            int out_f32, unsigned* overflow_flag, void* stream) {
   if (!in || !wfrag || !scale || !shift || !out) return AC_ERR_ARG;
   if (B <= 0 || Hp <= H || W < 2 || (W & (W - 1)) || Cin % 32 || Cout % 64) return AC_ERR_ARG;
   if (mode < 0 || mode > 2) return AC_ERR_ARG;
   if (mode == MODE_POOL && (Hp & 1)) return AC_ERR_ARG;
   if (mode == MODE_MEANW && W != 2) return AC_ERR_ARG;
+  if (out_f32 && (prec != 1 || mode != MODE_POOL)) return AC_ERR_ARG;
+  // the staging descriptors of this kernel hold 32-bit element offsets into `in`
+  if ((unsigned long long)B * Hp * W * Cin >= (1ull << 32)) return AC_ERR_ARG;
   ConvParams p;
+  p.ovf = prec == 1 ? overflow_flag : nullptr;
+  p.out32 = out_f32;
   p.m_valid = 0;
   p.in = in; p.wpk = (const float*)wfrag; p.scale = scale; p.shift = shift; p.out = out;
   p.rows_total = B * Hp; p.Hp = Hp; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
@@ -1153,23 +1196,25 @@ static int conv_gw_dispatch(int prec, const float* in, const void* wfrag, const 
 extern "C" int ac_conv3x3_bn_relu_bf16x3_gw(const float* in, const void* wfrag, const float* scale, const float* shift,
                                             float* out, int B, int Hp, int H, int W, int Cin, int Cout, int mode,
                                             int map_mode, void* stream) {
-  return conv_gw_dispatch(0, in, wfrag, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode, stream);
+  return conv_gw_dispatch(0, in, wfrag, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode, 0, nullptr, stream);
 }
 
 extern "C" int ac_conv3x3_bn_relu_f16x2_gw(const void* in, const void* wfrag, const float* scale, const float* shift,
                                            void* out, int B, int Hp, int H, int W, int Cin, int Cout, int mode,
-                                           int map_mode, void* stream) {
-  return conv_gw_dispatch(1, (const float*)in, wfrag, scale, shift, (float*)out, B, Hp, H, W, Cin, Cout, mode, map_mode, stream);
+                                           int map_mode, int out_f32, unsigned int* overflow_flag, void* stream) {
+  return conv_gw_dispatch(1, (const float*)in, wfrag, scale, shift, (float*)out, B, Hp, H, W, Cin, Cout, mode, map_mode,
+                          out_f32, overflow_flag, stream);
 }
 
 // Block 1 of the f16x2 tier in one kernel: conv1 (Cin = 1) + BN + ReLU computed into the patch, conv2 + BN + ReLU +
 // 2x2 pool on the matrix cores.  in1 [B*Hp][64] f32 log-mel, out [B*Hp/2][32][64] fp16.
 extern "C" int ac_conv3x3_block1_f16x2(const float* in1, const float* w1, const float* scale1, const float* shift1,
                                        const void* wfrag2, const float* scale2, const float* shift2, void* out,
-                                       int B, int Hp, int H, int W, void* stream) {
+                                       int B, int Hp, int H, int W, unsigned int* overflow_flag, void* stream) {
   if (!in1 || !w1 || !scale1 || !shift1 || !wfrag2 || !scale2 || !shift2 || !out) return AC_ERR_ARG;
   if (B <= 0 || Hp <= H || (Hp & 1) || W != 64) return AC_ERR_ARG;
   ConvParams p;
+  p.ovf = overflow_flag;
   p.m_valid = 0;
   p.in = nullptr; p.wpk = (const float*)wfrag2; p.scale = scale2; p.shift = shift2; p.out = (float*)out;
   p.in1 = in1; p.w1 = w1; p.sc1 = scale1; p.sh1 = shift1;
@@ -1190,6 +1235,7 @@ extern "C" int ac_linear_bf16x3(const float* X, const void* wfrag, const float* 
                                 int M, int N, int K, int relu, void* stream) {
   if (!X || !wfrag || !ones || !bias || !Y) return AC_ERR_ARG;
   if (M <= 0 || K % 32 || N % 64) return AC_ERR_ARG;
+  if ((unsigned long long)(M + 1) * K >= (1ull << 32)) return AC_ERR_ARG;   // 32-bit staging offsets
   ConvParams p;
   p.m_valid = 0;
   p.in = X; p.wpk = (const float*)wfrag; p.scale = ones; p.shift = bias; p.out = Y;
@@ -1219,9 +1265,10 @@ extern "C" int ac_conv3x3_first(const float* in, const float* w, const float* sc
 }
 
 extern "C" int ac_conv3x3_first_f16(const float* in, const float* w, const float* scale, const float* shift,
-                                    void* out, int B, int Hp, int H, int W, void* stream) {
+                                    void* out, int B, int Hp, int H, int W, unsigned int* overflow_flag, void* stream) {
   if (!in || !w || !scale || !shift || !out || B <= 0 || Hp <= H || W != 64) return AC_ERR_ARG;
   ConvFirstParams p;
+  p.ovf = overflow_flag;
   p.in = in; p.w = w; p.scale = scale; p.shift = shift; p.out = (float*)out;
   p.rows_total = B * Hp; p.Hp = Hp; p.H = H; p.W = W;
   const unsigned grid = (unsigned)((p.rows_total + 3) / 4);

@@ -1029,9 +1029,14 @@ __global__ void clip_coef_kernel(float* norm_state, float max_norm, float grad_d
   norm_state[3] = bad ? 1.f : 0.f;
 }
 __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long n, const float* norm_state, float lr,
-                            float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+                            float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, const int* step_dev) {
   const float coef = norm_state ? norm_state[2] : 1.0f;
   if (norm_state && norm_state[3] != 0.f) return;   // non-finite gradient: leave parameters and moments untouched
+  if (step_dev != nullptr) {   // device-side step counter: only APPLIED updates advance the bias correction
+    const float t = (float)(*step_dev + 1);
+    bc1 = 1.0f - powf(b1, t);
+    bc2_sqrt = sqrtf(1.0f - powf(b2, t));
+  }
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float gi = g[i] * coef;
     const float pi = p[i];
@@ -1043,6 +1048,9 @@ __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long n
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
     p[i] = pi - (lr / bc1) * (mi / denom);
   }
+}
+__global__ void adam_commit_kernel(int* step_dev, const float* norm_state) {
+  if (!(norm_state && norm_state[3] != 0.f)) *step_dev += 1;
 }
 // stochastic weight averaging (train_util.py:233-253 with torch's default avg_fn): avg += (p - avg) / (n_averaged + 1)
 __global__ void swa_kernel(float* avg, const float* p, long n, float inv) {
@@ -1341,12 +1349,18 @@ int ac_swa_update(float* avg, const float* p, long n, int n_averaged, void* stre
 }
 
 int ac_adam_step(float* p, const float* g, float* m, float* v, long n, const float* norm_state, float lr, float beta1,
-                 float beta2, float eps, float weight_decay, int step, void* stream) {
-  if (!p || !g || !m || !v || n <= 0 || step < 1) return AC_ERR_ARG;
-  const float bc1 = 1.0f - powf(beta1, (float)step);
-  const float bc2 = 1.0f - powf(beta2, (float)step);
+                 float beta2, float eps, float weight_decay, int step, const int* step_dev, void* stream) {
+  if (!p || !g || !m || !v || n <= 0 || (step < 1 && !step_dev)) return AC_ERR_ARG;
+  const float bc1 = 1.0f - powf(beta1, (float)(step < 1 ? 1 : step));
+  const float bc2 = 1.0f - powf(beta2, (float)(step < 1 ? 1 : step));
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, norm_state,
-                     lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2));
+                     lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), step_dev);
+  return ac_check_launch();
+}
+
+int ac_adam_commit(int* step_dev, const float* norm_state, void* stream) {
+  if (!step_dev) return AC_ERR_ARG;
+  hipLaunchKernelGGL(adam_commit_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev, norm_state);
   return ac_check_launch();
 }
 

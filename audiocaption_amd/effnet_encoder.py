@@ -21,7 +21,7 @@ from . import _lib
 from . import kernels as K
 from ._lib import check, ptr, stream
 from .cnn_encoder import cnn14_feat_len
-from .mel import MelTables
+from .mel import MelSpectrogramBuffers, MelTables
 
 # (repeats, kernel, stride, expand, in, out) of EfficientNet-B0; B2: width x1.1, depth x1.2, resolution 260
 _B0 = [(1, 3, 1, 1, 32, 16), (2, 3, 2, 6, 16, 24), (2, 5, 2, 6, 24, 40), (3, 3, 2, 6, 40, 80), (3, 5, 1, 6, 80, 112),
@@ -120,6 +120,8 @@ class EfficientNetB2(nn.Module):
         self.hop_length = 10 * self.sample_rate // 1000
         self.f_min = float(f_min)
         self.top_db = 120.0
+        self.melspec_extractor = MelSpectrogramBuffers(self.sample_rate, self.n_fft, self.f_min, self.sample_rate // 2, 64,
+                                                       None, "htk")
         self.backbone = _EffiNet()
         self.fc_emb_size = self.backbone.eff_net._conv_head.weight.shape[0]
         self.downsample_ratio = 32
@@ -127,13 +129,15 @@ class EfficientNetB2(nn.Module):
             for p in self.parameters():
                 p.requires_grad = False
         self._packed, self._packed_key, self._tables, self._bufs = None, None, None, {}
+        self._buf_gen = 0
+        self._tables_key = None
         self._graphs = {}   # (device, wav shape, packed-weights key) -> captured encoder
 
     # ---- weight packing (cached) ---------------------------------------------------------------------------
     def _pack(self):
         net = self.backbone.eff_net
-        key = tuple((t.data_ptr(), t._version) for t in list(net.parameters()) + list(net.buffers())) + \
-            (_lib.param_generation(),)
+        key = tuple((t.data_ptr(), t._version, _lib.tensor_generation(t))
+                    for t in list(net.parameters()) + list(net.buffers()))
         if self._packed is not None and key == self._packed_key:
             return self._packed
 
@@ -169,6 +173,7 @@ class EfficientNetB2(nn.Module):
         if b is None or b.numel() < numel or b.device != device:
             b = torch.empty(numel, device=device, dtype=torch.float32)
             self._bufs[name] = b
+            self._buf_gen += 1      # captured graphs hold the old address: they re-capture (``_encode_graph``)
         return b
 
     @staticmethod
@@ -187,9 +192,12 @@ class EfficientNetB2(nn.Module):
     def logmel(self, wav):
         """wav (B, L) -> log-mel dB [B][T][64] (time-major), clamped at (batch max - 120 dB) like AmplitudeToDB."""
         dev = wav.device
-        if self._tables is None or self._tables.window.device != dev:
+        mkey = self.melspec_extractor.key()
+        if self._tables is None or self._tables.window.device != dev or self._tables_key != mkey:
             self._tables = MelTables(self.sample_rate, self.n_fft, self.hop_length, self.f_min, self.sample_rate // 2, 64,
-                                     None, "htk", dev)
+                                     None, "htk", dev, window=self.melspec_extractor.spectrogram.window,
+                                     fb=self.melspec_extractor.mel_scale.fb)
+            self._tables_key = mkey
         x = K.logmel(wav, self._tables, channels_last=True)      # (B*T, 64)
         scratch = self._buf("maxscratch", 1024, dev)
         check(_lib.load().ac_top_db_clamp(ptr(x), x.numel(), self.top_db, ptr(scratch), 1024, stream()),
@@ -275,12 +283,17 @@ class EfficientNetB2(nn.Module):
         st["uses"] += 1
         if st["uses"] < 2:
             return self._encode(wav)
+        if st["graph"] is not None and st["buf_gen"] != self._buf_gen:
+            # a larger shape re-allocated the shared activation buffers since this graph was captured: its launches
+            # point at freed memory.  Drop it and capture again over the current buffers.
+            st["graph"] = None
         if st["graph"] is None:
             st["wav"] = wav.clone()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 st["attn"] = self._encode(st["wav"])
-            st["graph"] = graph
+            st["graph"], st["buf_gen"] = graph, self._buf_gen
+            st["hold"] = (dict(self._bufs), self._packed)   # what the graph's launches address stays alive with it
         st["wav"].copy_(wav)
         st["graph"].replay()
         return st["attn"].clone()

@@ -54,25 +54,27 @@ def logmel(wav, tables, scale=None, shift=None, rows_per_clip=None, channels_las
     return out
 
 
-def conv3x3_first(x, w, scale, shift, out, B, Hp, H, W=64):
-    """``out`` float32, or float16 for the "f16x2" conv tier."""
+def conv3x3_first(x, w, scale, shift, out, B, Hp, H, W=64, overflow=None):
+    """``out`` float32, or float16 for the "f16x2" conv tier (``overflow``: its fp16 range flag, see
+    ``conv3x3_bn_relu_f16x2_gw``)."""
     lib = _lib.load()
     if out.dtype == torch.float16:
-        check(lib.ac_conv3x3_first_f16(ptr(x), ptr(w), ptr(scale), ptr(shift), ptr(out), B, Hp, H, W, stream()),
-              "ac_conv3x3_first_f16")
+        check(lib.ac_conv3x3_first_f16(ptr(x), ptr(w), ptr(scale), ptr(shift), ptr(out), B, Hp, H, W, ptr(overflow),
+                                       stream()), "ac_conv3x3_first_f16")
         return out
     check(lib.ac_conv3x3_first(ptr(x), ptr(w), ptr(scale), ptr(shift), ptr(out), B, Hp, H, W, stream()),
           "ac_conv3x3_first")
     return out
 
 
-def conv3x3_block1_f16x2(x0, w1, scale1, shift1, wfrag2, scale2, shift2, out, B, Hp, H, W=64):
+def conv3x3_block1_f16x2(x0, w1, scale1, shift1, wfrag2, scale2, shift2, out, B, Hp, H, W=64, overflow=None):
     """conv_block1 of the "f16x2" tier in one launch (conv1 computed into conv2's patch); out fp16."""
     lib = _lib.load()
     if out.dtype != torch.float16:
         raise ValueError("conv3x3_block1_f16x2 writes fp16")
     check(lib.ac_conv3x3_block1_f16x2(ptr(x0), ptr(w1), ptr(scale1), ptr(shift1), ptr(wfrag2), ptr(scale2),
-                                      ptr(shift2), ptr(out), B, Hp, H, W, stream()), "ac_conv3x3_block1_f16x2")
+                                      ptr(shift2), ptr(out), B, Hp, H, W, ptr(overflow), stream()),
+          "ac_conv3x3_block1_f16x2")
     return out
 
 
@@ -146,16 +148,21 @@ def conv3x3_bn_relu_bf16x3_gw(x, wfrag, scale, shift, out, B, Hp, H, W, Cin, Cou
     return out
 
 
-def conv3x3_bn_relu_f16x2_gw(x, wfrag, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode=-1):
+def conv3x3_bn_relu_f16x2_gw(x, wfrag, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode=-1, overflow=None):
+    """``out``: fp16 for modes 0 / 1 (an f32 ``out`` with mode 1 selects the f32 pooled output that feeds a split-bf16
+    block), f32 for mode 2.  ``overflow``: a uint32 / int32 device word OR-ed with 1 when a value stored as fp16
+    exceeded the fp16 range."""
     lib = _lib.load()
     hook = CONV_LAUNCH_HOOK
     if hook is not None:
         info = {"B": B, "H": H, "Hp": Hp, "W": W, "Cin": Cin, "Cout": Cout, "mode": mode, "algo": "f16x2"}
         hook("pre", info)
-    if x.dtype != torch.float16 or out.dtype != (torch.float32 if mode == 2 else torch.float16):
+    out_f32 = 1 if (mode == 1 and out.dtype == torch.float32) else 0
+    if x.dtype != torch.float16 or out.dtype != (torch.float32 if (mode == 2 or out_f32) else torch.float16):
         raise ValueError("f16x2 conv: fp16 activations in, fp16 out (f32 for mode 2)")
     check(lib.ac_conv3x3_bn_relu_f16x2_gw(ptr(x), ptr(wfrag), ptr(scale), ptr(shift), ptr(out), B, Hp, H, W,
-                                          Cin, Cout, mode, map_mode, stream()), "ac_conv3x3_bn_relu_f16x2_gw")
+                                          Cin, Cout, mode, map_mode, out_f32, ptr(overflow), stream()),
+          "ac_conv3x3_bn_relu_f16x2_gw")
     if hook is not None:
         hook("post", info)
     return out

@@ -9,6 +9,7 @@ import math
 
 import numpy as np
 import torch
+import torch.nn as nn
 
 
 def _hz_to_mel(freq, mel_scale):
@@ -49,21 +50,57 @@ def melscale_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate, norm, mel_scale)
     return fb.contiguous()
 
 
-class MelTables:
-    """Device-resident tables for ac_logmel."""
+class _OptionalBuffers(nn.Module):
+    """Buffers that a checkpoint may or may not carry: absent keys are not reported as missing (the values are
+    constants of the front-end, recomputed at construction)."""
 
-    def __init__(self, sample_rate, n_fft, hop, f_min, f_max, n_mels, norm, mel_scale, device):
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        n = len(missing_keys)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                                      error_msgs)
+        del missing_keys[n:]
+
+
+class MelSpectrogramBuffers(nn.Module):
+    """The two buffers torchaudio's ``MelSpectrogram`` registers - ``spectrogram.window`` and ``mel_scale.fb`` - under the
+    attribute name the reference encoders use (``melspec_extractor``, cnn_encoder.py:338-348, hf_wrapper.py:270-277):
+    reference checkpoints carry ``...melspec_extractor.spectrogram.window`` / ``...melspec_extractor.mel_scale.fb`` (the
+    trainer saves every buffer, run.py:209-216) and must load with ``strict=True``; checkpoints written here carry them
+    too.  The HIP log-mel kernel reads its window and filterbank from these buffers.  Never called."""
+
+    def __init__(self, sample_rate, n_fft, f_min, f_max, n_mels, norm, mel_scale):
+        super().__init__()
+        self.spectrogram = _OptionalBuffers()
+        self.spectrogram.register_buffer("window", torch.hann_window(n_fft, periodic=True))
+        self.mel_scale = _OptionalBuffers()
+        self.mel_scale.register_buffer("fb", melscale_fbanks(n_fft // 2 + 1, f_min, f_max, n_mels, sample_rate, norm,
+                                                              mel_scale))
+
+    def key(self):
+        w, fb = self.spectrogram.window, self.mel_scale.fb
+        return (w.device, w.data_ptr(), w._version, fb.data_ptr(), fb._version)
+
+
+class MelTables:
+    """Device-resident tables for ac_logmel.  ``window`` / ``fb``: take these tensors (the module buffers a checkpoint
+    may have overwritten) instead of recomputing them."""
+
+    def __init__(self, sample_rate, n_fft, hop, f_min, f_max, n_mels, norm, mel_scale, device, window=None, fb=None):
         if n_mels != 64:
             raise ValueError("the HIP log-mel kernel is built for 64 mel bins")
         self.sample_rate, self.n_fft, self.hop = sample_rate, n_fft, hop
-        fb = melscale_fbanks(n_fft // 2 + 1, f_min, f_max, n_mels, sample_rate, norm, mel_scale)
+        if fb is None:
+            fb = melscale_fbanks(n_fft // 2 + 1, f_min, f_max, n_mels, sample_rate, norm, mel_scale)
+        fb = fb.detach().float().cpu()
         nz = fb > 0
         lo = torch.where(nz.any(0), nz.float().argmax(0), torch.zeros(n_mels, dtype=torch.long))
         hi = torch.where(nz.any(0), n_fft // 2 - nz.flip(0).float().argmax(0),
                          torch.full((n_mels,), -1, dtype=torch.long))
         n = np.arange(n_fft, dtype=np.float64)
         tw = np.stack([np.cos(2 * np.pi * n / n_fft), -np.sin(2 * np.pi * n / n_fft)], axis=1)
-        self.window = torch.hann_window(n_fft, periodic=True).to(device)
+        self.window = (torch.hann_window(n_fft, periodic=True) if window is None
+                       else window.detach().float().cpu().contiguous()).to(device)
         self.twiddle = torch.from_numpy(tw.astype(np.float32)).contiguous().to(device)
         self.melfb = fb.to(device)
         self.mel_lo = lo.to(torch.int32).to(device)

@@ -80,6 +80,18 @@ class FusedAdam(torch.optim.Optimizer):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._flat_state = {}
+        # Per group, the number of updates APPLIED so far lives on the device: a step whose gradient is not finite is
+        # skipped by the kernels (run.py:123) and must not advance Adam's bias correction either - the reference does
+        # not call optimizer.step() at all in that case.  ``state[p]["step"]`` is refreshed from it on ``state_dict()``.
+        self._step_dev = {}
+
+    def _group_step_dev(self, gi, params):
+        dev = params[0].device
+        t = self._step_dev.get(gi)
+        if t is None or t.device != dev:
+            done = max([int(self.state[p].get("step", 0)) for p in params] + [0])
+            t = self._step_dev[gi] = torch.full((1,), done, device=dev, dtype=torch.int32)
+        return t
 
     def _group_flat(self, gi, params):
         """Flat moment buffers for a group whose parameters (and gradients) are views of one storage each."""
@@ -95,24 +107,46 @@ class FusedAdam(torch.optim.Optimizer):
             dev = params[0].device
             m = torch.zeros(pspan[1], device=dev, dtype=torch.float32)
             v = torch.zeros(pspan[1], device=dev, dtype=torch.float32)
-            step = 0
             for p in params:  # adopt moments that already exist (e.g. loaded from a checkpoint)
                 o = (p.data_ptr() - pspan[0]) // 4
                 st = self.state[p]
                 if "exp_avg" in st:
                     m[o:o + p.numel()].copy_(st["exp_avg"].reshape(-1))
                     v[o:o + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
-                    step = int(st["step"])
+                st.setdefault("step", 0)
                 st["exp_avg"] = m[o:o + p.numel()].view(p.shape)
                 st["exp_avg_sq"] = v[o:o + p.numel()].view(p.shape)
-            fs = self._flat_state[gi] = {"pspan": pspan, "m": m, "v": v, "step": step}
+            fs = self._flat_state[gi] = {"pspan": pspan, "m": m, "v": v}
         fs["gspan"] = gspan
         return fs
+
+    def sync_step_counts(self):
+        """Copy the device-side counts of applied updates into ``state[p]["step"]`` (one small device->host read per
+        group).  Called by ``state_dict()``; not needed for stepping."""
+        for gi, group in enumerate(self.param_groups):
+            t = self._step_dev.get(gi)
+            if t is None:
+                continue
+            n = int(t.item())
+            for p in group["params"]:
+                if p in self.state:
+                    self.state[p]["step"] = n
+
+    def state_dict(self):
+        self.sync_step_counts()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        # the loaded moments and step counts replace whatever flat buffers / device counters existed: they are re-adopted
+        # from ``self.state`` by the next step
+        self._flat_state = {}
+        self._step_dev = {}
 
     @torch.no_grad()
     def step(self, closure=None, clip=None):
         """One Adam update.  ``clip``: a ``GradClip`` from ``clip_grad_norm_(..., scale_now=False)`` whose coefficient
-        is applied to the gradients inside the update."""
+        is applied to the gradients inside the update (and whose non-finite flag skips it)."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -120,31 +154,32 @@ class FusedAdam(torch.optim.Optimizer):
         lib = _lib.load()
         s = stream()
         coef = clip.state.data_ptr() if clip is not None else None
+        touched = []
         for gi, group in enumerate(self.param_groups):
             params = [p for p in group["params"] if p.grad is not None]
             if not params:
                 continue
             b1, b2 = group["betas"]
             fs = self._group_flat(gi, params)
+            step_dev = self._group_step_dev(gi, params)
+            touched += params
             if fs is not None:
-                fs["step"] += 1
                 check(lib.ac_adam_step(fs["pspan"][0], fs["gspan"][0], fs["m"].data_ptr(), fs["v"].data_ptr(),
                                        fs["pspan"][1], coef, float(group["lr"]), b1, b2, group["eps"],
-                                       group["weight_decay"], fs["step"], s), "ac_adam_step")
+                                       group["weight_decay"], 0, step_dev.data_ptr(), s), "ac_adam_step")
+            else:
                 for p in params:
-                    self.state[p]["step"] = fs["step"]
-                continue
-            for p in params:
-                st = self.state[p]
-                if "exp_avg" not in st:
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format)
-                st["step"] = int(st["step"]) + 1
-                if p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
-                    raise NotImplementedError("FusedAdam: contiguous fp32 parameters and gradients only")
-                check(lib.ac_adam_step(p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(),
-                                       st["exp_avg_sq"].data_ptr(), p.numel(), coef, float(group["lr"]), b1, b2,
-                                       group["eps"], group["weight_decay"], st["step"], s), "ac_adam_step")
-        _lib.bump_param_generation()  # packed inference weights must be rebuilt
+                    st = self.state[p]
+                    if "exp_avg" not in st:
+                        st["step"] = 0
+                        st["exp_avg"] = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format)
+                        st["exp_avg_sq"] = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format)
+                    if p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
+                        raise NotImplementedError("FusedAdam: contiguous fp32 parameters and gradients only")
+                    check(lib.ac_adam_step(p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(),
+                                           st["exp_avg_sq"].data_ptr(), p.numel(), coef, float(group["lr"]), b1, b2,
+                                           group["eps"], group["weight_decay"], 0, step_dev.data_ptr(), s), "ac_adam_step")
+            check(lib.ac_adam_commit(step_dev.data_ptr(), coef, s), "ac_adam_commit")
+        # packed inference weights of exactly these parameters must be rebuilt
+        _lib.bump_param_generation(touched)
         return loss

@@ -85,6 +85,12 @@ class FlatParams:
                 p.data = v
                 self.grad_views.append(self.grad[o:o + p.numel()].view(p.shape))
         self.index = {k: i for i, k in enumerate(names)}
+        # tied parameters (``tie_weights=True``: decoder.classifier.weight IS decoder.word_embedding.weight) appear once
+        # in named_parameters(); the other name resolves to the same slot, so both uses accumulate into one gradient
+        by_id = {id(p): i for i, p in enumerate(self.params)}
+        for k, p in model.named_parameters(remove_duplicate=False):
+            if k not in self.index and id(p) in by_id:
+                self.index[k] = by_id[id(p)]
 
     def intact(self):
         base = self.flat.data_ptr()
@@ -201,7 +207,7 @@ class TrainEngine:
         if self.flat is None or not self.flat.intact() or self.flat.flat.device != device:
             self.flat = FlatParams(self.model)
             self._states = {}
-            _lib.bump_param_generation()
+            _lib.bump_param_generation(self.flat.params)
 
     @staticmethod
     def _layout(N, T, Tm, teacher_forcing, device):
@@ -661,18 +667,27 @@ class TrainEngine:
         elif st["graph"] is None and st["steps"] < 2:
             self._launch_step_body(st, smoothing)          # first iteration of this shape: eager (also the warm-up)
         else:
-            gkey = (smoothing, _lib.param_generation_flat(self), st["ws"].gen)
+            # A captured graph holds RAW ADDRESSES: the flat parameter storage, the shared workspace, and - through the
+            # frozen Cnn14 - its packed weights and its activation buffers, which are shared by all batch shapes and
+            # re-allocated when a larger one arrives.  All of them are part of the key, and the state keeps references
+            # to what its graph addresses, so a stale graph is neither replayed nor left pointing at recycled memory.
+            cnn = getattr(self.model.encoder, "cnn", None)
+            cnn_algo = cnn.effective_algo(None, True) if cnn is not None and hasattr(cnn, "_pack") else None
+            if cnn_algo is not None:
+                # weight repacks (host uploads, float64 transforms of the Winograd tier) must not land inside a
+                # capture: pack the frozen Cnn14 for the tier the train-mode forward uses now (cached: a no-op
+                # unless the Cnn14's own tensors changed)
+                cnn._pack(st["cap"].device, cnn_algo)
+            ident, refs = cnn.capture_token(cnn_algo) if cnn_algo is not None else (None, None)
+            gkey = (smoothing, _lib.param_generation_flat(self), st["ws"].gen, ident)
             if st["graph"] is None or st["graph_key"] != gkey:
-                # weight repacks (host uploads, float64 transforms of the Winograd tier) must not land inside the
-                # capture: pack the frozen Cnn14 for the tier the train-mode forward uses now
-                cnn = getattr(self.model.encoder, "cnn", None)
-                if cnn is not None and hasattr(cnn, "_pack"):
-                    cnn._pack(st["cap"].device, "bf16x3" if cnn.conv_algo == "f16x2" else cnn.conv_algo)
                 torch.cuda.synchronize(st["cap"].device)
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     self._launch_step_body(st, smoothing)
-                st["graph"], st["graph_key"] = graph, (smoothing, _lib.param_generation_flat(self), st["ws"].gen)
+                ident, refs = cnn.capture_token(cnn_algo) if cnn_algo is not None else (None, None)
+                st["graph"], st["graph_hold"] = graph, refs
+                st["graph_key"] = (smoothing, _lib.param_generation_flat(self), st["ws"].gen, ident)
             st["graph"].replay()
         self.flat.attach_grads()
         world = allreduce_flat_gradients(self.flat.grad, process_group)
@@ -680,10 +695,17 @@ class TrainEngine:
         if isinstance(optimizer, FusedAdam):
             optimizer.step(clip=clip)
         else:
-            check(self.lib.ac_scale_by_coef(self.flat.grad.data_ptr(), self.flat.total, clip.state.data_ptr(),
-                                            _lib.stream()), "ac_scale_by_coef")
-            optimizer.step()
-            _lib.bump_param_generation()
+            # Any other torch optimiser: the clip coefficient is applied to the gradients first.  A non-finite gradient
+            # norm (state[3] != 0) must skip the WHOLE update like the reference does (run.py:123) - scaling by 0 would
+            # turn the NaNs into NaN * 0 = NaN and the optimiser would write them into parameters and moments - so
+            # this path reads the flag back (one host synchronisation per step; FusedAdam skips on the device).
+            if float(clip.state[3].item()) != 0.0:
+                self.flat.grad.zero_()
+            else:
+                check(self.lib.ac_scale_by_coef(self.flat.grad.data_ptr(), self.flat.total, clip.state.data_ptr(),
+                                                _lib.stream()), "ac_scale_by_coef")
+                optimizer.step()
+                _lib.bump_param_generation(self.flat.params)
         out = self._outputs(st)
         return {"loss": st["ws"].tensor("loss")[0], "total_norm": clip.total_norm, "logit": out["logit"],
                 "seq": out.get("seq")}

@@ -66,7 +66,17 @@ class CaptionModel(nn.Module, CaptionMetaMixin):
             return train_forward(self, input_dict)
         encoder_output_dict = self.encoder(input_dict)
         output = self.forward_decoder(input_dict, encoder_output_dict)
+        flag = output.get("f16_overflow")
+        if flag is not None and int(flag.item()) != 0:
+            return self._rerun_wide(input_dict)
         return output
+
+    def _rerun_wide(self, input_dict):
+        """An activation of the fp16-activation conv tier left the fp16 range (the kernels raise ``f16_overflow``
+        instead of storing inf): the batch is run again on the split-bf16 tier, whose activations are f32."""
+        if input_dict.get("conv_algo") == "bf16x3":
+            raise _lib.HipLibraryError("f16_overflow raised by a tier without fp16 activations")
+        return self.forward(dict(input_dict, conv_algo="bf16x3"))
 
     def forward_decoder(self, input_dict, encoder_output_dict):
         if input_dict["mode"] == "train":
@@ -112,9 +122,11 @@ class PendingCaption:
     def __init__(self, model=None):
         self._model = model
         self._done = self._seq = self._lp = self._out = self._release = self._result = None
+        self._flag = self._input = None
 
-    def _fill(self, done_event, host_seq, host_logprob, output, release):
+    def _fill(self, done_event, host_seq, host_logprob, output, release, host_flag=None):
         self._done, self._seq, self._lp, self._out, self._release = done_event, host_seq, host_logprob, output, release
+        self._flag = host_flag
 
     def result(self):
         if getattr(self, "_lazy", None) is not None:   # beam search: the host-driven loop runs now, on the decode stream
@@ -127,9 +139,12 @@ class PendingCaption:
         out = dict(self._out)
         out["seq"] = self._seq.clone()
         out["sampled_logprob"] = self._lp.clone()
+        overflow = self._flag is not None and int(self._flag[0]) != 0
         if self._release is not None:  # hand the pinned staging buffers back to the pool
             self._release()
             self._release = None
+        if overflow:                   # fp16 range exceeded in the conv tier: blocking re-run on f32 activations
+            out = self._model._rerun_wide(self._input)
         self._result = out
         self._seq = self._lp = None
         return dict(out)
@@ -174,6 +189,7 @@ class TransformerModel(CaptionModel):
             enc_done.record(enc_s)
         max_length = int(input_dict.get("max_length", self.max_length))
         item = (PendingCaption(self), enc, enc_done, max_length)
+        item[0]._input = input_dict
         held = self._held
         if held is not None:
             self._held = None
@@ -217,6 +233,9 @@ class TransformerModel(CaptionModel):
                     t.record_stream(dec_s)
             out = self.forward_decoder(input_dict, enc)
             dec_s.synchronize()
+            flag = out.get("f16_overflow")
+            if flag is not None and int(flag.item()) != 0:
+                out = self._rerun_wide(input_dict)
         pending._result = out
 
     def _flush_held(self):
@@ -249,22 +268,27 @@ class TransformerModel(CaptionModel):
                 pool = self._pinned.setdefault((B, max_length), [])
                 if not pool:
                     pool.append((torch.empty(B, max_length, dtype=torch.int64).pin_memory(),
-                                 torch.empty(B, max_length, dtype=torch.float32).pin_memory()))
-                host_seq, host_lp = pool.pop()
+                                 torch.empty(B, max_length, dtype=torch.float32).pin_memory(),
+                                 torch.zeros(1, dtype=torch.int32).pin_memory()))
+                host_seq, host_lp, host_flag = pool.pop()
                 host_seq.copy_(res["seq"][rows], non_blocking=True)
                 host_lp.copy_(res["sampled_logprob"][rows], non_blocking=True)
+                if enc.get("f16_overflow") is not None:
+                    host_flag.copy_(enc["f16_overflow"], non_blocking=True)
+                else:
+                    host_flag.zero_()
                 if len(items) == 1:
                     cnt = res["unfinished_cnt"]
                 else:   # rows still unfinished after step t: finished rows hold end_idx (csrc/decoder.hip greedy_pick)
                     cnt = (res["seq"][rows] != self.end_idx).sum(0).to(torch.int32)
                 out = {"logit": res["logit"][rows], "embed": res["embed"][rows], "unfinished_cnt": cnt}
                 out.update(enc)
-                staged.append((pending, host_seq, host_lp, out, pool))
+                staged.append((pending, host_seq, host_lp, host_flag, out, pool))
             done = torch.cuda.Event()
             done.record(dec_s)
-        for pending, host_seq, host_lp, out, pool in staged:
+        for pending, host_seq, host_lp, host_flag, out, pool in staged:
             pending._fill(done, host_seq, host_lp, out,
-                          (lambda pool=pool, a=host_seq, b=host_lp: pool.append((a, b))))
+                          (lambda pool=pool, a=host_seq, b=host_lp, c=host_flag: pool.append((a, b, c))), host_flag)
 
     # ---- greedy (base.py:152-218) -----------------------------------------------------------------
     def greedy_search(self, input_dict):

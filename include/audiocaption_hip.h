@@ -29,7 +29,7 @@ extern "C" {
 #define AC_ERR_ARG (-1)
 #define AC_ERR_LAUNCH (-2)
 
-#define AC_ABI_VERSION 1
+#define AC_ABI_VERSION 2
 int ac_abi_version(void);
 
 /* ---- log-mel front-end -------------------------------------------------------------------------
@@ -78,17 +78,22 @@ int ac_conv3x3_bn_relu_bf16x3_gw(const float* in, const void* wfrag, const float
  * fragment order, two fp16 MFMA products per f32 product, f32 accumulation, fp16 rounding (RNE, 2^-12 relative) once
  * per stored activation.  The caller scales every output channel of the weights by a power of two before splitting
  * (so the lo parts stay normal fp16 numbers) and multiplies `scale` by the inverse.  Same shape arguments and error
- * codes as ac_conv3x3_bn_relu_bf16x3_gw.  Replaces the same reference code: ConvBlock.forward, cnn_encoder.py:318-338. */
+ * codes as ac_conv3x3_bn_relu_bf16x3_gw.  Replaces the same reference code: ConvBlock.forward, cnn_encoder.py:318-338.
+ * out_f32 != 0 (mode 1 only): the pooled output is written as f32 (it feeds a split-bf16 block: the mixed tier runs
+ * conv_block6, K = 9216 / 18432, on ac_conv3x3_bn_relu_bf16x3_gw).  overflow_flag (may be NULL): one device word that is
+ * OR-ed with 1 when a value about to be stored as fp16 exceeds the fp16 range (65504) - the caller re-runs the batch
+ * on an f32-activation tier instead of returning inf/NaN-poisoned results.
+ * AC_ERR_ARG when B*Hp*W*Cin >= 2^32 (32-bit staging offsets). */
 int ac_conv3x3_bn_relu_f16x2_gw(const void* in, const void* wfrag, const float* scale, const float* shift,
                                 void* out, int B, int Hp, int H, int W, int Cin, int Cout, int mode,
-                                int map_mode, void* stream);
+                                int map_mode, int out_f32, unsigned int* overflow_flag, void* stream);
 /* Block 1 of the "f16x2" tier in one kernel: conv1 (Cin = 1) + BN + ReLU is computed straight into the LDS patch of
  * conv2 (the 64-channel intermediate never exists in HBM), conv2 + BN + ReLU + 2x2 average pool on the matrix cores.
  * in1 [B*Hp][64] f32 (log-mel after bn0), w1 [64][9], wfrag2 as for ac_conv3x3_bn_relu_f16x2_gw (Cin = Cout = 64),
  * out [B*Hp/2][32][64] fp16.  Replaces ConvBlock.forward of conv_block1, cnn_encoder.py:318-338 / :431. */
 int ac_conv3x3_block1_f16x2(const float* in1, const float* w1, const float* scale1, const float* shift1,
                             const void* wfrag2, const float* scale2, const float* shift2, void* out,
-                            int B, int Hp, int H, int W, void* stream);
+                            int B, int Hp, int H, int W, unsigned int* overflow_flag, void* stream);
 
 /* Y[M][N] = act(X[M][K] W[N][K]^T + bias) on the split-bf16 matrix path (2^-16 relative operand error, f32
  * accumulation): the one-tap instance of the "gw" convolution kernel.  X, Y dense row-major f32; wfrag = W split into
@@ -103,7 +108,7 @@ int ac_conv3x3_first(const float* in, const float* w, const float* scale, const 
                      int B, int Hp, int H, int W, void* stream);
 /* The same with an fp16 output [B*Hp][64][64] (first layer of the "f16x2" tier). */
 int ac_conv3x3_first_f16(const float* in, const float* w, const float* scale, const float* shift, void* out,
-                         int B, int Hp, int H, int W, void* stream);
+                         int B, int Hp, int H, int W, unsigned int* overflow_flag, void* stream);
 
 /* ---- dense projection ---------------------------------------------------------------------------
  * Y[M,N] = act(X[M,K] W[N,K]^T + bias): every F.linear of the path (rnn_encoder.py:41 input
@@ -325,7 +330,12 @@ int ac_grad_sumsq(const float* g, long n, float* norm_state, void* stream);
 int ac_clip_coef(float* norm_state, float max_norm, float grad_div, void* stream);
 int ac_scale_by_coef(float* x, long n, const float* norm_state, void* stream);
 int ac_adam_step(float* p, const float* g, float* m, float* v, long n, const float* norm_state, float lr, float beta1,
-                 float beta2, float eps, float weight_decay, int step, void* stream);
+                 float beta2, float eps, float weight_decay, int step, const int* step_dev, void* stream);
+/* step_dev (may be NULL): the number of updates APPLIED so far, kept on the device; when given, the bias correction
+ * uses *step_dev + 1 instead of `step`.  ac_adam_commit advances it after the ac_adam_step launches of one optimiser
+ * step - unless norm_state[3] says the update was skipped (the reference does not call optimizer.step() then,
+ * run.py:123, so its step count does not advance either). */
+int ac_adam_commit(int* step_dev, const float* norm_state, void* stream);
 
 /* ============================ EfficientNet-B2 encoder ============================
  * Replaces efficientnet_pytorch==0.7.1 EfficientNet.extract_features as the reference calls it (hf_wrapper.py:229-241,
