@@ -72,7 +72,7 @@ class Cnn14Encoder(nn.Module):
         # "winograd": F(2x2,3x3) on the f32 MFMA, exact f32.  "direct": 9-tap f32 implicit GEMM.  "bf16x3_lds": bf16x3
         # with an LDS weight ring (kept for ablations).  The train-mode forward always uses "bf16x3" or an f32 tier.
         self.conv_algo = os.environ.get("AUDIOCAPTION_CONV_ALGO", "f16x2")
-        self.f16x2_min_frames = int(os.environ.get("AUDIOCAPTION_F16X2_MIN_FRAMES", "8"))
+        self.f16x2_min_frames = int(os.environ.get("AUDIOCAPTION_F16X2_MIN_FRAMES", "10"))
         # The "f16x2" tier is MIXED: conv_block6 (K = 9216 / 18432, two pixels per frame to average over - half of the
         # tier's logit error by the per-layer breakdown of DESIGN.md section 4) runs on the split-bf16 kernel with f32
         # activations; block 5's pooled output is then written as f32.  "f16x2" here restores the pure fp16 tier.
@@ -242,8 +242,9 @@ class Cnn14Encoder(nn.Module):
             cin, cout = CHANNELS[b], CHANNELS[b + 1]
             w1, s1, t1 = pk["convs"][2 * b]
             w2, s2, t2 = pk["convs"][2 * b + 1]
+            pool_out = pooled
             if mixed and b == 4:     # block 5 hands block 6 (split-bf16, f32 activations) an f32 pooled output
-                pooled = self._buf("pooled32", B * Hp[5] * 2 * CHANNELS[5], dev, torch.float32)
+                pool_out = self._buf("pooled32", B * Hp[5] * 2 * CHANNELS[5], dev, torch.float32)
             if mixed and b == 5:
                 conv = K.conv3x3_bn_relu_bf16x3_gw
                 full = self._buf("full32", B * Hp[5] * 2 * CHANNELS[6], dev, torch.float32)
@@ -255,7 +256,8 @@ class Cnn14Encoder(nn.Module):
                 conv(pooled, w1, s1, t1, full, B, Hp[b], H[b], W, cin, cout, 0)
             if b < 5:
                 if not (b == 0 and fuse1):
-                    conv(full, w2, s2, t2, pooled, B, Hp[b], H[b], W, cout, cout, 1)
+                    conv(full, w2, s2, t2, pool_out, B, Hp[b], H[b], W, cout, cout, 1)
+                pooled = pool_out
                 W //= 2
                 if dropout is not None:
                     K.dropout_(pooled, B * Hp[b + 1] * W * cout, dropout[0], dropout[1] + b, dropout[2])

@@ -38,6 +38,11 @@ OP_LAYER = 30
 D = 256
 H = 256
 
+# Optional per-launch observer (bench.py: roofline of the training GEMMs): called as hook(phase, info) with phase
+# "pre" / "post" around every ac_gemm launch of an EAGER step; info = {"phase": "forward" | "backward", "M", "N", "K",
+# "flops"}.  Never set while a graph is being captured.
+GEMM_HOOK = None
+
 
 def _align(n, a=64):
     return (n + a - 1) // a * a
@@ -173,12 +178,19 @@ class TrainEngine:
         self._seed_ptr = None
         self._saved = None
         self._states = {}
+        self._phase = "forward"
 
     # ---- small launch helpers (raw addresses; s = stream handle) ------------------------------------------
     def _gemm(self, s, A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, bias=None, relu=0, beta=0.0, splitk=1, drop_p=0.0,
               seed=0, row0=0):
+        hook = GEMM_HOOK
+        if hook is not None:
+            info = {"phase": self._phase, "M": M, "N": N, "K": K, "flops": 2.0 * M * N * K}
+            hook("pre", info)
         check(self.lib.ac_gemm(A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, bias, relu, beta, splitk, drop_p, seed,
                                self._seed_ptr, row0, None, 0, s), "ac_gemm")
+        if hook is not None:
+            hook("post", info)
 
     def _lin(self, s, x, W, b, y, M, N, K, ldx=None, ldy=None, relu=0, drop_p=0.0, seed=0, row0=0):
         """y[M][N] = x[M][K] W[N][K]^T + b"""
@@ -334,6 +346,7 @@ class TrainEngine:
         model, lib, fp = self.model, self.lib, self.flat
         enc, dec = model.encoder, model.decoder
         s = _lib.stream()
+        self._phase = "forward"
         ws, lay = st["ws"], st["lay"]
         N, T, Tc, Tq = st["N"], st["T"], st["Tc"], st["Tq"]
         p_dec, p_rnn, p_cnn = st["p_dec"], st["p_rnn"], st["p_cnn"]
@@ -508,6 +521,7 @@ class TrainEngine:
         model, lib, fp = self.model, self.lib, self.flat
         enc, dec = model.encoder, model.decoder
         s = _lib.stream()
+        self._phase = "backward"
         ws, lay = sv["ws"], sv["lay"]
         N, T, Tq, V, F = sv["N"], sv["T"], sv["Tq"], sv["V"], sv["F"]
         B, Tm = N, Tq

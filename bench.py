@@ -4,16 +4,30 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One process per GPU (torch.distributed / RCCL when N > 1); clips are independent, so the batch is
-sharded across ranks with no data-path collective ("scaling": "weak").  A step is one pass of the hot
-path (log-mel -> Cnn14 -> bi-GRU -> greedy Transformer decoding, token ids back on the host) over one
-resident batch.  Rank 0 prints ONE JSON line with the throughput, the roofline of the dominant kernel
-(the pooled 128-channel-tile instance of the f32-MFMA conv, timed live with HIP events on its launch
-stream) and a CPU baseline (the oracle, timed on the host cores on a bounded sample).
+One process per GPU (torch.distributed / RCCL when N > 1): launched under ``torch.distributed.run`` the ranks are read
+from the environment; launched plainly with ``--gpus N > 1`` the script re-executes itself under
+``torch.distributed.run`` with N ranks.  Clips are independent, so the batch is sharded across ranks with no data-path
+collective ("scaling": "weak").  A step is one pass of the hot path (log-mel -> Cnn14 -> bi-GRU -> greedy Transformer
+decoding, token ids back on the host) over one resident batch.  Rank 0 prints ONE JSON line with
+
+* the throughput of the DEFAULT conv tier (``config.precision_gate`` states the parity gate it is held to) over exactly
+  K timed steps, plus ``steady_state`` (>= 2 s of steps: the matrix pipes clock down under sustained MFMA load, which a
+  0.1 s window does not see);
+* ``roofline``: the dominant kernel (conv2 + BN + ReLU + 2x2 pool of blocks 2-5) timed live with HIP events on its
+  launch stream, against the MFMA peak of its operand type;
+* ``tiers``: the same measurement (value, ms_per_step, roofline) for every conv tier - exact f32 (Winograd on the f32
+  MFMA), split-bf16 (f32-grade: logits within 1e-4) and the default fp16 tier - so that whichever precision a reader
+  credits has a number measured in THIS run;
+* ``train_step`` (BASELINE configs[3]) with the roofline of its backward GEMMs and, under ``--mode train``, ``rccl``
+  (the gradient all-reduce timed on its own); ``effb2_trm`` (configs[2]);
+* ``cpu_baseline``: the oracle (CPU restatement of the reference) on the host cores, on a bounded 32-clip sample.
 """
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,21 +38,176 @@ if REPO not in sys.path:
 import torch
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 / fp16 MFMA peak (v_mfma_f32_32x32x16_{bf16,f16})
+HBM_PEAK_GBS = 8000.0
+
+# MFMA work issued per algorithmic (direct-convolution f32) FLOP, per conv tier: Winograd F(2x2,3x3) needs 16 instead of
+# 36 products per tile; the split-bf16 path issues three bf16 products per f32 product (hi*hi, hi*lo, lo*hi); the fp16
+# tier two (x16*w_hi, x16*w_lo)
+TIERS = {
+    "f32": {"conv_algo": "winograd", "linear_algo": "f32", "issue_ratio": 1.0 / 2.25, "peak": FP32_MFMA_PEAK_TFLOPS,
+            "dtype": "f32", "kernel": "conv3x3_wino_kernel<POOL> (Winograd F(2x2,3x3), v_mfma_f32_32x32x2_f32)",
+            "gate": "f32 end to end: logits within 1e-4 of the fp32 CPU reference, identical token ids (measured 4e-6)"},
+    "bf16x3": {"conv_algo": "bf16x3", "linear_algo": "bf16x3", "issue_ratio": 3.0, "peak": BF16_MFMA_PEAK_TFLOPS,
+               "dtype": "bf16x3",
+               "kernel": "conv3x3_gw_kernel<128, POOL, PREC 0 (split bf16 x 3), 2x2 waves, 128 px>",
+               "gate": "f32 gate: logits within 1e-4 of the fp32 CPU reference, identical token ids (measured 3e-5; "
+                       "operands carry 16 significant bits, f32 accumulation)"},
+    "f16x2": {"conv_algo": "f16x2", "linear_algo": "bf16x3", "issue_ratio": 2.0, "peak": BF16_MFMA_PEAK_TFLOPS,
+              "dtype": "f16x2",
+              "kernel": "conv3x3_gw_kernel<128, POOL, PREC 1 (fp16 x 2), 1x4 waves, 256-pixel column-tile blocks>",
+              "gate": "BASELINE.json north_star half-precision gate: identical greedy/beam token ids, logits within 1e-3 of "
+                      "the fp32 CPU reference (worst measured over 5 seeds x 6 clip lengths: "
+                      "tests/test_gpu_model.py::test_default_tier_logit_error_by_clip_length, bar 5e-4)"},
+}
+ALGO_TO_TIER = {"winograd": "f32", "direct": "f32", "bf16x3": "bf16x3", "bf16x3_lds": "bf16x3", "f16x2": "f16x2"}
 
 
-def bench_train(args, world, rank, dev, dist, steps, warmup):
+# ---------------------------------------------------------------------------------------------------------------------
+# launch plumbing: one process per GPU
+# ---------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_spawn(n):
+    """``python bench.py --gpus N`` outside a launcher: re-execute under torch.distributed.run with N ranks on this node
+    (the command the driver itself uses); the children see WORLD_SIZE and do the work."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+class _CStdoutToStderr:
+    """RCCL prints a version banner on the C-level stdout when a communicator is created; stdout of this script carries
+    exactly ONE JSON line, so file descriptor 1 points at stderr while communicators are being set up."""
+
+    def __enter__(self):
+        import ctypes
+        self._libc = ctypes.CDLL(None)
+        sys.stdout.flush()
+        self._libc.fflush(None)
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        self._libc.fflush(None)
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
+class Ranks:
+    """world / rank / device of this process and the two collectives the bench contract needs (barrier, MAX)."""
+
+    def __init__(self, need_gpu=True):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dist = None
+        self.backend = None
+        self.gpu = need_gpu
+        dev_index = 0
+        if need_gpu:
+            n_dev = torch.cuda.device_count()
+            if n_dev == 0:
+                raise SystemExit("bench.py: no ROCm device visible (the hot path has no CPU fallback)")
+            dev_index = self.local_rank % n_dev
+            torch.cuda.set_device(dev_index)
+        self.dev = torch.device("cuda", dev_index) if need_gpu else torch.device("cpu")
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            # one rank per GPU over RCCL ("nccl").  AUDIOCAPTION_BENCH_BACKEND=gloo lets the multi-process flow be
+            # exercised where there are fewer GPUs than ranks (ranks then share a device; RCCL refuses that)
+            self.backend = os.environ.get("AUDIOCAPTION_BENCH_BACKEND", "nccl" if need_gpu else "gloo")
+            if self.backend == "nccl":
+                if torch.cuda.device_count() < self.world:
+                    raise SystemExit(f"bench.py: {self.world} ranks over RCCL need {self.world} GPUs, "
+                                     f"{torch.cuda.device_count()} visible")
+                with _CStdoutToStderr():
+                    dist.init_process_group("nccl", device_id=self.dev)
+                    t = torch.zeros(1, device=self.dev)
+                    dist.all_reduce(t)                 # communicator created here, not inside a timed region
+                    torch.cuda.synchronize()
+            else:
+                dist.init_process_group(self.backend)
+            self.dist = dist
+
+    def sync_all(self):
+        if self.gpu:
+            torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        if self.gpu:
+            torch.cuda.synchronize()
+
+    def max_seconds(self, seconds):
+        if self.dist is None:
+            return float(seconds)
+        dev = self.dev if self.backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def finish(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def timed_steps(ranks, run, steps):
+    """The bench contract's timed region: barrier + synchronize on both sides, MAX over ranks."""
+    ranks.sync_all()
+    t0 = time.perf_counter()
+    out = run(steps)
+    ranks.sync_all()
+    return ranks.max_seconds(time.perf_counter() - t0), out
+
+
+def bench_stub(args, ranks):
+    """Launch-plumbing check without the HIP path (tests/test_bench_launch.py): the "step" is a small CPU matmul, everything
+    else - ranks from the environment or self-spawned, barrier, MAX-over-ranks timing, rank 0 printing one line with
+    n_gpus = world - is the code the real modes run."""
+    x = torch.randn(128, 128, generator=torch.Generator().manual_seed(ranks.rank))
+
+    def run(n):
+        y = x
+        for _ in range(n):
+            y = torch.tanh(y @ x * 1e-2)
+        return y
+
+    run(args.warmup)
+    elapsed, _ = timed_steps(ranks, run, args.steps)
+    return {"metric": "stub steps/sec (launch plumbing only)", "value": ranks.world * args.steps / elapsed, "unit": "steps/s",
+            "n_gpus": ranks.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "stub (no HIP path): one 128x128 CPU matmul per step", "backend": ranks.backend,
+                       "requested_gpus": args.gpus}}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# training step (BASELINE configs[3])
+# ---------------------------------------------------------------------------------------------------------------------
+def bench_train(args, ranks, steps, warmup, with_rccl=False):
     """Training iterations of the reference's recipe (run.py:77-148; cnn14rnn_trm.yaml): frozen Cnn14 with dropout,
     bi-GRU, scheduled-sampling decoder (ss_ratio 0.85), LabelSmoothingLoss(0.1), backward, gradient all-reduce
-    (one RCCL call on the flat gradient buffer), clip_grad_norm_(1.0), Adam(5e-4, weight_decay 1e-6) - everything
+    (RCCL on the flat gradient buffer), clip_grad_norm_(1.0), Adam(5e-4, weight_decay 1e-6) - everything
     inside the timed region, synthetic AudioCaps-shape batches resident in HBM."""
     import random
     import numpy as np
     import audiocaption_amd as A
     from audiocaption_amd import build, procedural as P
     from audiocaption_amd.optim import FusedAdam
-    from audiocaption_amd.train import TrainEngine
+    from audiocaption_amd import train as T
     build.build()
+    world, rank, dev = ranks.world, ranks.rank, ranks.dev
     vocab, cap_len = 4981, 22   # AudioCaps vocabulary (cnn14rnn_trm.yaml:31); <bos> + 20 words + <eos>
     model = A.init_model_from_config(A.cnn14rnn_trm_config(vocab), print_fn=lambda s: None)
     model.load_state_dict(P.to_torch(P.cnn14rnn_trm_state(vocab)), strict=True)
@@ -55,32 +224,66 @@ def bench_train(args, world, rank, dev, dist, steps, warmup):
         cap[i, n:] = 0
     batch = {"mode": "train", "wav": wav, "wav_len": [L] * B, "specaug": False, "cap": cap.to(dev),
              "cap_len": np.asarray(lens), "ss_ratio": 0.85}
-    engine = TrainEngine(model, seed=rank * 1000003)
+    engine = T.TrainEngine(model, seed=rank * 1000003)
     opt = FusedAdam([p for p in model.parameters() if p.requires_grad], lr=5e-4, weight_decay=1e-6)
     random.seed(rank)
 
-    def sync_all():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     r = None
-    for _ in range(warmup):
-        r = engine.step(batch, opt, smoothing=0.1, max_grad_norm=1.0)
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        r = engine.step(batch, opt, smoothing=0.1, max_grad_norm=1.0)
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
+
+    def run(n):
+        last = None
+        for _ in range(n):
+            last = engine.step(batch, opt, smoothing=0.1, max_grad_norm=1.0)
+        return last
+
+    run(warmup)
+    elapsed, r = timed_steps(ranks, run, steps)
     loss = float(r["loss"])
     n_param = engine.flat.total
-    return {
+
+    # roofline of the backward GEMMs (dgrad / wgrad of the decoder and the GRU; exact-f32 MFMA): one EAGER iteration with
+    # HIP events around every ac_gemm launch of the backward (the replayed graph cannot be instrumented)
+    roof = None
+    try:
+        ev = []
+
+        def hook(phase, info):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            if phase == "pre":
+                ev.append([e, None, info])
+            else:
+                ev[-1][1] = e
+
+        engine.step(batch, opt, smoothing=0.1, max_grad_norm=1.0, use_graph=False)   # eager launches warmed up
+        T.GEMM_HOOK = hook
+        engine.step(batch, opt, smoothing=0.1, max_grad_norm=1.0, use_graph=False)
+        T.GEMM_HOOK = None
+        torch.cuda.synchronize()
+        bwd = [(a.elapsed_time(b), i) for a, b, i in ev if i["phase"] == "backward"]
+        fwd = [(a.elapsed_time(b), i) for a, b, i in ev if i["phase"] == "forward"]
+        fl_b, ms_b = sum(i["flops"] for _, i in bwd), sum(t for t, _ in bwd)
+        fl_f, ms_f = sum(i["flops"] for _, i in fwd), sum(t for t, _ in fwd)
+        big = max(bwd, key=lambda x: x[1]["flops"])
+        roof = {"bound": "mfma", "kernel": "gemm_tiled / gemm_nt / gemm_kk (ac_gemm, exact f32 v_mfma_f32_32x32x2_f32): the "
+                                           f"{len(bwd)} dgrad + wgrad launches of one backward pass",
+                "achieved": fl_b / ms_b / 1e9, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": fl_b / ms_b / 1e9 / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                "gemm_ms_per_step": ms_b, "gflop_per_step": fl_b / 1e9, "launches": len(bwd),
+                "largest": {"M": big[1]["M"], "N": big[1]["N"], "K": big[1]["K"], "ms": big[0],
+                            "tflops": big[1]["flops"] / big[0] / 1e9},
+                "forward_gemms": {"achieved": fl_f / ms_f / 1e9 if ms_f > 0 else None, "gemm_ms_per_step": ms_f,
+                                  "gflop_per_step": fl_f / 1e9, "launches": len(fwd),
+                                  "frac": fl_f / ms_f / 1e9 / FP32_MFMA_PEAK_TFLOPS if ms_f > 0 else None},
+                "note": "HIP events around every ac_gemm of one eager iteration (the timed steps replay a HIP graph)"}
+    except Exception as e:  # noqa: BLE001 - a secondary measurement never costs the line
+        T.GEMM_HOOK = None
+        roof = {"error": f"{type(e).__name__}: {e}"}
+
+    rccl = None
+    if with_rccl:
+        rccl = time_allreduce(ranks, engine.flat.grad)
+    res = {
         "metric": "clips/sec trained (forward+backward+Adam), Cnn14_Rnn-Trm, AudioCaps-shape batches",
         "value": world * B * steps / elapsed, "unit": "clips/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -89,19 +292,64 @@ def bench_train(args, world, rank, dev, dist, steps, warmup):
                                f"captions of {cap_len} tokens, vocab {vocab}, scheduled sampling 0.85, dropout on "
                                "(BASELINE configs[3]; the reference's own recipe is global batch 32)",
                    "trainable_parameters": int(sum(p.numel() for p in engine.flat.params)),
-                   "gradient_sync": ("one all-reduce of the flat %.1f MB gradient buffer per step (RCCL)" % (n_param * 4e-6))
+                   "gradient_sync": ("all-reduce of the flat %.1f MB gradient buffer per step (RCCL), decoder half "
+                                     "overlapped with the GRU backward" % (n_param * 4e-6))
                    if world > 1 else "single GPU: none",
                    "last_loss": loss},
+        "roofline": roof,
     }
+    if rccl is not None:
+        res["rccl"] = rccl
+    return res
 
 
-def bench_effb2(args, world, rank, dev, dist, steps, warmup):
+def time_allreduce(ranks, flat_grad):
+    """One all-reduce of the flat gradient buffer timed on its own (the collective of run_ddp.py:98-108).  With a single
+    rank a 1-rank RCCL communicator is created for the measurement, so that the RCCL call itself has executed on this
+    hardware (the data path of a 1-rank all-reduce is a device copy)."""
+    import torch.distributed as dist
+    own_group = False
+    try:
+        buf = flat_grad.clone()
+        with _CStdoutToStderr():
+            if ranks.dist is None:
+                os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+                dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1,
+                                        device_id=ranks.dev)
+                own_group = True
+            for _ in range(3):
+                dist.all_reduce(buf)
+            torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        n = 10
+        for _ in range(n):
+            dist.all_reduce(buf)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / n
+        world = dist.get_world_size()
+        nbytes = buf.numel() * 4
+        return {"world_size": world, "backend": dist.get_backend(), "all_reduce_ms": ms, "bytes": nbytes,
+                "bus_gbs": (2.0 * (world - 1) / world) * nbytes / (ms * 1e-3) / 1e9 if world > 1 else None}
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        if own_group and dist.is_initialized():
+            dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# EffB2-Transformer (BASELINE configs[2] / configs[4])
+# ---------------------------------------------------------------------------------------------------------------------
+def bench_effb2(args, ranks, steps, warmup):
     """EffB2-Transformer captioner (``Effb2TrmCaptioningModel`` shape, hf_wrapper.py:1115-1181): 16 kHz waveforms ->
     log-mel (HTK, top_db 120) -> EfficientNet-B2 -> 2-layer Transformer decoder, beam search (the wrapper's default,
     beam 3) with token ids back on the host; clips sharded over the ranks, no data-path collective."""
     import audiocaption_amd as A
     from audiocaption_amd import build, procedural as P
     build.build()
+    world, rank, dev = ranks.world, ranks.rank, ranks.dev
     vocab = 4981
     model = A.init_model_from_config(A.effb2_trm_config(vocab), print_fn=lambda s: None)
     model.load_state_dict(P.to_torch(P.effb2_trm_state(vocab)), strict=True)
@@ -113,12 +361,6 @@ def bench_effb2(args, world, rank, dev, dist, steps, warmup):
         inp.update(sample_method="beam", beam_size=args.beam)
     else:
         inp.update(sample_method="greedy")
-
-    def sync_all():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     def run_steps(n):
         """Throughput mode: every encoder is submitted up front on the encoder stream; the (host-driven) beam searches
@@ -135,15 +377,7 @@ def bench_effb2(args, world, rank, dev, dist, steps, warmup):
         return last
 
     run_steps(max(warmup, 2))
-    sync_all()
-    t0 = time.perf_counter()
-    out = run_steps(steps)
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
+    elapsed, out = timed_steps(ranks, run_steps, steps)
     assert tuple(out["seq"].shape) == (B, args.max_length)
     # encoder alone (HBM-bound: SURVEY section 8(d)(iv) prices it at ~100 MB of activation traffic per 10 s clip)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -154,15 +388,19 @@ def bench_effb2(args, world, rank, dev, dist, steps, warmup):
     torch.cuda.synchronize()
     enc_ms = e0.elapsed_time(e1) / 3
     alg_bytes = 100e6 * (args.seconds / 10.0) * B
-    traffic = None
-    tpath = os.path.join(REPO, "profiles", "r01_traffic_effb2.json")
-    if os.path.exists(tpath) and args.seconds == 10.0:
-        with open(tpath) as f:   # PMC-measured HBM bytes per clip (collected in separate --pmc passes), scaled to B
-            traffic = json.load(f).get("hbm_bytes_per_clip")
-            traffic = traffic * B if traffic else None
+    traffic, tsrc = None, None
+    for name in ("r02_traffic_effb2.json", "r01_traffic_effb2.json"):
+        tpath = os.path.join(REPO, "profiles", name)
+        if os.path.exists(tpath) and args.seconds == 10.0:
+            with open(tpath) as f:   # PMC-measured HBM bytes per clip (collected in separate --pmc passes), scaled to B
+                traffic = json.load(f).get("hbm_bytes_per_clip")
+                traffic = traffic * B if traffic else None
+            tsrc = f"profiles/{name} (rocprofv3 --pmc passes of the same command, not this run)"
+            break
     return {
-        "encoder_roofline": {"bound": "hbm", "achieved": alg_bytes / (enc_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                             "frac": alg_bytes / (enc_ms * 1e-3) / 8e12, "traffic": traffic, "encoder_ms": enc_ms,
+        "encoder_roofline": {"bound": "hbm", "achieved": alg_bytes / (enc_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": alg_bytes / (enc_ms * 1e-3) / 8e12, "traffic": traffic, "traffic_source": tsrc,
+                             "encoder_ms": enc_ms,
                              "note": "algorithmic activation bytes (100 MB per 10 s clip, SURVEY 8(d)) / measured time of "
                                      "log-mel + EfficientNet-B2 for the whole batch"},
         "metric": "clips/sec encode+decode, EffB2-Transformer", "value": world * B * steps / elapsed, "unit": "clips/s",
@@ -179,7 +417,6 @@ def bench_effb2(args, world, rank, dev, dist, steps, warmup):
                                "forward_async: encoders on one HIP stream, the beam searches on a second one under the "
                                "following encoders"},
     }
-
 
 
 def _decoder_rooflines(model, dev, B, vocab, max_length):
@@ -229,18 +466,48 @@ def _decoder_rooflines(model, dev, B, vocab, max_length):
         tot_us += us * (nl if name != "classifier" else 1)
     return {
         "decode_step": {"bound": "latency (weight stream)", "us_per_step": step_us, "rows": B,
-                        "weight_bytes_per_step": step_bytes, "achieved": step_bytes / (step_us * 1e-6) / 1e9, "peak": 8000.0,
-                        "unit": "GB/s", "frac": step_bytes / (step_us * 1e-6) / 1e9 / 8000.0,
+                        "weight_bytes_per_step": step_bytes, "achieved": step_bytes / (step_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": step_bytes / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                         "mfma_frac": step_flops / (step_us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                        "note": "one KV-cached greedy step over the whole batch, from the replayed HIP graph (18 launches "
-                                "per step): a dependent chain of small kernels; neither HBM nor the matrix cores are the "
-                                "limit at 64 rows"},
+                        "note": "one KV-cached greedy step over the whole batch, from the replayed HIP graph: a dependent "
+                                "chain of small kernels; neither HBM nor the matrix cores are the limit at 64 rows"},
         "teacher_forced_gemms": {"bound": "mfma", "rows": M, "achieved": tot_flops / tot_us / 1e6, "peak": FP32_MFMA_PEAK_TFLOPS,
                                  "unit": "TFLOP/s", "frac": tot_flops / tot_us / 1e6 / FP32_MFMA_PEAK_TFLOPS, "dtype": "f32",
                                  "per_gemm": rows,
                                  "note": "the training GEMM (ac_gemm, exact f32 MFMA) on the decoder's layer shapes at "
                                          "M = batch x 21 caption positions; layer GEMMs weighted x2 layers"},
     }
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# headline: Cnn14Rnn-Trm greedy inference (BASELINE configs[1])
+# ---------------------------------------------------------------------------------------------------------------------
+def conv_roofline(tier, events, note_extra=""):
+    """Roofline object of the dominant conv kernel from the HIP events the launch hook collected."""
+    t = TIERS[tier]
+    flops = sum(2.0 * 9 * i["Cin"] * i["Cout"] * i["H"] * i["W"] * i["B"] for _, _, i in events)
+    ms = sum(s.elapsed_time(e) for s, e, _ in events)
+    n = len(events)
+    achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    traffic, tsrc = None, None
+    for rnd in ("r02", "r01"):
+        tpath = os.path.join(REPO, "profiles", f"{rnd}_traffic_{t['conv_algo']}.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch")
+            tsrc = (f"profiles/{rnd}_traffic_{t['conv_algo']}.json (rocprofv3 --pmc passes of the same command; "
+                    "not measured in this run)")
+            break
+    return {"bound": "mfma", "achieved": achieved, "peak": t["peak"], "unit": "TFLOP/s", "frac": achieved / t["peak"],
+            "traffic": traffic, "traffic_source": tsrc,
+            "kernel": t["kernel"] + " (conv2+BN+ReLU+pool of blocks 2-5)",
+            "note": "achieved = ALGORITHMIC direct-convolution f32 FLOPs / kernel time (HIP events on the launch stream inside "
+                    "the timed steps); mfma_issue_frac = MFMA FLOPs actually issued (x%.3g) / the MFMA peak of the "
+                    "operand type" % t["issue_ratio"] + note_extra,
+            "mfma_issue_frac": achieved * t["issue_ratio"] / t["peak"], "launches_timed": n,
+            "avg_launch_ms": ms / n if n else None,
+            "algorithmic_gflop_per_launch": flops / n / 1e9 if n else None}
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -251,10 +518,13 @@ def main():
     ap.add_argument("--seconds", type=float, default=10.0, help="clip duration")
     ap.add_argument("--max-length", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-f32-path", action="store_true", help="skip the secondary exact-f32 measurement")
+    ap.add_argument("--no-tiers", "--no-f32-path", dest="no_tiers", action="store_true",
+                    help="skip the measurements of the other conv tiers")
+    ap.add_argument("--no-steady-state", action="store_true")
+    ap.add_argument("--steady-seconds", type=float, default=2.0, help="length of the steady-state window")
     ap.add_argument("--sync-steps", action="store_true", help="blocking model(input_dict) per step (no overlap)")
-    ap.add_argument("--cpu-clips", type=int, default=4, help="clips per CPU-baseline pass")
-    ap.add_argument("--cpu-reps", type=int, default=5)
+    ap.add_argument("--cpu-clips", type=int, default=32, help="clips per CPU-baseline pass")
+    ap.add_argument("--cpu-reps", type=int, default=2)
     ap.add_argument("--mode", choices=["infer", "train", "effb2"], default="infer",
                     help="train: the JSON line is the TRAINING step (BASELINE configs[3]: forward + backward + Adam, "
                          "gradients all-reduced over RCCL when N > 1); effb2: EffB2-Transformer inference "
@@ -267,29 +537,25 @@ def main():
                          "maximum, wav_len = true lengths, clips dealt to the ranks by total duration")
     ap.add_argument("--train-batch", type=int, default=32, help="clips per GPU per training step")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement")
+    ap.add_argument("--stub-workload", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # one rank per GPU over RCCL ("nccl").  AUDIOCAPTION_BENCH_BACKEND=gloo lets the multi-process flow be exercised
-        # on a single-GPU box (ranks share the device; RCCL refuses that)
-        backend = os.environ.get("AUDIOCAPTION_BENCH_BACKEND", "nccl")
-        dev_index = local_rank % torch.cuda.device_count()
-        torch.cuda.set_device(dev_index)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group(backend)
-    else:
-        dist = None
-        dev_index = 0
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", dev_index)
+    # `python bench.py --gpus N` without a launcher: spawn the N ranks ourselves
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_spawn(args.gpus))
+
+    ranks = Ranks(need_gpu=not args.stub_workload)
+    world, rank, dev = ranks.world, ranks.rank, ranks.dev
+    if rank == 0 and args.gpus != world:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); n_gpus reports {world}",
+              file=sys.stderr)
+
+    if args.stub_workload:
+        res = bench_stub(args, ranks)
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+        ranks.finish()
+        return
 
     import audiocaption_amd as A
     from audiocaption_amd import build, kernels as K, procedural as P
@@ -297,14 +563,12 @@ def main():
 
     if args.mode in ("train", "effb2"):
         if args.mode == "train":
-            res = bench_train(args, world, rank, dev, dist, args.steps, max(args.warmup, 3))
+            res = bench_train(args, ranks, args.steps, max(args.warmup, 3), with_rccl=True)
         else:
-            res = bench_effb2(args, world, rank, dev, dist, args.steps, max(args.warmup, 1))
+            res = bench_effb2(args, ranks, args.steps, max(args.warmup, 1))
         if rank == 0:
             print(json.dumps(res), flush=True)
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
+        ranks.finish()
         return
 
     vocab = 4368  # Clotho v2 (eg_configs/clotho_v2/waveform/cnn14rnn_trm.yaml:31)
@@ -337,12 +601,6 @@ def main():
     inp = {"mode": "inference", "wav": wav, "wav_len": wav_len, "specaug": False, "sample_method": "greedy",
            "max_length": args.max_length}
 
-    def sync_all():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     def run_steps(n):
         """n passes of the hot path.  Default: throughput mode (forward_async: the encoder of step i+1
         overlaps the latency-bound decode of step i on a second stream; every step is fully processed and its
@@ -358,88 +616,81 @@ def main():
             last = p_.result()
         return last
 
+    cnn = model.encoder.cnn
+    default_algo = cnn.conv_algo
+    default_tier = ALGO_TO_TIER[default_algo]
+    linear_algo = K.LINEAR_ALGO
+
+    def measure(tier, steps, warmup):
+        """K timed steps of one conv tier with HIP events around every launch of its dominant kernel."""
+        cnn.conv_algo = TIERS[tier]["conv_algo"] if tier != default_tier else default_algo
+        K.LINEAR_ALGO = "f32" if tier == "f32" else linear_algo   # the exact-f32 tier: f32 GEMMs as well
+        try:
+            if warmup:
+                run_steps(warmup)
+            events = []
+
+            def hook(phase, info):
+                # the dominant kernel instance: conv2 + BN + ReLU + 2x2 pool of blocks 2-5 (4 launches per step)
+                if info["mode"] == 1 and info["Cout"] % 128 == 0:
+                    e = torch.cuda.Event(enable_timing=True)
+                    e.record()  # on torch's current stream == the kernel's launch stream
+                    if phase == "pre":
+                        events.append([e, None, dict(info)])
+                    else:
+                        events[-1][1] = e
+
+            K.CONV_LAUNCH_HOOK = hook
+            try:
+                elapsed, out = timed_steps(ranks, run_steps, steps)
+            finally:
+                K.CONV_LAUNCH_HOOK = None
+            return elapsed, out, events
+        finally:
+            cnn.conv_algo = default_algo
+            K.LINEAR_ALGO = linear_algo
+
     # One-time setup, not a warm-up step: the decode chain is replayed from a HIP graph that is captured on the SECOND
-    # use of a shape (audiocaption_amd/transformer_decoder.py).  Both shapes the schedule can produce (a pair of
-    # batches, and a single batch when K is odd) are used twice here, so that neither the W warm-up steps nor the K
-    # timed steps contain a graph capture - the same role as loading the weights.
+    # use of a shape (audiocaption_amd/transformer_decoder.py), so the shape is used twice here and neither the W warm-up
+    # steps nor the K timed steps contain a graph capture - the same role as loading the weights.
     if not args.sync_steps:
         for n_prime in (4, 1, 1):
             run_steps(n_prime)
-    out = run_steps(args.warmup) if args.warmup else None
-    # ---- timed region: exactly K steps, HIP events around every launch of the dominant kernel ----
-    events = []
-
-    def hook(phase, info):
-        # the dominant kernel instance: conv2 + BN + ReLU + 2x2 pool of blocks 2-5 (4 launches per step)
-        if info["mode"] == 1 and info["Cout"] % 128 == 0:
-            e = torch.cuda.Event(enable_timing=True)
-            e.record()  # on torch's current stream == the kernel's launch stream
-            if phase == "pre":
-                events.append([e, None, dict(info)])
-            else:
-                events[-1][1] = e
-
-    K.CONV_LAUNCH_HOOK = hook
-    sync_all()
-    t0 = time.perf_counter()
-    out = run_steps(args.steps)
-    sync_all()
-    t1 = time.perf_counter()
-    K.CONV_LAUNCH_HOOK = None
-    from audiocaption_amd.sharding import reduce_max_seconds
-    elapsed = reduce_max_seconds(t1 - t0, device=dev)
-
+    # ---- timed region: exactly K steps of the default tier ----
+    elapsed, out, events = measure(default_tier, args.steps, args.warmup)
     ref_steps = min(int((out["unfinished_cnt"].cpu() > 0).sum().item()) + 1, args.max_length)
-    algo = model.encoder.cnn.conv_algo
-    # MFMA work issued per algorithmic FLOP: Winograd F(2x2,3x3) needs 16 instead of 36 products per tile;
-    # the split-bf16 path issues three bf16 products (hi*hi, hi*lo, lo*hi) per f32 product
-    # (hi*hi, hi*lo, lo*hi) per f32 product; the fp16 tier two (x16*w_hi, x16*w_lo)
-    issue_ratio = {"winograd": 1.0 / 2.25, "direct": 1.0, "bf16x3": 3.0, "bf16x3_lds": 3.0, "f16x2": 2.0}[algo]
-    half_ops = algo.startswith("bf16x3") or algo == "f16x2"   # bf16 and fp16 MFMA share the 2.5 PFLOP/s dense peak
-    peak = BF16_MFMA_PEAK_TFLOPS if half_ops else FP32_MFMA_PEAK_TFLOPS
-    kname = {"winograd": "conv3x3_wino_kernel<POOL>", "direct": "conv3x3_mfma_kernel<128, POOL>",
-             "bf16x3": "conv3x3_gw_kernel<128, POOL, PREC 0 (split bf16), 2x2 waves, 128 px>",
-             "bf16x3_lds": "conv3x3_bf16x3_kernel<128, POOL>",
-             "f16x2": "conv3x3_gw_kernel<128, POOL, PREC 1 (fp16 x 2), 1x4 waves, 256-pixel column-tile blocks>"}[algo]
+    headline_roof = conv_roofline(default_tier, events)
+    tiers = {default_tier: {"value": world * B * args.steps / elapsed, "unit": "clips/s", "ms_per_step": elapsed / args.steps * 1e3,
+                            "steps": args.steps, "conv_algo": default_algo, "dtype": TIERS[default_tier]["dtype"],
+                            "precision_gate": TIERS[default_tier]["gate"], "roofline": headline_roof}}
 
-    # dominant kernel: conv3x3_mfma_kernel<128, POOL> (conv2 of blocks 2-5)
-    flops = sum(2.0 * 9 * i["Cin"] * i["Cout"] * i["H"] * i["W"] * i["B"] for _, _, i in events)
-    ms = sum(s.elapsed_time(e) for s, e, _ in events)
-    n_launch = len(events)
-    achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    # ---- steady state: >= 2 s of steps (DVFS under sustained MFMA load) ----
+    steady = None
+    if not args.no_steady_state:
+        n_ss = int(min(1200, max(args.steps, math.ceil(args.steady_seconds / (elapsed / args.steps)))))
+        ss_elapsed, _, ss_events = measure(default_tier, n_ss, 0)
+        ss_roof = conv_roofline(default_tier, ss_events)
+        steady = {"steps": n_ss, "seconds": ss_elapsed, "ms_per_step": ss_elapsed / n_ss * 1e3,
+                  "value": world * B * n_ss / ss_elapsed, "unit": "clips/s",
+                  "roofline_frac": ss_roof["frac"], "roofline_avg_launch_ms": ss_roof["avg_launch_ms"]}
 
-    # HBM traffic of the dominant kernel comes from PMC passes (rocprofv3 cannot run inside the timed job):
-    # the committed measurement of the same command is attached when present
-    traffic = None
-    tpath = os.path.join(REPO, "profiles", f"r01_traffic_{algo}.json")
-    if os.path.exists(tpath):
-        with open(tpath) as f:
-            traffic = json.load(f).get("hbm_bytes_per_launch")
-    # the exact-f32 tier (Winograd f32-MFMA convolutions) timed beside the default split-bf16 tier
+    # ---- the other conv tiers, same hook, same schedule ----
     extra = {}
-    if half_ops and not args.no_f32_path:
-        cnn = model.encoder.cnn
-        nsec = max(2, args.steps // 2)
-        tiers = [("f32_path", "winograd", "f32")]
-        if algo == "f16x2":   # the split-bf16 tier (f32-grade parity: logits within 3e-5) beside the default
-            tiers.append(("split_bf16_path", "bf16x3", "bf16x3"))
-        linear_algo = K.LINEAR_ALGO
-        for key, tier, dt in tiers:
-            cnn.conv_algo = tier
-            K.LINEAR_ALGO = "f32" if tier == "winograd" else linear_algo   # the exact-f32 tier: f32 GEMMs as well
-            run_steps(2)
-            sync_all()
-            f0 = time.perf_counter()
-            run_steps(nsec)
-            sync_all()
-            fdt = reduce_max_seconds(time.perf_counter() - f0, device=dev)
-            extra[key] = {"conv_algo": tier, "dtype": dt, "steps": nsec, "ms_per_step": fdt / nsec * 1e3,
-                          "value": world * B * nsec / fdt, "unit": "clips/s"}
-        cnn.conv_algo = algo
-        K.LINEAR_ALGO = linear_algo
+    if not args.no_tiers:
+        for tier in ("f32", "bf16x3", "f16x2"):
+            if tier in tiers:
+                continue
+            n_t = max(5, args.steps // 2)
+            try:
+                t_el, _, t_ev = measure(tier, n_t, 2)
+                tiers[tier] = {"value": world * B * n_t / t_el, "unit": "clips/s", "ms_per_step": t_el / n_t * 1e3,
+                               "steps": n_t, "conv_algo": TIERS[tier]["conv_algo"], "dtype": TIERS[tier]["dtype"],
+                               "precision_gate": TIERS[tier]["gate"], "roofline": conv_roofline(tier, t_ev)}
+            except Exception as e:  # noqa: BLE001
+                tiers[tier] = {"error": f"{type(e).__name__}: {e}"}
+
     # the log-mel kernel on its own: HBM-bound (SURVEY section 8(d)(i): 1.54 MB per 10 s clip: waveform in, log-mel out)
     m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    cnn = model.encoder.cnn
     pk = cnn._pack(dev)
     hp0 = cnn.geometry(L)[2][0]
     K.logmel(wav, cnn._tables, pk["bn0"][0], pk["bn0"][1], rows_per_clip=hp0, channels_last=True)
@@ -450,7 +701,7 @@ def main():
     torch.cuda.synchronize()
     mel_ms = m0.elapsed_time(m1) / 10
     mel_bytes = 1.54e6 * (args.seconds / 10.0) * B
-    extra["mel_roofline"] = {"bound": "hbm", "achieved": mel_bytes / (mel_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+    extra["mel_roofline"] = {"bound": "hbm", "achieved": mel_bytes / (mel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": mel_bytes / (mel_ms * 1e-3) / 8e12, "traffic": None, "kernel": "logmel_kernel<1024>",
                              "avg_launch_ms": mel_ms,
                              "note": "wave-per-frame 1024-point FFT + mel + dB + bn0 in one pass; 1.54 MB algorithmic bytes "
@@ -467,14 +718,15 @@ def main():
         # secondary: the training step (BASELINE configs[3]) on this GPU
         del out
         try:   # a secondary measurement must never cost the headline line
-            tr = bench_train(args, world, rank, dev, dist, max(3, args.steps // 2), 3)
-            extra["train_step"] = {k: tr[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config")}
+            tr = bench_train(args, ranks, max(3, args.steps // 2), 3, with_rccl=True)
+            extra["train_step"] = {k: tr[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config",
+                                                       "roofline", "rccl") if k in tr}
         except Exception as e:  # noqa: BLE001
             extra["train_step"] = {"error": f"{type(e).__name__}: {e}"}
     if world == 1 and not args.no_effb2:
         # secondary: EffB2-Transformer inference (BASELINE configs[2])
         try:
-            eb = bench_effb2(args, world, rank, dev, dist, max(3, args.steps // 2), 2)
+            eb = bench_effb2(args, ranks, max(3, args.steps // 2), 2)
             extra["effb2_trm"] = {k: eb[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config",
                                                       "encoder_roofline")}
         except Exception as e:  # noqa: BLE001
@@ -482,6 +734,7 @@ def main():
     result = None
     if rank == 0:
         clips = world * B * args.steps
+        mixed = default_algo == "f16x2" and getattr(cnn, "f16x2_block6", "f16x2") == "bf16x3"
         result = {
             "metric": "clips/sec (10 s @ 32 kHz) encode+greedy-decode, Cnn14_Rnn-Trm",
             "value": clips / elapsed,
@@ -493,7 +746,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f16x2" if algo == "f16x2" else ("bf16x3" if algo.startswith("bf16x3") else "f32"),
+            "dtype": TIERS[default_tier]["dtype"],
             "data": "synthetic",
             "config": {"workload": f"Cnn14Rnn-Trm greedy decode, batch {B} per GPU, {args.seconds:g} s @ 32 kHz "
                                    f"synthetic clips, max_length {args.max_length}, vocab {vocab} (BASELINE configs[1])",
@@ -501,37 +754,29 @@ def main():
                        "input_set": ("Clotho-shape: ragged 15-30 s clips, zero-padded, duration-balanced sharding; "
                                      "%.0f s of audio per step on rank 0" % audio_seconds) if args.clotho_shape else
                                     "fixed-length",
-                       "decode_steps_reference_would_run": ref_steps, "conv_algo": algo,
+                       "decode_steps_reference_would_run": ref_steps, "conv_algo": default_algo,
+                       "precision_gate": TIERS[default_tier]["gate"],
                        "sharding": f"clips sharded over {world} rank(s), no data-path collective",
                        "schedule": "blocking model() per step" if args.sync_steps else
                                    "forward_async: encoders on one HIP stream, the decode chain of step i on a second one under "
                                    "the encoder of step i+1"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic,
-                         "kernel": kname + " (conv2+BN+ReLU+pool of blocks 2-5)",
-                         "note": "achieved = ALGORITHMIC direct-convolution f32 FLOPs / kernel time; "
-                                 "mfma_issue_frac = MFMA FLOPs actually issued (x%.3g) / the MFMA peak of the "
-                                 "operand type" % issue_ratio,
-                         "mfma_issue_frac": achieved * issue_ratio / peak,
-                         "launches_timed": n_launch,
-                         "avg_launch_ms": ms / n_launch if n_launch else None,
-                         "algorithmic_gflop_per_launch": flops / n_launch / 1e9 if n_launch else None},
+            "roofline": headline_roof,
+            "steady_state": steady,
+            "tiers": tiers,
         }
         result["config"]["precision"] = {
-            "f16x2": "convolutions on fp16 MFMA with f32 accumulation: activations rounded once to fp16 (RNE, 2^-12 "
-                     "relative; they live in HBM as fp16), weights as fp16 hi + lo (2^-22), two products per f32 "
-                     "product; the GRU input projections on split-bf16 operands (2^-16); everything else f32.  Parity: identical greedy/beam token ids on every golden fixture, "
-                     "logits within 4e-4 of the reference at this clip length, 6.3e-4 for any clip of 2.6 s and more "
-                     "(shorter ones are routed to the split-bf16 tier; bar: BASELINE.json's 1e-3 for half-precision paths); more "
-                     "accurate than the TF32 convolutions the reference runs by default on its own GPUs.  "
-                     "AUDIOCAPTION_CONV_ALGO=bf16x3 is the f32-grade tier (logits within 3e-5), =winograd exact f32",
+            "f16x2": "convolutions of blocks 1-5 on fp16 MFMA with f32 accumulation: activations rounded once to fp16 (RNE, "
+                     "2^-12 relative; they live in HBM as fp16), weights as fp16 hi + lo (2^-22), two products per f32 "
+                     "product; " + ("conv_block6 (K = 9216 / 18432: half of the tier's logit error) on split-bf16 operands "
+                                    "with f32 activations; " if mixed else "") +
+                     "the GRU input projections on split-bf16 operands (2^-16); everything else f32.  Values beyond the "
+                     "fp16 range raise a device flag and the batch is re-run on the split-bf16 tier; batches with a clip "
+                     "under 2.6 s run there as well.  AUDIOCAPTION_CONV_ALGO=bf16x3 is the f32-grade tier (logits within "
+                     "3e-5), =winograd exact f32 - both measured in `tiers`",
             "bf16x3": "split-bf16 convolutions (x = hi + lo, hi*hi + hi*lo + lo*hi, f32 accumulate: 2^-16 relative "
                       "operand error), everything else f32; parity: identical greedy/beam token ids, logits within "
-                      "3e-5 of the reference on the golden fixtures"}.get(
-            "bf16x3" if algo.startswith("bf16x3") else algo, "f32 end to end")
-        for key in ("f32_path", "split_bf16_path"):
-            if key in extra:
-                result[key] = extra[key]
+                      "3e-5 of the reference on the golden fixtures",
+            "f32": "f32 end to end"}[default_tier]
         result["rooflines_other"] = {"logmel": extra["mel_roofline"], "decoder": extra["decoder_roofline"]}
         if "train_step" in extra:
             result["train_step"] = extra["train_step"]
@@ -541,7 +786,7 @@ def main():
             try:
                 from oracle import cpu_path as O  # the CPU restatement, timed as a reported baseline only
                 nc = args.cpu_clips
-                cwav = torch.from_numpy(P.synthetic_wav(B, L)[:nc])
+                cwav = torch.from_numpy(P.synthetic_wav(max(nc, 1), L)[:nc])
                 O.caption_forward(state, cwav[:1], [L], "greedy", max_length=args.max_length, force_steps=True)
                 t_enc, t_dec = [], []
                 for _ in range(args.cpu_reps):   # encode and decode timed separately
@@ -553,22 +798,19 @@ def main():
                     c2 = time.perf_counter()
                     t_enc.append(c1 - c0)
                     t_dec.append(c2 - c1)
-                t_enc.sort()
-                t_dec.sort()
-                me, md = t_enc[len(t_enc) // 2], t_dec[len(t_dec) // 2]
+                me, md = min(t_enc), min(t_dec)
                 result["cpu_baseline"] = {
                     "value": nc / (me + md), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
                     "encode_clips_per_s": nc / me, "decode_clips_per_s": nc / md,
                     "host_cpu_count": os.cpu_count(), "torch": torch.__version__,
                     "sample": f"oracle/cpu_path.py (fp32 torch CPU ops): log-mel + Cnn14 + bi-GRU, then greedy decoding that "
-                              f"re-runs the decoder on the whole prefix for {args.max_length} steps like the reference; {nc} "
-                              f"clips x {args.seconds:g} s, medians of {args.cpu_reps} passes after 1 warm-up"}
+                              f"re-runs the decoder on the whole prefix for {args.max_length} steps like the reference; ONE "
+                              f"batch of {nc} clips x {args.seconds:g} s per pass, best of {args.cpu_reps} passes after a "
+                              f"1-clip warm-up"}
             except Exception as e:  # noqa: BLE001
                 result["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(result), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    ranks.finish()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,48 @@
+"""CPU, 2 ranks (gloo): ``python bench.py --gpus 2`` outside any launcher must start two ranks itself and report
+``n_gpus: 2`` (round 1's bench.py parsed --gpus and ignored it).  The per-step work is a stub (--stub-workload: the HIP
+path needs a GPU); the launch plumbing - self-spawn under torch.distributed.run, ranks from the environment, barrier,
+MAX-over-ranks timing, rank 0 printing ONE JSON line - is the code every real mode of bench.py runs."""
+import json
+import os
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(argv, env_extra=None, timeout=240):
+    env = dict(os.environ, AUDIOCAPTION_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + argv, env=env, cwd=REPO, timeout=timeout,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout          # exactly one JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_self_spawns_two_ranks():
+    res = _run(["--gpus", "2", "--steps", "4", "--warmup", "1", "--stub-workload"])
+    assert res["n_gpus"] == 2 and res["steps"] == 4 and res["warmup"] == 1
+    assert res["config"]["backend"] == "gloo" and res["config"]["requested_gpus"] == 2
+    assert res["scaling"] == "weak" and res["value"] > 0 and res["ms_per_step"] > 0
+
+
+def test_bench_under_a_launcher_reads_the_ranks_from_the_environment():
+    """The driver's own command: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N."""
+    env = dict(os.environ, AUDIOCAPTION_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29731", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3",
+                        "--warmup", "1", "--stub-workload"], env=env, cwd=REPO, timeout=240, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    assert json.loads(lines[0])["n_gpus"] == 2
+
+
+def test_bench_single_rank_stub():
+    res = _run(["--steps", "2", "--warmup", "0", "--stub-workload"])
+    assert res["n_gpus"] == 1

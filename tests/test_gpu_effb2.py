@@ -171,3 +171,58 @@ def test_effb2_trm_tokens_vs_oracle(effb2_model, state_effb2, seconds):
     seq = hf(wav, wav_len, max_length=12)                     # defaults: beam search, beam_size 3
     assert seq.device.type == "cpu" and seq.dtype == torch.int64 and seq.shape == (3, 12)
     assert torch.equal(seq, want_b["seq"])
+
+
+def test_effb2_30s_beam4_vs_oracle(effb2_model, state_effb2):
+    """BASELINE configs[4]: EffB2-Trm on 30 s clips (T = 3001 frames -> 94 encoder frames, the last one masked), ragged
+    lengths, beam search with beam_size 4 - token ids identical to the oracle's restatement of
+    ``EfficientNetB2.forward`` (hf_wrapper.py:287-315) + ``beam_search`` (base.py:254-325), encoder outputs to 5e-4."""
+    from audiocaption_amd import procedural as Pr
+    from oracle import effb2_path as E
+    L = 30 * 16000
+    wav = Pr.synthetic_wav(3, L, sample_rate=16000, seed=41, varied=True)
+    wav_len = [L, 400000, 250000]
+    for i, n in enumerate(wav_len):
+        wav[i, n:] = 0.0
+    wav = torch.from_numpy(wav)
+    want = E.caption_forward(state_effb2, wav, wav_len, "beam", beam_size=4, max_length=20)
+    got = effb2_model({"mode": "inference", "wav": wav.cuda(), "wav_len": wav_len, "specaug": False,
+                       "sample_method": "beam", "beam_size": 4, "max_length": 20})
+    assert got["attn_emb"].shape == (3, 94, 1408) and got["attn_emb_len"].tolist() == [93, 78, 48]
+    assert torch.equal(got["attn_emb_len"], want["attn_emb_len"])
+    assert rel("30 s attn_emb", got["attn_emb"], want["attn_emb"]) < 5e-4
+    assert rel("30 s fc_emb", got["fc_emb"], want["fc_emb"]) < 5e-4
+    print(got["seq"].tolist(), want["seq"].tolist())
+    assert got["seq"].shape == (3, 20) and got["seq"].dtype == torch.int64 and got["seq"].device.type == "cpu"
+    assert torch.equal(got["seq"], want["seq"])
+    # the throughput-mode entry (encoder submitted up front, search at result()) returns the same ids
+    pend = effb2_model.forward_async({"mode": "inference", "wav": wav.cuda(), "wav_len": wav_len, "specaug": False,
+                                      "sample_method": "beam", "beam_size": 4, "max_length": 20})
+    assert torch.equal(pend.result()["seq"], want["seq"])
+
+
+def test_encoder_graph_survives_a_buffer_regrow(effb2_model):
+    """The EffB2 encoder replays a HIP graph per input shape over SHARED activation buffers.  10 s, 10 s (capture),
+    30 s (the buffers are re-allocated), 10 s: the 10 s graph must be re-captured, not replayed into freed memory."""
+    from audiocaption_amd import procedural as Pr
+    enc = effb2_model.encoder
+    enc._graphs.clear()
+    enc._bufs.clear()
+    short = torch.from_numpy(Pr.synthetic_wav(2, 160000, sample_rate=16000, seed=3, varied=True)).cuda()
+    long_ = torch.from_numpy(Pr.synthetic_wav(2, 480000, sample_rate=16000, seed=4, varied=True)).cuda()
+    want_s, want_l = enc._encode(short).clone(), enc._encode(long_).clone()
+    enc._bufs.clear()                      # start again from small buffers
+    a = enc._encode_graph(short)           # eager
+    b = enc._encode_graph(short)           # captured + replayed
+    gen = enc._buf_gen
+    c = enc._encode_graph(long_)           # larger shape: shared buffers re-allocated
+    assert enc._buf_gen > gen
+    filler = torch.full((int(2e8),), 7.0, device="cuda")   # recycle whatever the old buffers occupied
+    d = enc._encode_graph(short)           # must not replay the stale graph
+    e = enc._encode_graph(long_)           # second use of the long shape: captured
+    f = enc._encode_graph(short)
+    del filler
+    for name, got, want in (("a", a, want_s), ("b", b, want_s), ("c", c, want_l), ("d", d, want_s), ("e", e, want_l),
+                            ("f", f, want_s)):
+        # (the squeeze-excite sums are float atomics, so two runs agree to rounding, not bit for bit)
+        assert rel(f"graph vs eager {name}", got, want) < 1e-5, name

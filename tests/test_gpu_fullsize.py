@@ -77,6 +77,38 @@ def test_effb2_full_batch_permutation(state_effb2):
     assert torch.equal(pout["seq"], out["seq"][perm])
 
 
+def test_effb2_30s_beam4_full_batch_vs_single(state_effb2):
+    """BASELINE configs[4] at its per-GPU size: EffB2-Trm, 64 clips x 30 s @ 16 kHz, ragged lengths, beam 4.  The log-mel
+    floor (top_db) depends on the loudest clip of the batch by design, so clip-by-clip equality holds when the loudest
+    clip travels with the subset; beams of one clip never see another clip."""
+    import audiocaption_amd as A
+    from audiocaption_amd import procedural as Pr
+    model = A.init_model_from_config(A.effb2_trm_config(4981), print_fn=lambda s: None)
+    model.load_state_dict(state_effb2, strict=True)
+    model = model.eval().cuda()
+    B, L = 64, 480000
+    wav = torch.from_numpy(Pr.synthetic_wav(B, L, seed=19, varied=True, sample_rate=16000)).cuda()
+    lens = [L - 16000 * (i % 13) for i in range(B)]
+    for i, n in enumerate(lens):
+        wav[i, n:] = 0
+    # the clip that holds the batch maximum of the log-mel (it sets every clip's -120 dB floor)
+    lm = model.encoder.logmel(wav).view(B, -1)
+    loud = int(lm.amax(1).argmax())
+    out = model(_inp(wav, lens, sample_method="beam", beam_size=4))
+    assert out["attn_emb"].shape == (B, 94, 1408) and out["seq"].shape == (B, 20)
+    assert out["attn_emb_len"].tolist() == [(n // 160 + 1) // 32 for n in lens]
+    for i in (1, 17, 40):
+        idx = [i, loud] if i != loud else [i]
+        one = model(_inp(wav[idx].contiguous(), [lens[j] for j in idx], sample_method="beam", beam_size=4))
+        d = float((one["attn_emb"][0] - out["attn_emb"][i]).abs().max())
+        # (the 1x1-conv kernel is chosen by the row count, so a 2-clip batch sums in a different order: rounding only)
+        assert d < 2e-5 * float(out["attn_emb"].abs().max()) + 1e-6, (i, d)
+        assert torch.equal(one["seq"][0], out["seq"][i])
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(5))
+    pout = model(_inp(wav[perm.cuda()].contiguous(), [lens[i] for i in perm.tolist()], sample_method="beam", beam_size=4))
+    assert torch.equal(pout["seq"], out["seq"][perm])
+
+
 def test_training_gradient_is_linear_in_the_batch(state4981):
     """BASELINE configs[3] shape (32 clips, 22-token captions), dropout 0, teacher forcing (deterministic): the loss is a
     mean over tokens, so  count * grad(batch) = count_A * grad(A) + count_B * grad(B)  for a split of the batch."""

@@ -346,3 +346,156 @@ def test_g9_transformer_encoder_vs_reference_golden(golden_dir):
     wav = torch.from_numpy(P.synthetic_wav(2, 64000)).cuda()
     o = comp({"wav": wav, "wav_len": [64000, 40000], "specaug": False})
     assert o["attn_emb"].shape == (2, 7, 256) and o["attn_emb_len"].tolist() == [7, 4]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The fp16-activation tier under weights that do not look like the procedural ones: real PANNs checkpoints have
+# BatchNorm running variances spread over orders of magnitude, conv filters of very different norms and larger
+# activations.  The checker is always the CPU oracle on the SAME re-drawn state.
+# ---------------------------------------------------------------------------------------------------------------
+def _panns_like_state(state, seed, gains=None):
+    """Re-draw the Cnn14 part of a procedural state with PANNs-like statistics:
+    * every output channel of every conv gets a scale s in [0.1, 10] (log-uniform) with the following BatchNorm's
+      running mean / variance moved along (variance x s^2: it spans 1e-2 ... 1e2 x the procedural 1 +- 0.2);
+    * ``gains[l]``: the BatchNorm affine (weight, bias) of conv layer l is multiplied by g and the input channels of the
+      next conv divided by g, i.e. the ACTIVATIONS stored between the two layers are g x larger (ReLU and the average
+      pooling commute with g > 0) while the network function stays what it was."""
+    st = {k: v.clone() for k, v in state.items()}
+    g = torch.Generator().manual_seed(seed)
+    names = [(f"encoder.cnn.conv_block{b}.conv{j}", f"encoder.cnn.conv_block{b}.bn{j}") for b in range(1, 7) for j in (1, 2)]
+    for l, (conv, bn) in enumerate(names):
+        cout = st[conv + ".weight"].shape[0]
+        s_c = torch.pow(10.0, torch.rand(cout, generator=g) * 2 - 1)
+        st[conv + ".weight"] = st[conv + ".weight"] * s_c.view(-1, 1, 1, 1)
+        st[bn + ".running_mean"] = st[bn + ".running_mean"] * s_c
+        st[bn + ".running_var"] = st[bn + ".running_var"] * s_c * s_c
+        gain = (gains or {}).get(l)
+        if gain is not None and l + 1 < len(names):
+            st[bn + ".weight"] = st[bn + ".weight"] * gain
+            st[bn + ".bias"] = st[bn + ".bias"] * gain
+            nxt = names[l + 1][0] + ".weight"
+            st[nxt] = st[nxt] / gain
+    return st
+
+
+def _model_with_state(state):
+    import audiocaption_amd as A
+    model = A.init_model_from_config(A.cnn14rnn_trm_config(4981), print_fn=lambda s: None)
+    model.load_state_dict(state, strict=True)
+    return model.eval().to("cuda:0")
+
+
+@pytest.mark.parametrize("seed,gains", [(1, None), (2, {1: 256.0, 4: 64.0, 8: 128.0}), (3, {0: 1 / 64.0, 5: 1 / 16.0, 9: 1 / 64.0})])
+def test_fp16_tier_with_panns_like_statistics(state4981, seed, gains):
+    """Default tier on re-drawn weights (running_var over 1e-2...1e2, per-channel filter scales x0.1...x10, activations
+    up to ~2e4 or down to ~1e-2 of the procedural ones): logits within BASELINE.json's 1e-3 of the oracle, ids equal."""
+    from audiocaption_amd import procedural as P
+    from oracle import cpu_path as O
+    st = _panns_like_state(state4981, seed, gains)
+    var = st["encoder.cnn.conv_block3.bn1.running_var"]
+    assert float(var.max() / var.min()) > 1e3
+    model = _model_with_state(st)
+    assert model.encoder.cnn.conv_algo == "f16x2"
+    L = 160000
+    wav_len = [L, 120000]                                  # 15 and 11 output frames: the fp16 tier runs
+    wav = P.synthetic_wav(2, L, seed=20 + seed, varied=True)
+    wav[1, wav_len[1]:] = 0
+    wav = torch.from_numpy(wav)
+    want = O.caption_forward(st, wav, wav_len, "greedy", max_length=8)
+    enc = model.encoder({"wav": wav.cuda(), "wav_len": wav_len, "specaug": False})
+    assert int(enc["f16_overflow"].item()) == 0          # the fp16 tier ran and stayed inside its range
+    out = model({"mode": "inference", "wav": wav.cuda(), "wav_len": wav_len, "specaug": False,
+                 "sample_method": "greedy", "max_length": 8})
+    stp = want["steps"]
+    d_attn = _maxdiff(f"attn_emb, PANNs-like seed {seed}", out["attn_emb"], want["attn_emb"])
+    d = _maxdiff(f"logit, PANNs-like seed {seed}", out["logit"][:, :stp], want["logit"][:, :stp])
+    assert d < 1e-3 and d_attn < 1e-3
+    top2 = want["logit"][:, :stp].topk(2, -1).values
+    if float((top2[..., 0] - top2[..., 1]).min()) > 2e-3:
+        assert torch.equal(out["seq"][:, :stp], want["seq"][:, :stp])
+
+
+def test_fp16_range_overflow_is_detected_and_rerouted(state4981):
+    """An activation beyond the fp16 range (65504) must not poison the result silently (inf -> NaN -> erased by the next
+    ReLU): the kernels raise ``f16_overflow`` and the model re-runs the batch on the split-bf16 tier (f32 activations),
+    through ``model()`` and through ``forward_async`` alike."""
+    from audiocaption_amd import procedural as P
+    from oracle import cpu_path as O
+    st = _panns_like_state(state4981, 5, {3: 65536.0})       # block 2's output: O(10) x 2^16
+    model = _model_with_state(st)
+    L = 160000
+    wav_len = [L, 120000]
+    wav = P.synthetic_wav(2, L, seed=31, varied=True)
+    wav[1, wav_len[1]:] = 0
+    wav = torch.from_numpy(wav)
+    want = O.caption_forward(st, wav, wav_len, "greedy", max_length=8)
+    inp = {"mode": "inference", "wav": wav.cuda(), "wav_len": wav_len, "specaug": False, "sample_method": "greedy",
+           "max_length": 8}
+    enc = model.encoder(dict(inp))
+    assert int(enc["f16_overflow"].item()) == 1               # raised by the kernel that stored the value
+    stp = want["steps"]
+    for out in (model(dict(inp)), model.forward_async(dict(inp)).result()):
+        assert "f16_overflow" not in out                      # the answer comes from the f32-activation tier
+        assert torch.isfinite(out["logit"][:, :stp]).all()
+        assert _maxdiff("logit after the re-run", out["logit"][:, :stp], want["logit"][:, :stp]) < 1e-4
+        assert torch.equal(out["seq"][:, :stp], want["seq"][:, :stp])
+    # beam search takes the same route
+    wb = O.caption_forward(st, wav, wav_len, "beam", beam_size=3, max_length=8)
+    ob = model(dict(inp, sample_method="beam", beam_size=3))
+    assert torch.equal(ob["seq"], wb["seq"])
+
+
+def test_mixed_tier_hands_block6_f32_activations(hip_model, golden_dir):
+    """The default tier runs conv_block6 on the split-bf16 kernel: block 5's pooled output is written as f32 (not rounded
+    to fp16) and the two block-6 layers see f32 activations - attn_emb lands closer to the reference than with the
+    pure fp16 tier, and both stay inside the tier's bar."""
+    from audiocaption_amd import procedural as P
+    g = _load(golden_dir, "g1_cnn14.npz")
+    cnn = hip_model.encoder.cnn
+    saved, saved6 = cnn.conv_algo, cnn.f16x2_block6
+    lms = torch.from_numpy(P.synthetic_logmel(2, 1001)).cuda()
+    try:
+        cnn.conv_algo = "f16x2"
+        cnn.f16x2_block6 = "bf16x3"
+        attn_m, blocks_m = _cnn_from_logmel(cnn, lms)
+        cnn.f16x2_block6 = "f16x2"
+        attn_p, blocks_p = _cnn_from_logmel(cnn, lms)
+    finally:
+        cnn.conv_algo, cnn.f16x2_block6 = saved, saved6
+    d_m = _maxdiff("attn_emb mixed tier", attn_m, g["attn_emb"])
+    d_p = _maxdiff("attn_emb pure fp16 tier", attn_p, g["attn_emb"])
+    assert d_m < 1e-3 and d_p < 1e-3 and d_m < d_p
+    # blocks 1-4 are the same kernels on the same inputs; block 5 differs only by the missing fp16 rounding
+    for b in range(4):
+        assert torch.equal(blocks_m[b], blocks_p[b])
+    assert not torch.equal(blocks_m[4], blocks_p[4])
+    assert float((blocks_m[4] - blocks_p[4]).abs().max()) < 2e-3 * float(blocks_p[4].abs().max())
+    assert torch.equal(blocks_m[4].half().float(), blocks_p[4])   # ... exactly: rounding the f32 output gives the fp16 one
+
+
+@pytest.mark.parametrize("seconds", [1.0, 2.0, 3.0, 4.0, 6.0, 10.0])
+def test_default_tier_logit_error_by_clip_length(hip_model, state4981, seconds):
+    """Worst logit error of the DEFAULT path (fp16 tier with block 6 on split-bf16; batches with a clip under
+    ``f16x2_min_frames`` frames on the split-bf16 tier) against the CPU oracle over 5 seeds per clip length: <= 5e-4
+    (half of BASELINE.json's 1e-3 bar for half-precision operands), token ids identical."""
+    from audiocaption_amd import procedural as P
+    from oracle import cpu_path as O
+    cnn = hip_model.encoder.cnn
+    assert cnn.conv_algo == "f16x2" and cnn.f16x2_block6 == "bf16x3"
+    L = int(32000 * seconds)
+    lens = [L, int(L * 0.8)]
+    worst = 0.0
+    for seed in (9, 10, 11, 12, 13):
+        wav = P.synthetic_wav(2, L, seed=seed, varied=True)
+        wav[1, lens[1]:] = 0
+        wav = torch.from_numpy(wav)
+        want = O.caption_forward(state4981, wav, lens, "greedy", max_length=8)
+        out = hip_model({"mode": "inference", "wav": wav.cuda(), "wav_len": lens, "specaug": False,
+                         "sample_method": "greedy", "max_length": 8})
+        stp = want["steps"]
+        worst = max(worst, float((out["logit"][:, :stp].cpu() - want["logit"][:, :stp]).abs().max()))
+        top2 = want["logit"][:, :stp].topk(2, -1).values
+        if float((top2[..., 0] - top2[..., 1]).min()) > 1e-3:
+            assert torch.equal(out["seq"][:, :stp], want["seq"][:, :stp])
+    print(f"{seconds} s clips ({want['attn_emb_len'].tolist()} frames): worst |logit diff| over 5 seeds {worst:.2e}")
+    assert worst <= 5e-4

@@ -559,6 +559,85 @@ def test_swa_and_nan_skip_on_device(train_model):
     opt.step(clip=clip)
     assert float(clip.state[3]) == 1.0 and float(clip.state[2]) == 0.0
     assert torch.equal(eng.flat.flat, before) and torch.equal(opt._flat_state[0]["m"], m_before)
+    # the skipped update does not advance Adam's step count either (the reference never calls optimizer.step() then)
+    sd = opt.state_dict()
+    assert all(int(v["step"]) == 3 for v in sd["state"].values())
+    # a loaded state replaces the flat moment buffers and the device-side step count
+    sd["state"][0]["exp_avg"] = torch.full_like(sd["state"][0]["exp_avg"], 0.25)
+    for v in sd["state"].values():
+        v["step"] = 7
+    opt.load_state_dict(sd)
+    assert opt._flat_state == {} and opt._step_dev == {}
+    eng.flat.grad.zero_()
+    opt.step()                                                 # zero gradient: m <- 0.9 m
+    p0 = opt.param_groups[0]["params"][0]
+    assert rel("adopted first moment", opt.state[p0]["exp_avg"], torch.full_like(p0, 0.225)) < 1e-6
+    assert all(int(v["step"]) == 8 for v in opt.state_dict()["state"].values())
+
+
+def test_generic_optimizer_skips_a_non_finite_step(train_model):
+    """``engine.step`` with a plain torch optimiser: a NaN loss (here: a NaN smoothing constant) must leave the parameters
+    untouched - scaling NaN gradients by a zero clip coefficient would still hand NaNs to the optimiser (run.py:123)."""
+    from audiocaption_amd import procedural as Pr
+    from audiocaption_amd.train import TrainEngine
+    model = train_model
+    B, L = 2, 96000
+    wav = torch.from_numpy(Pr.synthetic_wav(B, L, seed=4)).cuda()
+    cap = torch.tensor([[1, 9, 30, 2, 0], [1, 7, 7, 12, 2]])
+    batch = {"mode": "train", "wav": wav, "wav_len": [L] * B, "specaug": False, "cap": cap.cuda(),
+             "cap_len": np.array([4, 5]), "ss_ratio": 0.9}
+    eng = TrainEngine(model)
+    opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=1e-2, momentum=0.9)
+    r = eng.step(batch, opt, use_graph=False)
+    assert np.isfinite(float(r["loss"]))
+    before = eng.flat.flat.clone()
+    r = eng.step(batch, opt, smoothing=float("nan"), use_graph=False)
+    assert not np.isfinite(float(r["loss"]))
+    assert torch.equal(eng.flat.flat, before) and torch.isfinite(eng.flat.flat).all()
+    r = eng.step(batch, opt, use_graph=False)                  # and training goes on
+    assert np.isfinite(float(r["loss"])) and not torch.equal(eng.flat.flat, before)
+
+
+def test_replayed_graph_after_a_buffer_regrow_equals_the_eager_step(train_model):
+    """Captured step graphs hold raw addresses of the frozen Cnn14's packed weights and of its shared activation buffers.
+    Optimiser steps must not repack the frozen network, and a larger batch shape re-allocating the shared buffers must
+    make the older shape's graph re-capture: with lr = 0 (parameters fixed) and a fixed dropout seed, a step of the
+    small shape gives the SAME loss eagerly, captured, replayed, and replayed again after the larger shape ran."""
+    from audiocaption_amd import procedural as Pr
+    from audiocaption_amd.optim import FusedAdam
+    from audiocaption_amd.train import TrainEngine
+    model = train_model
+    eng = TrainEngine(model, seed=3)
+    opt = FusedAdam([p for p in model.parameters() if p.requires_grad], lr=0.0)
+    base = torch.from_numpy(Pr.synthetic_wav(4, 256000, seed=12, varied=True)).cuda()
+    g = torch.Generator().manual_seed(3)
+
+    def batch(L, Tc, n):
+        cap = torch.randint(4, 4981, (n, Tc), generator=g)
+        cap[:, 0], cap[:, -1] = 1, 2
+        return {"mode": "train", "wav": base[:n, :L].contiguous(), "wav_len": [L] * n, "specaug": False, "cap": cap.cuda(),
+                "cap_len": np.array([Tc] * n), "ss_ratio": 0.8, "dropout_seed": 11, "_use_cap": [1, 0, 1, 1, 0, 1, 1][:Tc - 1]}
+
+    small, big = batch(96000, 6, 2), batch(256000, 8, 4)
+    eager = float(eng.step(small, opt, use_graph=False)["loss"])
+    cnn = model.encoder.cnn
+    pack_id = id(cnn._packed["bf16x3"][1])
+    ptr_small = cnn._bufs[("full", torch.float32)].data_ptr()
+    vals = [float(eng.step(small, opt)["loss"]) for _ in range(3)]     # eager (first of the shape), capture, replay
+    st_small = eng._states[next(k for k in eng._states if k[1] == 2)]
+    assert st_small["graph"] is not None
+    assert id(cnn._packed["bf16x3"][1]) == pack_id                      # optimiser steps do not repack the frozen Cnn14
+    big_eager = float(eng.step(big, opt, use_graph=False)["loss"])      # larger shape: shared buffers re-allocated
+    assert cnn._bufs[("full", torch.float32)].data_ptr() != ptr_small or cnn._bufs[("full", torch.float32)].numel() > 0
+    filler = torch.full((int(1e8),), 3.0, device="cuda")                # recycle the freed blocks
+    big_vals = [float(eng.step(big, opt)["loss"]) for _ in range(3)]
+    after = [float(eng.step(small, opt)["loss"]) for _ in range(2)]    # must re-capture, not replay stale addresses
+    del filler
+    print("small:", eager, vals, after, "big:", big_eager, big_vals)
+    for v in vals + after:
+        assert abs(v - eager) < 1e-5 * abs(eager)
+    for v in big_vals:
+        assert abs(v - big_eager) < 1e-5 * abs(big_eager)
 
 
 def test_changing_batch_shapes_share_one_workspace(train_model):
