@@ -1,10 +1,10 @@
 """Make the reference's dotted class paths import THIS package's implementations.
 
 ``install()`` registers ``captioning.models.{cnn_encoder, rnn_encoder, crnn_trm_encoder,
-transformer_decoder, transformer_model, transformer_encoder}`` in ``sys.modules`` so that the reference's own
+transformer_decoder, transformer_model, transformer_encoder, hf_wrapper}`` in ``sys.modules`` so that the reference's own
 ``train_util.init_model_from_config`` (train_util.py:63-94), ``run.py``, ``inference.py`` and ``demo.py``
 build the MI355X classes from unchanged YAML files.  If the reference package is importable its other
-modules (datasets, losses, utils) stay the reference's; only the five hot-path modules are replaced.
+modules (datasets, losses, utils) stay the reference's; only the hot-path modules are replaced.
 See INTEGRATION.md.
 """
 import importlib
@@ -18,6 +18,8 @@ HOT_MODULES = {
     "captioning.models.transformer_decoder": "audiocaption_amd.transformer_decoder",
     "captioning.models.transformer_model": "audiocaption_amd.transformer_model",
     "captioning.models.transformer_encoder": "audiocaption_amd.transformer_encoder",
+    # Effb2TrmConfig / Effb2TrmCaptioningModel / ContraEncoderKdWrapper (hf_wrapper.py:1071-1181)
+    "captioning.models.hf_wrapper": "audiocaption_amd.hf_wrapper",
 }
 # single classes patched into (or stubbed for) modules that also hold things outside the path
 HOT_CLASSES = {

@@ -71,11 +71,13 @@ class MelSpectrogramBuffers(nn.Module):
 
     def __init__(self, sample_rate, n_fft, f_min, f_max, n_mels, norm, mel_scale):
         super().__init__()
+        with torch.device("cpu"):   # real values even when the model is being built under a meta-device context (HF loaders)
+            window = torch.hann_window(n_fft, periodic=True)
+            fb = melscale_fbanks(n_fft // 2 + 1, f_min, f_max, n_mels, sample_rate, norm, mel_scale)
         self.spectrogram = _OptionalBuffers()
-        self.spectrogram.register_buffer("window", torch.hann_window(n_fft, periodic=True))
+        self.spectrogram.register_buffer("window", window)
         self.mel_scale = _OptionalBuffers()
-        self.mel_scale.register_buffer("fb", melscale_fbanks(n_fft // 2 + 1, f_min, f_max, n_mels, sample_rate, norm,
-                                                              mel_scale))
+        self.mel_scale.register_buffer("fb", fb)
 
     def key(self):
         w, fb = self.spectrogram.window, self.mel_scale.fb

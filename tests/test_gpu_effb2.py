@@ -226,3 +226,30 @@ def test_encoder_graph_survives_a_buffer_regrow(effb2_model):
                             ("f", f, want_s)):
         # (the squeeze-excite sums are float atomics, so two runs agree to rounding, not bit for bit)
         assert rel(f"graph vs eager {name}", got, want) < 1e-5, name
+
+
+def test_effb2_hf_class_on_the_published_layout(state_effb2):
+    """``Effb2TrmCaptioningModel`` (hf_wrapper.py:1144-1181) built from ``Effb2TrmConfig`` defaults, weights loaded from a
+    state dict in the published layout (``model.model.*`` + the distillation heads), called the way README.md:30-40 does:
+    ``model(audio, audio_length)`` -> CPU LongTensor, beam 3 by default - ids identical to the oracle."""
+    from audiocaption_amd import procedural as Pr
+    from audiocaption_amd.hf_wrapper import Effb2TrmCaptioningModel, Effb2TrmConfig
+    from oracle import effb2_path as E
+    ck = {"model.model." + k: v for k, v in state_effb2.items()}
+    g = torch.Generator().manual_seed(0)
+    ck.update({"model.stdnt_proj.weight": torch.randn(1024, 1408, generator=g), "model.stdnt_proj.bias": torch.zeros(1024),
+               "model.tchr_proj.weight": torch.randn(1024, 768, generator=g), "model.tchr_proj.bias": torch.zeros(1024),
+               "model.logit_scale": torch.tensor(2.66)})
+    model = Effb2TrmCaptioningModel(Effb2TrmConfig())
+    model.load_checkpoint(ck, strict=True)
+    model = model.to("cuda:0").eval()
+    assert model.device.type == "cuda" and model.config.sample_rate == 16000
+    L = 5 * 16000
+    wav = torch.from_numpy(Pr.synthetic_wav(3, L, sample_rate=16000, seed=8, varied=True))
+    lens = [L, 60000, 50000]
+    want = E.caption_forward(state_effb2, wav, lens, "beam", beam_size=3, max_length=20)
+    seq = model(wav, lens)                                   # CPU tensor in, moved by the wrapper (hf_wrapper.py:1170)
+    assert seq.device.type == "cpu" and seq.dtype == torch.int64 and seq.shape == (3, 20)
+    assert torch.equal(seq, want["seq"])
+    want_g = E.caption_forward(state_effb2, wav, lens, "greedy", max_length=10)
+    assert torch.equal(model(audio=wav, audio_length=torch.tensor(lens), sample_method="greedy", max_length=10), want_g["seq"])
