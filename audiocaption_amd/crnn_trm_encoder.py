@@ -23,6 +23,8 @@ def _accepts_skip_fc(cnn):
 def _run_cnn(cnn, skip_fc, input_dict):
     out = cnn(input_dict, skip_fc=True) if skip_fc else cnn(input_dict)
     res = {"attn": out["attn_emb"], "attn_len": out["attn_emb_len"]}
+    if "gru_algo" in input_dict:
+        res["gru_algo"] = input_dict["gru_algo"]
     return res, out.get("f16_overflow")
 
 

@@ -520,7 +520,7 @@ __device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {
 // so vertically adjacent pixels are adjacent registers and horizontally adjacent ones are the same register of the
 // neighbouring m-tile: 2x2 pooling and the mean over the two mel columns stay in registers.  fp16 outputs (f32 for
 // MEANW), WM = 1 (a wave owns all four m-tiles of the block).
-template <int BN, int MODE, int TC, int MW>
+template <int BN, int MODE, int TC, int MW, bool OUT32 = false>
 __device__ __forceinline__ void conv_epilogue_cols(const ConvParams& p, const f32x16 (&acc)[MW][1], int n_tile, int row0,
                                                    int col0, int wn, int lane) {
   const int half = lane >> 5;
@@ -535,7 +535,13 @@ __device__ __forceinline__ void conv_epilogue_cols(const ConvParams& p, const f3
     float y[MW];
 #pragma unroll
     for (int m = 0; m < MW; ++m) y[m] = fmaxf(fmaf(acc[m][0][r], sc, sh), 0.f);
-    if (MODE == MODE_FULL) {
+    if (MODE == MODE_FULL && OUT32) {   // split-bf16 tier: f32 activations, 32 lanes store 128 contiguous bytes
+#pragma unroll
+      for (int m = 0; m < MW; ++m) {
+        const int gr = row0 + (m / TC) * 32 + row, gc = col0 + m % TC;
+        if (gr < p.rows_total) p.out[((size_t)gr * p.W + gc) * p.Cout + ch] = by_hp.mod(gr) < p.H ? y[m] : 0.f;
+      }
+    } else if (MODE == MODE_FULL) {
       // Lane pairs (channels 2j, 2j+1) trade values so that every lane stores ONE 4-byte word: the even lane both
       // channels of row r, the odd lane both channels of row r + 1 (r even: the rows are adjacent registers) - half the
       // store instructions of one 2-byte store per value.
@@ -587,7 +593,7 @@ __device__ __forceinline__ void conv_epilogue_cols(const ConvParams& p, const f3
             for (int dr = 0; dr < 2; ++dr) o += fmaxf(fmaf(acc[rg * TC + 2 * oc + dm][0][r + dr], sc, sh), 0.f);
           const size_t oi = ((size_t)orow * p.W_out + (col0 >> 1) + oc) * p.Cout + ch;
           o = valid ? 0.25f * o : 0.f;
-          if (p.out32) {
+          if (OUT32 || p.out32) {
             p.out[oi] = o;
           } else {
             guard.track(o);
@@ -597,7 +603,7 @@ __device__ __forceinline__ void conv_epilogue_cols(const ConvParams& p, const f3
       }
     }
   }
-  if (MODE != MODE_MEANW) guard.commit(p.ovf);
+  if (MODE != MODE_MEANW && !OUT32) guard.commit(p.ovf);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -900,7 +906,7 @@ __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(Conv
     }
     if (FUSE1) guard1.commit(p.ovf);
   }
-  if constexpr (COLT != 0) conv_epilogue_cols<BN, MODE, COLT, MW>(p, acc, n_tile, row0, col0, wn, lane);
+  if constexpr (COLT != 0) conv_epilogue_cols<BN, MODE, COLT, MW, PREC == 0>(p, acc, n_tile, row0, col0, wn, lane);
   else conv_epilogue<BN, MODE, MW, NTW, PREC == 1>(p, acc, n_tile, row0, col0, wm, wn, lane);
 }
 
@@ -1129,6 +1135,18 @@ static int conv_gw_dispatch(int prec, const float* in, const void* wfrag, const 
   p.map_mode = map_mode;
   hipStream_t s = (hipStream_t)stream;
   if (prec == 0) {
+    // The 2- and 4-column layers (blocks 5-6) as COLUMN tiles, like the fp16 tier: the taps that read the zero padding
+    // beside the image (a third / a sixth of all products) are skipped, and a wave walks four 32-row tiles per weight
+    // fragment (1x4 wave grid) instead of two
+    static const bool colt0 = getenv("AC_GW_NO_COLT0") == nullptr;
+    if (BN == 128 && colt0 && TC == 2) {
+      if (mode == MODE_FULL) return launch_conv_gw<128, MODE_FULL, 0, 1, 128, false, 9, 2>(p, s);
+      if (mode == MODE_MEANW) return launch_conv_gw<128, MODE_MEANW, 0, 1, 128, false, 9, 2>(p, s);
+    }
+    if (BN == 128 && colt0 && TC == 4) {
+      if (mode == MODE_FULL) return launch_conv_gw<128, MODE_FULL, 0, 1, 128, false, 9, 4>(p, s);
+      if (mode == MODE_POOL) return launch_conv_gw<128, MODE_POOL, 0, 1, 128, false, 9, 4>(p, s);
+    }
     if (BN == 128) {
       if (mode == MODE_FULL) return launch_conv_gw<128, MODE_FULL>(p, s);
       if (mode == MODE_POOL) return launch_conv_gw<128, MODE_POOL>(p, s);

@@ -296,6 +296,24 @@ def gru_layer(gx, whhT, bhh, lens_i32, B, T, hidden):
     return out
 
 
+def gru_layer_split(gx, whh, bhh, lens_i32, B, T, hidden, workspace=None):
+    """The recurrence with every (clip, direction) split over two CUs (W_hh fully register resident).  ``whh``: the
+    UNPACKED [2][3H][H] weights.  Returns (out, workspace); ``gru_split_error(workspace)`` is its sticky error word."""
+    lib = _lib.load()
+    need = lib.ac_gru_split_workspace_bytes(B)
+    if workspace is None or workspace.numel() * 8 < need or workspace.device != gx.device:
+        workspace = torch.zeros((need + 7) // 8, device=gx.device, dtype=torch.int64)
+    out = torch.empty(B, T, 2 * hidden, device=gx.device, dtype=torch.float32)
+    check(lib.ac_gru_layer_split(ptr(gx), ptr(whh), ptr(bhh), ptr(lens_i32), ptr(out), ptr(workspace), B, T, hidden,
+                                 stream()), "ac_gru_layer_split")
+    return out, workspace
+
+
+def gru_split_error(workspace, B):
+    """The error word of a split-GRU workspace as a 1-element int32 view (device tensor; reading it synchronises)."""
+    return workspace.view(torch.int32)[:1]
+
+
 def mean_with_lens(x, lens_i32, add_max=False):
     lib = _lib.load()
     B, T, C = x.shape

@@ -7,6 +7,8 @@
 for the input projections of all time steps (csrc/gemm.hip) plus the persistent recurrence kernel of
 csrc/gru.hip, which reproduces pack_padded_sequence semantics (model_util.py:10-27) from the lengths.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -37,6 +39,14 @@ class RnnEncoder(nn.Module):
                               bidirectional=True, dropout=self.dropout, batch_first=True)
         self._packed = None
         self._packed_key = None
+        # "split" (default): every (clip, direction) runs on two CUs with W_hh register resident (csrc/gru.hip
+        # gru_layer_split_kernel); "single": one workgroup per (clip, direction), 44 % of W_hh re-streamed per step
+        # "auto" (default): "split" for a blocking call, "single" when the caller says the chip is shared with another
+        # stream's work (``forward_async`` passes gru_algo="single": 4 x 64 split workgroups need every CU at once and
+        # lose more to the decode chain of the previous batch than they gain - 6.04 vs 5.81 ms per step - while the
+        # blocking call gains 0.2 ms).  The two kernels differ in summation order only (~2e-6).
+        self.gru_algo = os.environ.get("AUDIOCAPTION_GRU_ALGO", "auto")
+        self._split_ws = None
 
     def _pack(self):
         ps = dict(self.network.named_parameters())
@@ -52,7 +62,7 @@ class RnnEncoder(nn.Module):
                 whh = torch.stack([ps["weight_hh" + f], ps["weight_hh" + r]], 0).float().contiguous()
                 whhT = K.gru_pack_whh(whh, self.hidden_size)   # [2][H/4][3H][4]
                 bhh = torch.stack([ps["bias_hh" + f], ps["bias_hh" + r]], 0).float().contiguous()
-                layers.append((w_ih, b_ih, whhT, bhh))
+                layers.append((w_ih, b_ih, whhT, bhh, whh))
         self._packed, self._packed_key = layers, key
         return layers
 
@@ -68,12 +78,23 @@ class RnnEncoder(nn.Module):
             raise ValueError("attn_len must lie in [1, attn.size(1)]")
         lens_dev = K.upload(lens, x.device, torch.int32)
         h = K.f32c(x).reshape(B * T, -1)
-        for (w_ih, b_ih, whhT, bhh) in self._pack():
+        algo = self.gru_algo if self.gru_algo != "auto" else input_dict.get("gru_algo", "split")
+        split = algo == "split"
+        for (w_ih, b_ih, whhT, bhh, whh) in self._pack():
             gx = K.linear(h, w_ih, b_ih)                       # (B*T, 2*3H): all steps, both directions
-            h = K.gru_layer(gx, whhT, bhh, lens_dev, B, T, self.hidden_size).reshape(B * T, -1)
+            if split:
+                h, self._split_ws = K.gru_layer_split(gx, whh, bhh, lens_dev, B, T, self.hidden_size, self._split_ws)
+                h = h.reshape(B * T, -1)
+            else:
+                h = K.gru_layer(gx, whhT, bhh, lens_dev, B, T, self.hidden_size).reshape(B * T, -1)
         out = h.reshape(B, T, self.embed_dim)
         t_out = int(lens.max())                                 # pad_packed_sequence truncates to max(len)
         if t_out < T:
             out = out[:, :t_out].contiguous()
         fc_emb = K.mean_with_lens(out, lens_dev)
-        return {"attn_emb": out, "fc_emb": fc_emb, "attn_emb_len": lens}
+        res = {"attn_emb": out, "fc_emb": fc_emb, "attn_emb_len": lens}
+        if split:
+            # sticky device word: non-zero if a workgroup's partner never started (the output is then invalid);
+            # TransformerModel reads it where it synchronises anyway and raises
+            res["gru_error"] = K.gru_split_error(self._split_ws, B)
+        return res

@@ -66,10 +66,21 @@ class CaptionModel(nn.Module, CaptionMetaMixin):
             return train_forward(self, input_dict)
         encoder_output_dict = self.encoder(input_dict)
         output = self.forward_decoder(input_dict, encoder_output_dict)
-        flag = output.get("f16_overflow")
-        if flag is not None and int(flag.item()) != 0:
-            return self._rerun_wide(input_dict)
+        flags = _device_flags(output)
+        if flags is not None:
+            redo = self._check_flags(flags.cpu(), input_dict)
+            if redo is not None:
+                return redo
         return output
+
+    def _check_flags(self, host_flags, input_dict):
+        """host_flags = [fp16 overflow of the conv tier, split-GRU partner timeout] read back with the results."""
+        if int(host_flags[1]) != 0:
+            raise _lib.HipLibraryError("split GRU kernel: a workgroup's partner never started (GPU shared with another "
+                                       "process?); set AUDIOCAPTION_GRU_ALGO=single")
+        if int(host_flags[0]) != 0:
+            return self._rerun_wide(input_dict)
+        return None
 
     def _rerun_wide(self, input_dict):
         """An activation of the fp16-activation conv tier left the fp16 range (the kernels raise ``f16_overflow``
@@ -108,6 +119,16 @@ class CaptionModel(nn.Module, CaptionMetaMixin):
             "(dbs / gumbel / top-k / top-p sampling are out of scope, SURVEY.md §2.1 row 7)")
 
 
+def _device_flags(enc):
+    """The encoder's device-side status words as one int32[2] tensor (None when the encoder raises none)."""
+    a, b = enc.get("f16_overflow"), enc.get("gru_error")
+    if a is None and b is None:
+        return None
+    dev = (a if a is not None else b).device
+    z = torch.zeros(1, device=dev, dtype=torch.int32)
+    return torch.cat([a.view(1).to(torch.int32) if a is not None else z, b.view(1).to(torch.int32) if b is not None else z])
+
+
 def _make_streams(dev):
     """(encoder stream, decode stream) of the throughput mode.  AUDIOCAPTION_STREAM_PRIORITIES="enc,dec" sets their HIP
     priorities (lower = more urgent; default 0,0)."""
@@ -139,12 +160,14 @@ class PendingCaption:
         out = dict(self._out)
         out["seq"] = self._seq.clone()
         out["sampled_logprob"] = self._lp.clone()
-        overflow = self._flag is not None and int(self._flag[0]) != 0
+        flags = self._flag.clone() if self._flag is not None else None
         if self._release is not None:  # hand the pinned staging buffers back to the pool
             self._release()
             self._release = None
-        if overflow:                   # fp16 range exceeded in the conv tier: blocking re-run on f32 activations
-            out = self._model._rerun_wide(self._input)
+        if flags is not None:          # fp16 range exceeded in the conv tier: blocking re-run on f32 activations
+            redo = self._model._check_flags(flags, self._input)
+            if redo is not None:
+                out = redo
         self._result = out
         self._seq = self._lp = None
         return dict(out)
@@ -184,7 +207,8 @@ class TransformerModel(CaptionModel):
         cur = torch.cuda.current_stream(dev)
         enc_s.wait_stream(cur)  # inputs produced on the caller's stream
         with torch.cuda.stream(enc_s):
-            enc = self.encoder(input_dict)
+            # the chip is shared with the previous batch's decode chain: the one-workgroup GRU recurrence (see RnnEncoder)
+            enc = self.encoder(dict(input_dict, gru_algo=input_dict.get("gru_algo", "single")))
             enc_done = torch.cuda.Event()
             enc_done.record(enc_s)
         max_length = int(input_dict.get("max_length", self.max_length))
@@ -215,7 +239,7 @@ class TransformerModel(CaptionModel):
         enc_s, dec_s = self._streams
         enc_s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(enc_s):
-            enc = self.encoder(input_dict)
+            enc = self.encoder(dict(input_dict, gru_algo=input_dict.get("gru_algo", "single")))
             enc_done = torch.cuda.Event()
             enc_done.record(enc_s)
         pending = PendingCaption(self)
@@ -233,9 +257,11 @@ class TransformerModel(CaptionModel):
                     t.record_stream(dec_s)
             out = self.forward_decoder(input_dict, enc)
             dec_s.synchronize()
-            flag = out.get("f16_overflow")
-            if flag is not None and int(flag.item()) != 0:
-                out = self._rerun_wide(input_dict)
+            flags = _device_flags(out)
+            if flags is not None:
+                redo = self._check_flags(flags.cpu(), input_dict)
+                if redo is not None:
+                    out = redo
         pending._result = out
 
     def _flush_held(self):
@@ -269,12 +295,13 @@ class TransformerModel(CaptionModel):
                 if not pool:
                     pool.append((torch.empty(B, max_length, dtype=torch.int64).pin_memory(),
                                  torch.empty(B, max_length, dtype=torch.float32).pin_memory(),
-                                 torch.zeros(1, dtype=torch.int32).pin_memory()))
+                                 torch.zeros(2, dtype=torch.int32).pin_memory()))
                 host_seq, host_lp, host_flag = pool.pop()
                 host_seq.copy_(res["seq"][rows], non_blocking=True)
                 host_lp.copy_(res["sampled_logprob"][rows], non_blocking=True)
-                if enc.get("f16_overflow") is not None:
-                    host_flag.copy_(enc["f16_overflow"], non_blocking=True)
+                dflags = _device_flags(enc)
+                if dflags is not None:
+                    host_flag.copy_(dflags, non_blocking=True)
                 else:
                     host_flag.zero_()
                 if len(items) == 1:

@@ -238,7 +238,10 @@ def test_conv3x3_first(K):
     assert _report("conv_first", out, _to_rows(y, Hp)) < 1e-5
 
 
-def test_gru_layer_and_pooling_vs_oracle(K, state4981):
+@pytest.mark.parametrize("gru_algo", ["split", "single"])
+def test_gru_layer_and_pooling_vs_oracle(K, state4981, gru_algo):
+    """Both recurrence kernels: "split" (default: a (clip, direction) on two CUs, W_hh register resident, hidden halves
+    traded through L2 every step) and "single" (one workgroup, 44 % of W_hh re-streamed per step)."""
     from oracle import cpu_path as O
     import audiocaption_amd as A
     g = torch.Generator().manual_seed(11)
@@ -248,7 +251,10 @@ def test_gru_layer_and_pooling_vs_oracle(K, state4981):
     rnn = A.RnnEncoder(-1, 2048, 2048, bidirectional=True, hidden_size=256, dropout=0.5, num_layers=3)
     rnn.load_state_dict({k[len("encoder.rnn."):]: v for k, v in state4981.items() if k.startswith("encoder.rnn.")})
     rnn = rnn.eval().cuda()
+    rnn.gru_algo = gru_algo
     got = rnn({"attn": x.cuda(), "attn_len": torch.tensor(lens)})
+    if gru_algo == "split":
+        assert int(got["gru_error"].item()) == 0
     assert _report("gru attn_emb", got["attn_emb"], want["attn_emb"]) < 2e-5
     assert _report("gru fc_emb", got["fc_emb"], want["fc_emb"]) < 2e-5
     assert torch.equal(got["attn_emb_len"], torch.tensor(lens))
@@ -256,3 +262,31 @@ def test_gru_layer_and_pooling_vs_oracle(K, state4981):
     got2 = rnn({"attn": x.cuda(), "attn_len": torch.tensor([9, 20, 7, 1, 12])})
     assert got2["attn_emb"].shape == (5, 20, 512)
     assert float(got2["attn_emb"][0, 9:].abs().max()) == 0.0
+
+
+def test_gru_split_kernel_under_uneven_load(K):
+    """The split recurrence trades data between workgroups inside one launch (8-byte {tag, value} granules, agent-scope
+    relaxed atomics).  Such hand-offs have to be tested with the consumer's L1 warm and the chip unevenly loaded: a
+    second stream streams memory while 130 clips x 93 steps (520 workgroups: more than the 256 CUs hold, so partners
+    start at different times) run, five times over the same workspace; every word against the single-workgroup kernel."""
+    g = torch.Generator().manual_seed(5)
+    B, T, Hh = 130, 93, 256
+    gx = torch.randn(B * T, 6 * Hh, generator=g).cuda()
+    whh = (torch.randn(2, 3 * Hh, Hh, generator=g) / 16).cuda()
+    bhh = torch.randn(2, 3 * Hh, generator=g).cuda()
+    lens = torch.randint(1, T + 1, (B,), generator=g).to(torch.int32).cuda()
+    want = K.gru_layer(gx, K.gru_pack_whh(whh, Hh), bhh, lens, B, T, Hh)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    junk = torch.randn(64 << 20, device="cuda")
+    ws = None
+    for rep in range(5):
+        with torch.cuda.stream(side):
+            for _ in range(6):
+                junk.mul_(1.0001)
+        got, ws = K.gru_layer_split(gx, whh, bhh, lens, B, T, Hh, ws)
+        torch.cuda.synchronize()
+        assert int(K.gru_split_error(ws, B).item()) == 0
+        assert float((got - want).abs().max()) < 1e-5, rep
+    for b in range(B):   # zeros at the padded steps
+        assert float(got[b, int(lens[b]):].abs().max() if int(lens[b]) < T else 0.0) == 0.0

@@ -21,3 +21,19 @@ for _ in range(20):
     out = K.gru_layer(gx, pk, bhh, lens, B, T, Hh)
 b.record(); torch.cuda.synchronize()
 print(f"gru_layer {a.elapsed_time(b) / 20 * 1e3:.1f} us; checksum {float(out.double().sum()):.9f} absmax {float(out.abs().max()):.6f}")
+
+out2, ws = K.gru_layer_split(gx, whh, bhh, lens, B, T, Hh)
+torch.cuda.synchronize()
+a.record()
+for _ in range(20):
+    out2, ws = K.gru_layer_split(gx, whh, bhh, lens, B, T, Hh, ws)
+b.record(); torch.cuda.synchronize()
+print(f"gru_layer_split {a.elapsed_time(b) / 20 * 1e3:.1f} us; max|diff| vs single-workgroup kernel "
+      f"{float((out2 - out).abs().max()):.2e}; error word {int(K.gru_split_error(ws, B).item())}")
+for Bx, Tx in ((3, 7), (130, 93)):
+    gxx = torch.randn(Bx * Tx, 6 * Hh, device=dev)
+    lx = torch.randint(1, Tx + 1, (Bx,), device=dev, dtype=torch.int32)
+    o1 = K.gru_layer(gxx, pk, bhh, lx, Bx, Tx, Hh)
+    o2, w2 = K.gru_layer_split(gxx, whh, bhh, lx, Bx, Tx, Hh)
+    torch.cuda.synchronize()
+    print(f"B={Bx} T={Tx}: max|diff| {float((o2 - o1).abs().max()):.2e} error {int(K.gru_split_error(w2, Bx).item())}")
