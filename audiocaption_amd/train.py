@@ -90,6 +90,9 @@ class FlatParams:
                 p.data = v
                 self.grad_views.append(self.grad[o:o + p.numel()].view(p.shape))
         self.index = {k: i for i, k in enumerate(names)}
+        # the GRU tensors come first, the decoder's after them: [0, decoder_offset) is final only after the GRU's
+        # backward through time, [decoder_offset, total) as soon as the decoder's backward is done
+        self.decoder_offset = next((o for k, o in zip(names, self.offsets) if k.startswith("decoder.")), off)
         # tied parameters (``tie_weights=True``: decoder.classifier.weight IS decoder.word_embedding.weight) appear once
         # in named_parameters(); the other name resolves to the same slot, so both uses accumulate into one gradient
         by_id = {id(p): i for i, p in enumerate(self.params)}
@@ -113,17 +116,24 @@ class FlatParams:
             p.grad = v
 
 
-def allreduce_flat_gradients(flat_grad, process_group=None):
-    """Sum the flat gradient buffer over the ranks (ONE collective for all 10.7 M gradients, the reference's DDP
-    all-reduce run_ddp.py:98-108) and return the world size; the division by it is folded into the clip coefficient
-    (``clip_grad_norm_(..., grad_div=world)``).  No-op without an initialised process group."""
+def dist_world_size(process_group=None):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return 1
-    world = dist.get_world_size(process_group)
+    return dist.get_world_size(process_group)
+
+
+def allreduce_flat_gradients(flat_grad, process_group=None, async_op=False):
+    """Sum (a slice of) the flat gradient buffer over the ranks - the reference's DDP gradient all-reduce
+    (run_ddp.py:98-108) as ONE collective per slice instead of per-parameter buckets - and return the world size (or,
+    with ``async_op``, the work handle, None for a single rank); the division by the world size is folded into the clip
+    coefficient (``clip_grad_norm_(..., grad_div=world)``).  No-op without an initialised process group."""
+    import torch.distributed as dist
+    world = dist_world_size(process_group)
+    work = None
     if world > 1:
-        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=process_group)
-    return world
+        work = dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=process_group, async_op=async_op)
+    return work if async_op else world
 
 
 class _Ws:
@@ -517,7 +527,12 @@ class TrainEngine:
             dlogit = dlogit.float()
         self._launch_backward(sv, dlogit.data_ptr())
 
-    def _launch_backward(self, sv, dl):
+    def _launch_backward(self, sv, dl, part="all"):
+        """``part``: "all", or the two halves of it - "head" (classifier, decoder layers, audio memory, attn_proj: every
+        decoder gradient is final after it, and d(loss)/d(GRU output) is in the workspace) and "gru" (the backward through
+        time of the three GRU layers) - so that the all-reduce of the decoder's gradients can run under the GRU's."""
+        if part == "gru":
+            return self._launch_backward_gru(sv)
         model, lib, fp = self.model, self.lib, self.flat
         enc, dec = model.encoder, model.decoder
         s = _lib.stream()
@@ -626,6 +641,20 @@ class TrainEngine:
         rows_g = B * Tq
         dout = ws.f("gru_dout", rows_g, A)
         self._lin_dx(s, da, fp.p(dp + "attn_proj.0.weight"), dout, rows_m, D, A)
+        if part == "all":
+            self._launch_backward_gru(sv)
+
+    def _launch_backward_gru(self, sv):
+        model, lib, fp = self.model, self.lib, self.flat
+        enc = model.encoder
+        s = _lib.stream()
+        self._phase = "backward"
+        ws = sv["ws"]
+        N, Tq = sv["N"], sv["Tq"]
+        B, p_rnn, A = N, sv["p_rnn"], 2 * H
+        self._seed_ptr = sv["small"].data_ptr()
+        rows_g = B * Tq
+        dout = ws.f("gru_dout", rows_g, A)
         lens_p = sv["small"].data_ptr() + 8
         nl = enc.rnn.num_layers
         dgx, dgh, hprev = ws.f("dgx", rows_g, 6 * H), ws.f("dgh", rows_g, 6 * H), ws.f("hprev", rows_g, 2 * H)
@@ -648,8 +677,11 @@ class TrainEngine:
                 self._lin_dx(s, dgx, fp.p(f"{pre}weight_ih_l{l}"), dout, rows_g, 6 * H, g["in_dim"])
 
     # ---- fast path: forward + loss + backward (+ gradient all-reduce) + clip + Adam -----------------------
-    def _launch_step_body(self, st, smoothing):
-        """forward, label-smoothing loss (mean over the valid target tokens, counted on the device) and backward."""
+    def _launch_step_body(self, st, smoothing, part="all"):
+        """forward, label-smoothing loss (mean over the valid target tokens, counted on the device) and backward.
+        ``part`` "head" stops after the decoder's backward, "gru" is the rest (see ``_launch_backward``)."""
+        if part == "gru":
+            return self._launch_backward(st, None, "gru")
         self._launch_forward(st)
         N, T, Tc, V = st["N"], st["T"], st["Tc"], st["V"]
         ws = st["ws"]
@@ -660,7 +692,7 @@ class TrainEngine:
         check(self.lib.ac_label_smoothing_loss(logit, st["cap"].data_ptr() + 8, Tc, tgt_len, N, T, V, float(smoothing), 0.0,
                                                row_loss, loss, dlogit, 0.0, None, _lib.stream()),
               "ac_label_smoothing_loss")
-        self._launch_backward(st, dlogit)
+        self._launch_backward(st, dlogit, part)
 
     def step(self, input_dict, optimizer, smoothing=0.1, max_grad_norm=1.0, process_group=None, use_graph=True):
         """One training iteration (run.py:106-126) without leaving the HIP path; returns the loss as a device scalar.
@@ -669,42 +701,56 @@ class TrainEngine:
         batch shape they are captured ONCE into a HIP graph over static buffers (second iteration of that shape) and
         replayed; the per-iteration data - audio, captions, lengths, the scheduled-sampling draws and the dropout
         seed - are copied into those buffers first.  Gradients land in the flat buffer (= the parameters' ``.grad``);
-        with ``torch.distributed`` initialised they are summed over the ranks in ONE all-reduce and the division by
-        the world size is folded into the clip coefficient; clip + Adam are three launches on the flat buffers."""
+        with ``torch.distributed`` initialised they are summed over the ranks by two all-reduces (the decoder's slice
+        under the GRU backward, then the GRU's) and the division by the world size is folded into the clip coefficient;
+        clip + Adam are three launches on the flat buffers."""
         from .optim import FusedAdam, clip_grad_norm_
         if "cap_len" not in input_dict:
             raise KeyError("cap_len")
         st = self._prepare(input_dict)
         st["steps"] += 1
-        if not use_graph:
-            self._launch_step_body(st, smoothing)
-        elif st["graph"] is None and st["steps"] < 2:
-            self._launch_step_body(st, smoothing)          # first iteration of this shape: eager (also the warm-up)
-        else:
-            # A captured graph holds RAW ADDRESSES: the flat parameter storage, the shared workspace, and - through the
-            # frozen Cnn14 - its packed weights and its activation buffers, which are shared by all batch shapes and
-            # re-allocated when a larger one arrives.  All of them are part of the key, and the state keeps references
-            # to what its graph addresses, so a stale graph is neither replayed nor left pointing at recycled memory.
-            cnn = getattr(self.model.encoder, "cnn", None)
-            cnn_algo = cnn.effective_algo(None, True) if cnn is not None and hasattr(cnn, "_pack") else None
-            if cnn_algo is not None:
-                # weight repacks (host uploads, float64 transforms of the Winograd tier) must not land inside a
-                # capture: pack the frozen Cnn14 for the tier the train-mode forward uses now (cached: a no-op
-                # unless the Cnn14's own tensors changed)
-                cnn._pack(st["cap"].device, cnn_algo)
-            ident, refs = cnn.capture_token(cnn_algo) if cnn_algo is not None else (None, None)
-            gkey = (smoothing, _lib.param_generation_flat(self), st["ws"].gen, ident)
-            if st["graph"] is None or st["graph_key"] != gkey:
-                torch.cuda.synchronize(st["cap"].device)
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    self._launch_step_body(st, smoothing)
+        world = dist_world_size(process_group)
+        # Several ranks: the step runs as TWO parts - everything up to the end of the decoder's backward, then the GRU's
+        # backward through time - and the all-reduce of the decoder's gradients (45 % of the 42.8 MB, final after part
+        # one) is issued between them, so that it travels under the GRU backward; the GRU's gradients follow.
+        parts = ("head", "gru") if world > 1 else ("all",)
+        works = []
+        for pi, part in enumerate(parts):
+            gname = "graph" if part in ("all", "head") else "graph_gru"
+            if not use_graph or (st.get("graph") is None and st["steps"] < 2):
+                self._launch_step_body(st, smoothing, part)   # first iteration of this shape: eager (also the warm-up)
+            else:
+                # A captured graph holds RAW ADDRESSES: the flat parameter storage, the shared workspace, and - through
+                # the frozen Cnn14 - its packed weights and its activation buffers, which are shared by all batch shapes
+                # and re-allocated when a larger one arrives.  All of them are part of the key, and the state keeps
+                # references to what its graph addresses, so a stale graph is neither replayed nor left pointing at
+                # recycled memory.
+                cnn = getattr(self.model.encoder, "cnn", None)
+                cnn_algo = cnn.effective_algo(None, True) if cnn is not None and hasattr(cnn, "_pack") else None
+                if cnn_algo is not None:
+                    # weight repacks (host uploads, float64 transforms of the Winograd tier) must not land inside a
+                    # capture: pack the frozen Cnn14 for the tier the train-mode forward uses now (cached: a no-op
+                    # unless the Cnn14's own tensors changed)
+                    cnn._pack(st["cap"].device, cnn_algo)
                 ident, refs = cnn.capture_token(cnn_algo) if cnn_algo is not None else (None, None)
-                st["graph"], st["graph_hold"] = graph, refs
-                st["graph_key"] = (smoothing, _lib.param_generation_flat(self), st["ws"].gen, ident)
-            st["graph"].replay()
+                gkey = (smoothing, _lib.param_generation_flat(self), st["ws"].gen, ident, parts)
+                if st.get(gname) is None or st.get(gname + "_key") != gkey:
+                    torch.cuda.synchronize(st["cap"].device)
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        self._launch_step_body(st, smoothing, part)
+                    ident, refs = cnn.capture_token(cnn_algo) if cnn_algo is not None else (None, None)
+                    st[gname], st[gname + "_hold"] = graph, refs
+                    st[gname + "_key"] = (smoothing, _lib.param_generation_flat(self), st["ws"].gen, ident, parts)
+                st[gname].replay()
+            if world > 1:
+                o = self.flat.decoder_offset
+                piece = self.flat.grad[o:] if part == "head" else self.flat.grad[:o]
+                works.append(allreduce_flat_gradients(piece, process_group, async_op=True))
+        for w_ in works:
+            if w_ is not None:
+                w_.wait()
         self.flat.attach_grads()
-        world = allreduce_flat_gradients(self.flat.grad, process_group)
         clip = clip_grad_norm_(self.flat.params, max_grad_norm, grad_div=float(world), scale_now=False)
         if isinstance(optimizer, FusedAdam):
             optimizer.step(clip=clip)
