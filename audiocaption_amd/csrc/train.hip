@@ -352,6 +352,195 @@ __global__ __launch_bounds__(256) void gemm_kk_kernel(GemmP p) {
   }
 }
 
+// =========================================================================================================
+// Split-bf16 GEMM ("bf16x3"): the same contract as gemm_general_kernel - C = epilogue(sum_k A(m,k) B(k,n)), each operand
+// contiguous along k OR along its row dimension - at 5x the f32 matrix rate.  Every f32 operand is split when it is
+// staged into LDS, x = hi + lo (bf16 each, RNE; 16 significant bits together), and a product is three bf16 MFMAs
+// (lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_bf16, f32 accumulation): 2^-16 relative operand error instead of exact
+// f32, the arithmetic of the split-bf16 conv tier.  It serves the backward GEMMs of the training step (dY W, dY^T X
+// with split-K atomics; 7 392 rows) and the teacher-forced forward GEMMs, which is where the decoder's matrix work is.
+//
+// Workgroup tile (64 TM) x (64 TN), 2x2 waves, each wave TM x TN MFMA tiles of 32x32; K chunks of 32.  LDS holds, per
+// operand, a hi and a lo plane of [row][32 k + 8 pad] bf16 (80-byte rows: a lane's fragment - 8 consecutive k of its
+// row - is one 16-byte read).  Waves 0-1 stage A, waves 2-3 stage B; a thread's share of the NEXT chunk (8 float4) is
+// requested right after the barrier and lands while the 24 (TM = TN = 2) MFMAs of the current chunk run.
+//   operand contiguous along k     : item = (row, 8-k group): two 16-byte loads, one 16-byte LDS store per plane
+//   operand contiguous along rows  : item = (4 rows, 8-k group): eight 16-byte loads (4 rows at one k each), transposed
+//                                    in registers, one 16-byte LDS store per row and plane
+// =========================================================================================================
+typedef __bf16 gb_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned gb_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int GB_ROW = 40;   // bf16 elements per LDS row
+
+__device__ __forceinline__ unsigned gb_cvt_pk_bf16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+// 8 floats -> 8 bf16 hi (4 dwords) + 8 bf16 lo
+__device__ __forceinline__ void gb_split8(const float (&x)[8], gb_u32x4& hi, gb_u32x4& lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned h = gb_cvt_pk_bf16(x[2 * i], x[2 * i + 1]);
+    const float h0 = __builtin_bit_cast(float, h << 16), h1 = __builtin_bit_cast(float, h & 0xffff0000u);
+    hi[i] = h;
+    lo[i] = gb_cvt_pk_bf16(x[2 * i] - h0, x[2 * i + 1] - h1);
+  }
+}
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmP p) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int ROWS = BM > BN ? BM : BN;          // staging threads are laid out for the larger operand tile
+  __shared__ __attribute__((aligned(16))) __bf16 sA[2][BM * GB_ROW];   // [hi, lo]
+  __shared__ __attribute__((aligned(16))) __bf16 sB[2][BN * GB_ROW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  int kbeg = 0, kend = p.K;
+  if (p.splitk > 1) {
+    const int per = ((p.K + p.splitk - 1) / p.splitk + 31) / 32 * 32;
+    kbeg = blockIdx.z * per;
+    kend = min(p.K, kbeg + per);
+    if (kbeg >= kend) return;
+  }
+  // ---- staging role of this thread: operand (A: waves 0-1, B: waves 2-3), layout, items ----
+  const bool isB = tid >= 128;
+  const int u = tid & 127;
+  const float* base = isB ? p.B : p.A;
+  const long s_row = isB ? p.sbn : p.sam, s_k = isB ? p.sbk : p.sak;
+  const int r0 = isB ? n0 : m0, rmax = isB ? p.N : p.M, rows = isB ? BN : BM;
+  const bool kfast = s_k == 1;
+  __bf16* dst_hi = isB ? sB[0] : sA[0];
+  __bf16* dst_lo = isB ? sB[1] : sA[1];
+  (void)ROWS;
+  float pre[8][4];   // scalar registers only (every index below is a compile-time constant after unrolling)
+  auto ld4 = [&](float (&d)[4], const float* src, bool ok) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) v = *(const float4*)src;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  };
+  auto request = [&](int k0) {
+    if (kfast) {
+      // items (row, kg): idx = u + 128 j, row = idx / 4, kg = idx % 4; rows / 32 items per thread
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int idx = u + 128 * j, row = idx >> 2, kg = idx & 3;
+        const bool ok = row < rows && r0 + row < rmax;
+        const int gr = min(r0 + row, rmax - 1), gk = k0 + kg * 8;
+        const float* src = base + (long)gr * s_row;
+        ld4(pre[2 * j], src + min(gk, kend - 4), ok && gk < kend);
+        ld4(pre[2 * j + 1], src + min(gk + 4, kend - 4), ok && gk + 4 < kend);
+      }
+    } else {
+      // item (4 rows, kg): rg = u % (rows / 4) (consecutive lanes -> consecutive rows), kg = u / (rows / 4): one item per
+      // thread for a 128-row tile, the threads u < 64 for a 64-row tile
+      const int rgs = rows >> 2;
+      const int rg = u % rgs, kg = u / rgs;
+      const int grow = r0 + rg * 4;
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const int gk = k0 + kg * 8 + kk;
+        const bool in = kg < 4 && gk < kend && grow < rmax;       // rmax % 4 == 0 for row-contiguous operands (launcher)
+        ld4(pre[kk], base + (long)min(gk, kend - 1) * s_k + min(grow, rmax - 4), in);
+      }
+    }
+  };
+  auto commit = [&]() {
+    if (kfast) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int idx = u + 128 * j, row = idx >> 2, kg = idx & 3;
+        if (row >= rows) continue;
+        const float x[8] = {pre[2 * j][0], pre[2 * j][1], pre[2 * j][2], pre[2 * j][3],
+                            pre[2 * j + 1][0], pre[2 * j + 1][1], pre[2 * j + 1][2], pre[2 * j + 1][3]};
+        gb_u32x4 hi, lo;
+        gb_split8(x, hi, lo);
+        *(gb_u32x4*)(dst_hi + row * GB_ROW + kg * 8) = hi;
+        *(gb_u32x4*)(dst_lo + row * GB_ROW + kg * 8) = lo;
+      }
+    } else {
+      const int rgs = rows >> 2;
+      const int rg = u % rgs, kg = u / rgs;
+      if (kg < 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float x[8] = {pre[0][i], pre[1][i], pre[2][i], pre[3][i], pre[4][i], pre[5][i], pre[6][i], pre[7][i]};
+          gb_u32x4 hi, lo;
+          gb_split8(x, hi, lo);
+          *(gb_u32x4*)(dst_hi + (rg * 4 + i) * GB_ROW + kg * 8) = hi;
+          *(gb_u32x4*)(dst_lo + (rg * 4 + i) * GB_ROW + kg * 8) = lo;
+        }
+      }
+    }
+  };
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  const int frag = (lane & 31) * GB_ROW + 8 * (lane >> 5);
+  const int nchunks = (kend - kbeg + 31) / 32;
+  request(kbeg);
+  for (int c = 0; c < nchunks; ++c) {
+    if (c > 0) lds_barrier();          // every wave is done with the previous chunk's tiles
+    commit();
+    lds_barrier();
+    if (c + 1 < nchunks) request(kbeg + (c + 1) * 32);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      gb_bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        ah[a] = *(const gb_bf16x8*)(sA[0] + ((wm * TM + a) * 32) * GB_ROW + frag + ks * 16);
+        al[a] = *(const gb_bf16x8*)(sA[1] + ((wm * TM + a) * 32) * GB_ROW + frag + ks * 16);
+      }
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        bh[b] = *(const gb_bf16x8*)(sB[0] + ((wn * TN + b) * 32) * GB_ROW + frag + ks * 16);
+        bl[b] = *(const gb_bf16x8*)(sB[1] + ((wn * TN + b) * 32) * GB_ROW + frag + ks * 16);
+      }
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+        }
+    }
+  }
+  // ---- epilogue: the same as gemm_general_kernel's ----
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const int n = n0 + (wn * TN + b) * 32 + (lane & 31);
+    if (n >= p.N) continue;
+    const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m >= p.M) continue;
+        float* cp = p.C + (long)m * p.ldc + n;
+        if (p.splitk > 1) {
+          atomicAdd(cp, acc[a][b][r]);
+        } else {
+          float v = acc[a][b][r] + bias;
+          if (p.relu == 1) v = fmaxf(v, 0.f);
+          else if (p.relu == 2) v = v / (1.0f + expf(-v));
+          else if (p.relu == 3) v = 1.0f / (1.0f + expf(-v));
+          v *= p.drop.mask((uint64_t)(p.row0 + m) * (uint64_t)p.N + (uint64_t)n);
+          if (p.beta != 0.f) v += p.beta * *cp;
+          *cp = v;
+        }
+      }
+    }
+  }
+}
+
 // ---- elementwise dropout (GRU inter-layer, Cnn14 block outputs): y = x * mask(idx0 + i) -----------------------
 __global__ void dropout_kernel(const float* x, float* y, long n, Drop d, long idx0) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
@@ -1104,6 +1293,46 @@ int ac_gemm(const float* A, long sam, long sak, const float* B, long sbk, long s
                        (hipStream_t)stream, p);
   else
     hipLaunchKernelGGL(gemm_general_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+  return ac_check_launch();
+}
+
+// Whether the split-bf16 kernel can take an operand: contiguous along k or along its row dimension, the other stride a
+// multiple of 4 floats, 16-byte aligned base; k-contiguous operands need K % 4 == 0, row-contiguous ones rows % 4 == 0.
+static bool gb_operand_ok(const float* base, long s_row, long s_k, int rows, int K) {
+  if (((uintptr_t)base & 15) != 0) return false;
+  if (s_k == 1) return s_row % 4 == 0 && K % 4 == 0;
+  if (s_row == 1) return s_k % 4 == 0 && rows % 4 == 0;
+  return false;
+}
+
+int ac_gemm_bf16x3(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc, int M,
+                   int N, int K, const float* bias, int relu, float beta, int splitk, float drop_p,
+                   unsigned long long drop_seed, const unsigned long long* seed_dev, long row0, void* stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || relu < 0 || relu > 3) return AC_ERR_ARG;
+  if (splitk > 1 && (bias || relu || drop_p > 0.f || beta != 1.0f)) return AC_ERR_ARG;
+  // small or oddly laid out products: the exact-f32 kernels (a split-bf16 tile would be mostly padding / latency)
+  const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64) * (splitk < 1 ? 1 : splitk);
+  if ((double)M * N * K < 3.0e7 || t64 < 200 || !gb_operand_ok(A, sam, sak, M, K) || !gb_operand_ok(B, sbn, sbk, N, K))
+    return ac_gemm(A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, bias, relu, beta, splitk, drop_p, drop_seed, seed_dev, row0,
+                   nullptr, 0, stream);
+  GemmP p;
+  p.A = A; p.sam = sam; p.sak = sak; p.B = B; p.sbk = sbk; p.sbn = sbn; p.C = C; p.ldc = ldc;
+  p.M = M; p.N = N; p.K = K; p.bias = bias; p.relu = relu; p.beta = beta;
+  p.a_scale = nullptr; p.a_rows = 0;
+  p.splitk = splitk < 1 ? 1 : splitk;
+  p.drop = make_drop(drop_p, drop_seed, seed_dev);
+  p.row0 = row0;
+  const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * p.splitk;
+  static const int force = getenv("AC_GB_TILE") ? atoi(getenv("AC_GB_TILE")) : 0;   // development: 22 / 21 / 12 / 11
+  // 64x64 tiles fill the chip at the step's row counts (85-120 TFLOP/s); 128x128 only pays from ~450 such tiles on
+  const int tile = force ? force : (t128 >= 448 ? 22 : 11);
+  const int bm = tile / 10 * 64, bn = tile % 10 * 64;
+  dim3 grid((M + bm - 1) / bm, (N + bn - 1) / bn, p.splitk);
+  if (grid.y > 65535) return AC_ERR_ARG;
+  if (tile == 22) hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 2>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  else if (tile == 21) hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 1>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  else if (tile == 12) hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 2>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 1>), grid, dim3(256), 0, (hipStream_t)stream, p);
   return ac_check_launch();
 }
 

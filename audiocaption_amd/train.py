@@ -189,6 +189,10 @@ class TrainEngine:
         self._saved = None
         self._states = {}
         self._phase = "forward"
+        # GEMMs of the step: "bf16x3" = split-bf16 operands on the bf16 MFMA for the large products (the backward over
+        # all rows, teacher forcing), "f32" = exact f32 MFMA everywhere
+        import os
+        self.gemm_algo = os.environ.get("AUDIOCAPTION_TRAIN_GEMM", "bf16x3")
 
     # ---- small launch helpers (raw addresses; s = stream handle) ------------------------------------------
     def _gemm(self, s, A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, bias=None, relu=0, beta=0.0, splitk=1, drop_p=0.0,
@@ -197,8 +201,13 @@ class TrainEngine:
         if hook is not None:
             info = {"phase": self._phase, "M": M, "N": N, "K": K, "flops": 2.0 * M * N * K}
             hook("pre", info)
-        check(self.lib.ac_gemm(A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, bias, relu, beta, splitk, drop_p, seed,
-                               self._seed_ptr, row0, None, 0, s), "ac_gemm")
+        if self.gemm_algo == "bf16x3":
+            # split-bf16 operands (2^-16), f32 accumulation; small or unaligned products fall through to exact f32
+            check(self.lib.ac_gemm_bf16x3(A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, bias, relu, beta, splitk, drop_p, seed,
+                                          self._seed_ptr, row0, s), "ac_gemm_bf16x3")
+        else:
+            check(self.lib.ac_gemm(A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, bias, relu, beta, splitk, drop_p, seed,
+                                   self._seed_ptr, row0, None, 0, s), "ac_gemm")
         if hook is not None:
             hook("post", info)
 
@@ -255,7 +264,7 @@ class TrainEngine:
                 cls_rows[:] = torch.arange(N * T, dtype=torch.int32)
             else:
                 cls_rows[t::T] = off + torch.arange(N, dtype=torch.int32) * L + t
-        lay = {"passes": passes, "R": R, "S": S}
+        lay = {"passes": passes, "R": R, "S": S, "ones": torch.ones(max(T, 1), dtype=torch.int32, device=device)}
         for k, v in (("pos", pos), ("qrow0", qrow0), ("qlen", qlen), ("cls_rows", cls_rows),
                      ("mrow0", torch.arange(S, dtype=torch.int32) * Tm), ("mklen", torch.full((S,), Tm, dtype=torch.int32))):
             lay[k] = v.to(device)
@@ -295,7 +304,7 @@ class TrainEngine:
             if self._wsg is None or self._wsg.device != dev:
                 self._wsg = _Ws(dev)
             st = {"key": key, "ws": self._wsg, "lay": lay, "N": N, "T": T, "Tc": Tc, "Tq": Tq, "teacher_forcing": teacher_forcing,
-                  "p_dec": p_dec, "p_rnn": p_rnn, "p_cnn": p_cnn, "graph": None, "steps": 0,
+                  "p_dec": p_dec, "p_rnn": p_rnn, "p_cnn": p_cnn, "graphs": {}, "steps": 0,
                   "wav": torch.empty_like(wav, dtype=torch.float32) if hook is None else None,
                   "cnn_attn_in": torch.empty(N, Tq, 2048, device=dev) if hook is not None else None,
                   "cap": torch.empty(N, Tc, device=dev, dtype=torch.int64),
@@ -322,6 +331,8 @@ class TrainEngine:
         # one draw per step, exactly the reference's call pattern (transformer_model.py:44)
         use_cap = [1] * T if teacher_forcing else [int(random.random() < ss_ratio) for _ in range(T)]
         use_cap = input_dict.get("_use_cap", use_cap)
+        # passes whose prefix is the model's own prediction (pass 0 always starts from <start> alone)
+        st["free_ts"] = [] if teacher_forcing else [t for t in range(1, T) if not int(use_cap[t])]
         S = st["lay"]["S"]
         base_seed = int(input_dict.get("dropout_seed", self.seed))
         self.seed = base_seed + 1
@@ -352,7 +363,7 @@ class TrainEngine:
         return st
 
     # ---- forward launches (no host synchronisation, capturable) ---------------------------------------------------
-    def _launch_forward(self, st):
+    def _launch_forward(self, st, free=True):
         model, lib, fp = self.model, self.lib, self.flat
         enc, dec = model.encoder, model.decoder
         s = _lib.stream()
@@ -445,55 +456,101 @@ class TrainEngine:
                                                        ("hdn", F), ("ff", D), ("pre3", D))}
             a["x3"] = ws.f(f"x_l{l + 1}", R, D)
             acts.append(a)
-        cap_p = st["cap"].data_ptr()
-        for t, (L, off) in enumerate(passes):
-            nr = N * L
-            o4 = 4 * off * D
-            check(lib.ac_build_prefix(cap_p, Tc, seq, T, ucap, 0 if teacher_forcing else t, model.start_idx, word, off, N,
-                                      L, s), "ac_build_prefix")
-            check(lib.ac_embed_fwd(emb, pe, word, pos, x0, off, nr, D, p_dec, OP_EMB_A, p_dec, OP_EMB_B, self._seed_ptr,
-                                   s), "ac_embed_fwd")
-            x = x0
-            for l in range(nlay):
-                lp = f"{dp}model.layers.{l}."
-                a = acts[l]
-                op = OP_LAYER + 10 * l
-                qkv = a["qkv"] + 4 * off * 3 * D
-                self._lin(s, x + o4, fp.p(lp + "self_attn.in_proj_weight"), fp.p(lp + "self_attn.in_proj_bias"), qkv, nr,
-                          3 * D, D)
-                check(lib.ac_attn_seq_fwd(a["qkv"], 3 * D, a["qkv"] + 4 * D, 3 * D, a["qkv"] + 8 * D, 3 * D, a["ctx1"], D,
-                                          P1[l], T, T, qrow0, qlen, qrow0, qlen, None, word, model.pad_idx, 1, t * N, N, nh,
-                                          64, L, L, p_dec, op + 0, self._seed_ptr, s), "ac_attn_seq_fwd")
-                self._lin(s, a["ctx1"] + o4, fp.p(lp + "self_attn.out_proj.weight"), fp.p(lp + "self_attn.out_proj.bias"),
-                          a["sa"] + o4, nr, D, D)
-                check(lib.ac_dropadd_ln_fwd(a["sa"], x, fp.p(lp + "norm1.weight"), fp.p(lp + "norm1.bias"), a["pre1"],
-                                            a["x1"], off, nr, 0, D, p_dec, op + 1, self._seed_ptr, 1e-5, s), "ln1")
-                self._lin(s, a["x1"] + o4, fp.p(lp + "multihead_attn.in_proj_weight"),
-                          fp.p(lp + "multihead_attn.in_proj_bias"), a["q2"] + o4, nr, D, D)
-                check(lib.ac_attn_seq_fwd(a["q2"], D, kv[l], 2 * D, kv[l] + 4 * D, 2 * D, a["ctx2"], D, P2[l], T, Tm, qrow0,
-                                          qlen, mrow0, mklen, mvalid, None, 0, 0, t * N, N, nh, 64, L, Tm, p_dec, op + 2,
-                                          self._seed_ptr, s), "ac_attn_seq_fwd(cross)")
-                self._lin(s, a["ctx2"] + o4, fp.p(lp + "multihead_attn.out_proj.weight"),
-                          fp.p(lp + "multihead_attn.out_proj.bias"), a["ca"] + o4, nr, D, D)
-                check(lib.ac_dropadd_ln_fwd(a["ca"], a["x1"], fp.p(lp + "norm2.weight"), fp.p(lp + "norm2.bias"),
-                                            a["pre2"], a["x2"], off, nr, 0, D, p_dec, op + 3, self._seed_ptr, 1e-5, s),
-                      "ln2")
-                self._lin(s, a["x2"] + o4, fp.p(lp + "linear1.weight"), fp.p(lp + "linear1.bias"),
-                          a["hdn"] + 4 * off * F, nr, F, D, relu=1, drop_p=p_dec, seed=op + 4, row0=off)
-                self._lin(s, a["hdn"] + 4 * off * F, fp.p(lp + "linear2.weight"), fp.p(lp + "linear2.bias"), a["ff"] + o4,
-                          nr, D, F)
-                check(lib.ac_dropadd_ln_fwd(a["ff"], a["x2"], fp.p(lp + "norm3.weight"), fp.p(lp + "norm3.bias"),
-                                            a["pre3"], a["x3"], off, nr, 0, D, p_dec, op + 5, self._seed_ptr, 1e-5, s),
-                      "ln3")
-                x = a["x3"]
-            if teacher_forcing:
-                self._lin(s, x, cls, None, logit, N * T, V, D)
-            else:
-                # classifier on the last position of every sequence of this pass -> logit[:, t]
-                self._lin(s, x + o4 + 4 * t * D, cls, None, logit + 4 * t * V, N, V, D, ldx=L * D, ldy=T * V)
-                check(lib.ac_argmax_rows(logit + 4 * t * V, T * V, N, V, seq + 4 * t, T, s), "ac_argmax_rows")
         st.update(V=V, F=F, gru=gru, kv=kv, acts=acts, x0=x0, word=word, P1=P1, P2=P2, mem=mem, mem_pre=mem_pre,
                   mem_a=mem_a, attn_emb=attn_emb)
+        st["ctx"] = dict(seq=seq, logit=logit, pos=pos, qrow0=qrow0, qlen=qlen, mrow0=mrow0, mklen=mklen, emb=emb, pe=pe,
+                         cls=cls, ucap=ucap, mvalid=mvalid, Tm=Tm)
+        # The reference runs T sequential decoder passes (pass t on the prefix of length t + 1).  Which passes are
+        # teacher forced is known on the host (the scheduled-sampling draws), and a teacher-forced pass depends on nothing
+        # the model produced - so ALL passes first run teacher forced as ONE batch over the whole row space (26 launches
+        # over 7 392 rows instead of 21 x 26 over 32 ... 704), and only the free-running passes (15 % at ss_ratio 0.85)
+        # are then re-run in order on their own predictions, overwriting their rows.  Same results: a pass reads earlier
+        # passes only through `seq`, and the dropout masks are a function of (seed, row), not of the launch.
+        if teacher_forcing:
+            self._decoder_passes(st, 0, 1, ucap)
+        else:
+            self._decoder_passes(st, 0, NP, lay["ones"].data_ptr())
+            if free:
+                for t in st["free_ts"]:
+                    self._decoder_passes(st, t, t + 1, ucap)
+
+    def _decoder_passes(self, st, ta, tb, ucap_ptr):
+        """Decoder passes [ta, tb) of the row space as one batch: prefixes (teacher tokens where ``ucap_ptr[t]`` is set,
+        else the model's own earlier predictions), embedding, the decoder layers, the classifier on the last position of
+        every sequence -> logit[:, t], arg-max -> seq[:, t]."""
+        model, lib, fp = self.model, self.lib, self.flat
+        dec = model.decoder
+        s = _lib.stream()
+        self._phase = "forward"
+        ws, lay, c = st["ws"], st["lay"], st["ctx"]
+        N, T, Tc = st["N"], st["T"], st["Tc"]
+        V, F, acts, kv, P1, P2, x0, word = st["V"], st["F"], st["acts"], st["kv"], st["P1"], st["P2"], st["x0"], st["word"]
+        p_dec, teacher_forcing = st["p_dec"], st["teacher_forcing"]
+        passes = lay["passes"]
+        NP = len(passes)
+        nlay, nh, Tm = dec.nlayers, dec.nhead, c["Tm"]
+        dp = "decoder."
+        off = passes[ta][1]
+        nr = sum(N * passes[t][0] for t in range(ta, tb))
+        lmax = max(passes[t][0] for t in range(ta, tb))
+        seq0, nseq = ta * N, (tb - ta) * N
+        o4 = 4 * off * D
+        cap_p = st["cap"].data_ptr()
+        for t in range(ta, tb):
+            L, off_t = passes[t]
+            check(lib.ac_build_prefix(cap_p, Tc, c["seq"], T, ucap_ptr, 0 if teacher_forcing else t, model.start_idx, word,
+                                      off_t, N, L, s), "ac_build_prefix")
+        check(lib.ac_embed_fwd(c["emb"], c["pe"], word, c["pos"], x0, off, nr, D, p_dec, OP_EMB_A, p_dec, OP_EMB_B,
+                               self._seed_ptr, s), "ac_embed_fwd")
+        qrow0, qlen, mrow0, mklen, mvalid = c["qrow0"], c["qlen"], c["mrow0"], c["mklen"], c["mvalid"]
+        x = x0
+        for l in range(nlay):
+            lp = f"{dp}model.layers.{l}."
+            a = acts[l]
+            op = OP_LAYER + 10 * l
+            qkv = a["qkv"] + 4 * off * 3 * D
+            self._lin(s, x + o4, fp.p(lp + "self_attn.in_proj_weight"), fp.p(lp + "self_attn.in_proj_bias"), qkv, nr,
+                      3 * D, D)
+            check(lib.ac_attn_seq_fwd(a["qkv"], 3 * D, a["qkv"] + 4 * D, 3 * D, a["qkv"] + 8 * D, 3 * D, a["ctx1"], D,
+                                      P1[l], T, T, qrow0, qlen, qrow0, qlen, None, word, model.pad_idx, 1, seq0, nseq, nh,
+                                      64, lmax, lmax, p_dec, op + 0, self._seed_ptr, s), "ac_attn_seq_fwd")
+            self._lin(s, a["ctx1"] + o4, fp.p(lp + "self_attn.out_proj.weight"), fp.p(lp + "self_attn.out_proj.bias"),
+                      a["sa"] + o4, nr, D, D)
+            check(lib.ac_dropadd_ln_fwd(a["sa"], x, fp.p(lp + "norm1.weight"), fp.p(lp + "norm1.bias"), a["pre1"],
+                                        a["x1"], off, nr, 0, D, p_dec, op + 1, self._seed_ptr, 1e-5, s), "ln1")
+            self._lin(s, a["x1"] + o4, fp.p(lp + "multihead_attn.in_proj_weight"),
+                      fp.p(lp + "multihead_attn.in_proj_bias"), a["q2"] + o4, nr, D, D)
+            check(lib.ac_attn_seq_fwd(a["q2"], D, kv[l], 2 * D, kv[l] + 4 * D, 2 * D, a["ctx2"], D, P2[l], T, Tm, qrow0,
+                                      qlen, mrow0, mklen, mvalid, None, 0, 0, seq0, nseq, nh, 64, lmax, Tm, p_dec, op + 2,
+                                      self._seed_ptr, s), "ac_attn_seq_fwd(cross)")
+            self._lin(s, a["ctx2"] + o4, fp.p(lp + "multihead_attn.out_proj.weight"),
+                      fp.p(lp + "multihead_attn.out_proj.bias"), a["ca"] + o4, nr, D, D)
+            check(lib.ac_dropadd_ln_fwd(a["ca"], a["x1"], fp.p(lp + "norm2.weight"), fp.p(lp + "norm2.bias"),
+                                        a["pre2"], a["x2"], off, nr, 0, D, p_dec, op + 3, self._seed_ptr, 1e-5, s),
+                  "ln2")
+            self._lin(s, a["x2"] + o4, fp.p(lp + "linear1.weight"), fp.p(lp + "linear1.bias"),
+                      a["hdn"] + 4 * off * F, nr, F, D, relu=1, drop_p=p_dec, seed=op + 4, row0=off)
+            self._lin(s, a["hdn"] + 4 * off * F, fp.p(lp + "linear2.weight"), fp.p(lp + "linear2.bias"), a["ff"] + o4,
+                      nr, D, F)
+            check(lib.ac_dropadd_ln_fwd(a["ff"], a["x2"], fp.p(lp + "norm3.weight"), fp.p(lp + "norm3.bias"),
+                                        a["pre3"], a["x3"], off, nr, 0, D, p_dec, op + 5, self._seed_ptr, 1e-5, s),
+                  "ln3")
+            x = a["x3"]
+        logit, seq, cls = c["logit"], c["seq"], c["cls"]
+        if teacher_forcing:
+            self._lin(s, x, cls, None, logit, N * T, V, D)
+        elif tb - ta == NP:
+            # every pass at once: the last position of every sequence, gathered in (clip, step) order = logit's layout
+            xlast = ws.f("xlast", N * T, D)
+            check(lib.ac_gather_rows(x, lay["cls_rows"].data_ptr(), xlast, N * T, D, s), "ac_gather_rows")
+            self._lin(s, xlast, cls, None, logit, N * T, V, D)
+            check(lib.ac_argmax_rows(logit, V, N * T, V, seq, 1, s), "ac_argmax_rows")
+        else:
+            for t in range(ta, tb):
+                L, off_t = passes[t]
+                # classifier on the last position of every sequence of this pass -> logit[:, t]
+                self._lin(s, x + 4 * off_t * D + 4 * t * D, cls, None, logit + 4 * t * V, N, V, D, ldx=L * D, ldy=T * V)
+                check(lib.ac_argmax_rows(logit + 4 * t * V, T * V, N, V, seq + 4 * t, T, s), "ac_argmax_rows")
 
     def _outputs(self, st):
         N, T, V = st["N"], st["T"], st["V"]
@@ -677,12 +734,19 @@ class TrainEngine:
                 self._lin_dx(s, dgx, fp.p(f"{pre}weight_ih_l{l}"), dout, rows_g, 6 * H, g["in_dim"])
 
     # ---- fast path: forward + loss + backward (+ gradient all-reduce) + clip + Adam -----------------------
-    def _launch_step_body(self, st, smoothing, part="all"):
-        """forward, label-smoothing loss (mean over the valid target tokens, counted on the device) and backward.
-        ``part`` "head" stops after the decoder's backward, "gru" is the rest (see ``_launch_backward``)."""
+    def _launch_part(self, st, smoothing, part):
+        """One capturable piece of an iteration:
+        "fwd0"       frozen Cnn14, GRU, audio memory and EVERY decoder pass teacher forced as one batch;
+        ("pass", t)  free-running pass t re-run on the model's own predictions (only the passes the draws made so);
+        "tail"       label-smoothing loss (mean over the valid target tokens, counted on the device) + the whole backward;
+        "tail_head" / "gru"   the same in two halves (see ``_launch_backward``) when gradients are all-reduced."""
+        self._seed_ptr = st["small"].data_ptr()
+        if part == "fwd0":
+            return self._launch_forward(st, free=False)
+        if isinstance(part, tuple):
+            return self._decoder_passes(st, part[1], part[1] + 1, st["ctx"]["ucap"])
         if part == "gru":
             return self._launch_backward(st, None, "gru")
-        self._launch_forward(st)
         N, T, Tc, V = st["N"], st["T"], st["Tc"], st["V"]
         ws = st["ws"]
         logit = ws.f("logit", N * T, V)
@@ -692,60 +756,66 @@ class TrainEngine:
         check(self.lib.ac_label_smoothing_loss(logit, st["cap"].data_ptr() + 8, Tc, tgt_len, N, T, V, float(smoothing), 0.0,
                                                row_loss, loss, dlogit, 0.0, None, _lib.stream()),
               "ac_label_smoothing_loss")
-        self._launch_backward(st, dlogit, part)
+        self._launch_backward(st, dlogit, "all" if part == "tail" else "head")
 
     def step(self, input_dict, optimizer, smoothing=0.1, max_grad_norm=1.0, process_group=None, use_graph=True):
         """One training iteration (run.py:106-126) without leaving the HIP path; returns the loss as a device scalar.
 
-        The ~700 launches of forward + loss + backward are latency-bound at the reference's batch sizes, so for each
-        batch shape they are captured ONCE into a HIP graph over static buffers (second iteration of that shape) and
-        replayed; the per-iteration data - audio, captions, lengths, the scheduled-sampling draws and the dropout
-        seed - are copied into those buffers first.  Gradients land in the flat buffer (= the parameters' ``.grad``);
-        with ``torch.distributed`` initialised they are summed over the ranks by two all-reduces (the decoder's slice
-        under the GRU backward, then the GRU's) and the division by the world size is folded into the clip coefficient;
-        clip + Adam are three launches on the flat buffers."""
+        The launches of an iteration are latency-bound at the reference's batch sizes, so for each batch shape they are
+        captured into HIP graphs over static buffers (from the second iteration of that shape on) and replayed; the
+        per-iteration data - audio, captions, lengths, the scheduled-sampling draws and the dropout seed - are copied
+        into those buffers first.  An iteration replays: one graph for the encoder + all decoder passes teacher forced,
+        one small graph per free-running pass the draws produced (captured the first time pass t is free), one graph for
+        loss + backward.  Gradients land in the flat buffer (= the parameters' ``.grad``); with ``torch.distributed``
+        initialised they are summed over the ranks by two all-reduces (the decoder's slice under the GRU backward, then
+        the GRU's) and the division by the world size is folded into the clip coefficient; clip + Adam are three launches
+        on the flat buffers."""
         from .optim import FusedAdam, clip_grad_norm_
         if "cap_len" not in input_dict:
             raise KeyError("cap_len")
         st = self._prepare(input_dict)
         st["steps"] += 1
         world = dist_world_size(process_group)
-        # Several ranks: the step runs as TWO parts - everything up to the end of the decoder's backward, then the GRU's
-        # backward through time - and the all-reduce of the decoder's gradients (45 % of the 42.8 MB, final after part
-        # one) is issued between them, so that it travels under the GRU backward; the GRU's gradients follow.
-        parts = ("head", "gru") if world > 1 else ("all",)
+        # Several ranks: the backward runs as TWO parts - up to the end of the decoder's backward, then the GRU's backward
+        # through time - and the all-reduce of the decoder's gradients (45 % of the 42.8 MB, final after part one) is
+        # issued between them, so that it travels under the GRU backward; the GRU's gradients follow.
+        parts = ["fwd0"] + [("pass", t) for t in st["free_ts"]] + (["tail_head", "gru"] if world > 1 else ["tail"])
+        graphs = st.setdefault("graphs", {})
+        eager = (not use_graph) or st["steps"] < 2      # first iteration of this shape: eager (also the warm-up)
         works = []
-        for pi, part in enumerate(parts):
-            gname = "graph" if part in ("all", "head") else "graph_gru"
-            if not use_graph or (st.get("graph") is None and st["steps"] < 2):
-                self._launch_step_body(st, smoothing, part)   # first iteration of this shape: eager (also the warm-up)
+        for part in parts:
+            if eager:
+                self._launch_part(st, smoothing, part)
             else:
                 # A captured graph holds RAW ADDRESSES: the flat parameter storage, the shared workspace, and - through
                 # the frozen Cnn14 - its packed weights and its activation buffers, which are shared by all batch shapes
                 # and re-allocated when a larger one arrives.  All of them are part of the key, and the state keeps
-                # references to what its graph addresses, so a stale graph is neither replayed nor left pointing at
+                # references to what its graphs address, so a stale graph is neither replayed nor left pointing at
                 # recycled memory.
                 cnn = getattr(self.model.encoder, "cnn", None)
                 cnn_algo = cnn.effective_algo(None, True) if cnn is not None and hasattr(cnn, "_pack") else None
-                if cnn_algo is not None:
+                if cnn_algo is not None and part == "fwd0":
                     # weight repacks (host uploads, float64 transforms of the Winograd tier) must not land inside a
                     # capture: pack the frozen Cnn14 for the tier the train-mode forward uses now (cached: a no-op
                     # unless the Cnn14's own tensors changed)
                     cnn._pack(st["cap"].device, cnn_algo)
                 ident, refs = cnn.capture_token(cnn_algo) if cnn_algo is not None else (None, None)
-                gkey = (smoothing, _lib.param_generation_flat(self), st["ws"].gen, ident, parts)
-                if st.get(gname) is None or st.get(gname + "_key") != gkey:
+                gkey = (smoothing, _lib.param_generation_flat(self), st["ws"].gen, ident, world > 1)
+                hit = graphs.get(part)
+                if hit is None or hit[1] != gkey:
+                    if part != "fwd0" and (graphs.get("fwd0") is None or graphs["fwd0"][1] != gkey):
+                        raise RuntimeError("TrainEngine: graph parts out of order")   # fwd0 refreshes the shared context
                     torch.cuda.synchronize(st["cap"].device)
                     graph = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(graph):
-                        self._launch_step_body(st, smoothing, part)
+                        self._launch_part(st, smoothing, part)
                     ident, refs = cnn.capture_token(cnn_algo) if cnn_algo is not None else (None, None)
-                    st[gname], st[gname + "_hold"] = graph, refs
-                    st[gname + "_key"] = (smoothing, _lib.param_generation_flat(self), st["ws"].gen, ident, parts)
-                st[gname].replay()
-            if world > 1:
+                    hit = graphs[part] = (graph, (smoothing, _lib.param_generation_flat(self), st["ws"].gen, ident,
+                                                  world > 1), refs)
+                hit[0].replay()
+            if world > 1 and part in ("tail_head", "gru"):
                 o = self.flat.decoder_offset
-                piece = self.flat.grad[o:] if part == "head" else self.flat.grad[:o]
+                piece = self.flat.grad[o:] if part == "tail_head" else self.flat.grad[:o]
                 works.append(allreduce_flat_gradients(piece, process_group, async_op=True))
         for w_ in works:
             if w_ is not None:

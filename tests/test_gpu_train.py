@@ -69,6 +69,44 @@ def test_general_gemm_all_layouts(lib):
     assert lib.ac_gemm(P(xd), K, 1, P(wd), 1, K, P(y), N, M, N, K, P(bd), 0, 1.0, 4, 0.0, 0, None, 0, None, 0, S()) == -1
 
 
+@pytest.mark.parametrize("M,N,K", [(1344, 768, 256), (7392, 256, 1024), (520, 1024, 512), (4100, 260, 776)])
+def test_split_bf16_gemm_all_layouts(lib, M, N, K):
+    """ac_gemm_bf16x3 (three bf16 MFMAs per product on operands split into hi + lo at staging) in the three layouts the
+    training step uses - x w^T (+ bias, ReLU), dy w (+ beta), dy^T x (split-K atomics, strided views) - against float64:
+    2^-16 relative operand error, so 3e-5 of the largest output instead of the exact-f32 kernels' 1e-5; tile tails
+    (M, N, K not multiples of the 128 / 64 / 32 tile) included."""
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g)
+    b = torch.randn(N, generator=g)
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+    y = torch.empty(M, N, device="cuda")
+    assert lib.ac_gemm_bf16x3(P(xd), K, 1, P(wd), 1, K, P(y), N, M, N, K, P(bd), 1, 0.0, 1, 0.0, 0, None, 0, S()) == 0
+    assert rel("bf16x3: x w^T + b, relu", y, torch.relu(x.double() @ w.double().t() + b.double())) < 3e-5
+    dy = torch.randn(M, N, generator=g)
+    dx0 = torch.randn(M, K, generator=g)
+    dx = dx0.cuda()
+    assert lib.ac_gemm_bf16x3(P(dy.cuda()), N, 1, P(wd), K, 1, P(dx), K, M, K, N, None, 0, 1.0, 1, 0.0, 0, None, 0, S()) == 0
+    assert rel("bf16x3: dy w + dx0", dx, dy.double() @ w.double() + dx0.double()) < 3e-5
+    dyp = torch.randn(M, N + 24, generator=g)
+    xp = torch.randn(M, K + 8, generator=g)
+    for splitk in (1, 7):
+        dw0 = torch.randn(N, K, generator=g)
+        dw = dw0.cuda()
+        assert lib.ac_gemm_bf16x3(P(dyp.cuda()), 1, N + 24, P(xp.cuda()), K + 8, 1, P(dw), K, N, K, M, None, 0, 1.0, splitk,
+                                  0.0, 0, None, 0, S()) == 0
+        want = dyp[:, :N].double().t() @ xp[:, :K].double() + dw0.double()
+        assert rel(f"bf16x3: dy^T x split-K {splitk}", dw, want) < 3e-5
+    # a layout it cannot take (rows of 4981 floats are not 16-byte aligned) is forwarded to the exact-f32 kernels
+    V = 4981
+    dl = torch.randn(672, V, generator=g)
+    wc = torch.randn(V, 256, generator=g)
+    dxl = torch.empty(672, 256, device="cuda")
+    assert lib.ac_gemm_bf16x3(P(dl.cuda()), V, 1, P(wc.cuda()), 256, 1, P(dxl), 256, 672, 256, V, None, 0, 0.0, 1, 0.0, 0,
+                              None, 0, S()) == 0
+    assert rel("forwarded: dl w_cls", dxl, dl.double() @ wc.double()) < 1e-5
+
+
 def test_dropout_hash_is_the_oracles(lib):
     from oracle import train_path as OT
     n = 100003
@@ -420,7 +458,9 @@ def test_training_step_vs_reference_gradients(train_model, golden_dir, tag):
         delta = (named[key].detach() - before[key]).reshape(-1)[idx].cpu().numpy()
         want = g8[f"{tag}_delta/{key}"]
         gs = np.abs(g8[f"{tag}_gsample/{key}"])
-        solid = gs > 1e-5 * (gs.max() + 1e-30) + 1e-7   # Adam's first step is lr*sign(g): skip near-zero gradients
+        # Adam's first step is lr * g / (|g| + 1e-8), i.e. lr * sign(g) unless |g| is near eps: entries whose gradient is
+        # within the GEMMs' error of zero are skipped (split-bf16 GEMMs: 7e-6 of the tensor's max; exact f32: 1e-6)
+        solid = gs > 1e-4 * (gs.max() + 1e-30) + 1e-6
         assert np.abs(delta - want)[solid].max(initial=0.0) < 5e-6, key
 
 
@@ -625,7 +665,7 @@ def test_replayed_graph_after_a_buffer_regrow_equals_the_eager_step(train_model)
     ptr_small = cnn._bufs[("full", torch.float32)].data_ptr()
     vals = [float(eng.step(small, opt)["loss"]) for _ in range(3)]     # eager (first of the shape), capture, replay
     st_small = eng._states[next(k for k in eng._states if k[1] == 2)]
-    assert st_small["graph"] is not None
+    assert "fwd0" in st_small["graphs"] and "tail" in st_small["graphs"]
     assert id(cnn._packed["bf16x3"][1]) == pack_id                      # optimiser steps do not repack the frozen Cnn14
     big_eager = float(eng.step(big, opt, use_graph=False)["loss"])      # larger shape: shared buffers re-allocated
     assert cnn._bufs[("full", torch.float32)].data_ptr() != ptr_small or cnn._bufs[("full", torch.float32)].numel() > 0
@@ -665,7 +705,7 @@ def test_changing_batch_shapes_share_one_workspace(train_model):
     for _ in range(3):                       # eager, capture, replay
         r = eng.step(small, opt)
     st_small = next(iter(eng._states.values()))
-    assert st_small["graph"] is not None
+    assert "fwd0" in st_small["graphs"] and "tail" in st_small["graphs"]
     gen0 = eng._wsg.gen
     losses = [float(r["loss"])]
     torch.cuda.synchronize()

@@ -83,3 +83,49 @@ def test_two_rank_step_equals_single_process_step(tmp_path):
     # Adam's first step is lr * sign-like: near-zero gradients may flip, everything else must agree
     frac = float(((r0["flat"] - flat).abs() > 1e-5).float().mean())
     assert frac < 1e-3
+
+
+def _graph_worker(rank, world, port, out_dir):
+    """Three iterations with use_graph=True: the first eager, the second captures BOTH graphs of the two-part step (decoder
+    part, GRU part - the decoder's gradients are all-reduced between them), the third replays them."""
+    from audiocaption_amd.optim import FusedAdam
+    from audiocaption_amd.train import TrainEngine
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = _model()
+        eng = TrainEngine(model)
+        opt = FusedAdam([p for p in model.parameters() if p.requires_grad], lr=5e-4, weight_decay=1e-6)
+        losses = []
+        for _ in range(3):
+            losses.append(float(eng.step(_batch(slice(2 * rank, 2 * rank + 2)), opt, smoothing=0.1, max_grad_norm=1.0)["loss"]))
+        st = next(iter(eng._states.values()))
+        assert {"fwd0", "tail_head", "gru"} <= set(st["graphs"])
+        torch.cuda.synchronize()
+        torch.save({"losses": losses, "flat": eng.flat.flat.detach().cpu().clone()}, os.path.join(out_dir, f"g{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_graph_steps_keep_the_ranks_identical(tmp_path):
+    from audiocaption_amd import build
+    from audiocaption_amd.optim import FusedAdam
+    from audiocaption_amd.train import TrainEngine
+    build.build()
+    port = 29950 + random.randint(0, 40)
+    mp.spawn(_graph_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "g0.pt"), torch.load(tmp_path / "g1.pt")
+    assert torch.equal(r0["flat"], r1["flat"]), "ranks diverged"
+    # against three single-process iterations on the union batch (eager, one part): same trajectory up to rounding
+    model = _model()
+    eng = TrainEngine(model)
+    opt = FusedAdam([p for p in model.parameters() if p.requires_grad], lr=5e-4, weight_decay=1e-6)
+    losses = [float(eng.step(_batch(slice(0, 4)), opt, smoothing=0.1, max_grad_norm=1.0, use_graph=False)["loss"])
+              for _ in range(3)]
+    for k in range(3):
+        assert 0.5 * (r0["losses"][k] + r1["losses"][k]) == pytest.approx(losses[k], rel=2e-4), k
+    assert losses[2] < losses[0]
+    frac = float(((r0["flat"] - eng.flat.flat.cpu()).abs() > 5e-5).float().mean())
+    print(f"entries off by more than 5e-5 after three steps: {frac:.2e}")
+    assert frac < 5e-3
