@@ -66,7 +66,7 @@ SIGNATURES = {
     "ac_trm_beam_reorder": (_I, [_WP, _I, _I, _I, _P, _P, _P]),
     # training step (csrc/train.hip)
     "ac_gemm": (_I, [_P, _L, _L, _P, _L, _L, _P, _L, _I, _I, _I, _P, _I, _F, _I, _F, _U64, _P, _L, _P, _I, _P]),
-    "ac_gemm_bf16x3": (_I, [_P, _L, _L, _P, _L, _L, _P, _L, _I, _I, _I, _P, _I, _F, _I, _F, _U64, _P, _L, _P]),
+    "ac_gemm_bf16x3": (_I, [_P, _L, _L, _P, _L, _L, _P, _L, _I, _I, _I, _P, _I, _F, _I, _F, _U64, _P, _L, _P, _I, _P]),
     "ac_dropout": (_I, [_P, _P, _L, _F, _U64, _P, _L, _P]),
     "ac_mask_pos_scale": (_I, [_P, _P, _L, _F, _P]),
     "ac_build_prefix": (_I, [_P, _I, _P, _I, _P, _I, _I, _P, _L, _I, _I, _P]),

@@ -164,6 +164,173 @@ __global__ __launch_bounds__(64) void attn_step_kernel(AttnParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// One attention sub-layer of a decode step for ONE row per workgroup (d_model 256, 4 heads of 64): everything after the
+// QKV projection is row-local, so the four launches attention -> out-projection -> residual + LayerNorm -> next
+// projection become one.  Wave h runs head h of the single-query attention (the same code path as attn_step_kernel);
+// the 256-float context then stays in LDS; the out-projection is a matrix-vector product against a TRANSPOSED copy of
+// the weights (WoT[k][n]: wave w takes k in [64 w, 64 w + 64), lane l the four outputs 4 l .. 4 l + 3, so a wave
+// instruction reads one contiguous 1 KiB row and 16 such loads are in flight per lane), reduced over the waves in LDS;
+// then the residual join + LayerNorm, and for the self-attention sub-layer the cross-attention query projection of the
+// fresh row.  A workgroup streams 256 KiB per projection from L2 (64 workgroups: 16 MB per launch, ~2 us), which
+// replaces two 5.5-7 us launches whose cost was launch boundary + first-touch latency, not arithmetic.
+// ---------------------------------------------------------------------------------------------
+constexpr int ROW_D = 256, ROW_H = 4;
+
+struct RowParams {
+  AttnParams a;                          // attention geometry; a.out is unused
+  const float* res; long ldres;          // residual input rows
+  const float* WoT; const float* bo;     // out-projection, transposed [k][n]
+  const float* ln_w; const float* ln_b;
+  float* xout; long ldxo;                // LayerNorm(res + attention output)
+  const float* WqT; const float* bq;     // optional next projection of the normalised row (self: the cross query)
+  float* qout; long ldqo;
+};
+
+__device__ __forceinline__ float attn_head_row(const AttnParams& p, int r, int h, int lane, float* sc, bool active) {
+  // head h of row r, one wave; returns output channel `lane` (< 64) of the head.  Mirrors attn_step_kernel.  Waves with
+  // `active` false only take part in the workgroup barriers.
+  (void)active;
+  const int kr = r / p.row_div;
+  const size_t hoff = (size_t)h * 64;
+  if (p.new_k) {
+    const size_t dst = (size_t)kr * p.row_stride + (size_t)(p.nkeys - 1) * p.key_stride + hoff + lane;
+    p.Kw[dst] = p.new_k[(size_t)r * p.ld_new + hoff + lane];
+    p.Vw[dst] = p.new_v[(size_t)r * p.ld_new + hoff + lane];
+  }
+  __syncthreads();
+  const float* qp = p.q + (size_t)r * p.ldq + hoff;
+  const float* Kb = p.K + (size_t)kr * p.row_stride + hoff;
+  const float* Vb = p.V + (size_t)kr * p.row_stride + hoff;
+  const int klen = p.key_len ? p.key_len[kr] : p.nkeys;
+  if (lane < 32 && lane >= p.nkeys) sc[lane] = 0.f;
+  {
+    const int ks = lane >> 4, d4 = lane & 15;
+    const f32x4 q4 = *(const f32x4*)(qp + 4 * d4);
+    // the key rows of the first 32 keys are all requested at once (a decode step has <= 21 self keys; 31 audio frames
+    // for a 10 s clip): one memory round trip instead of one per four keys
+    constexpr int KPRE = 8;
+    f32x4 kpre[KPRE];
+#pragma unroll
+    for (int i = 0; i < KPRE; ++i) {
+      const int j = 4 * i + ks;
+      kpre[i] = j < p.nkeys ? *(const f32x4*)(Kb + (size_t)j * p.key_stride + 4 * d4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll 4
+    for (int j0 = 0; j0 < p.nkeys; j0 += 4) {
+      const int j = j0 + ks;
+      float s = 0.f;
+      if (j < p.nkeys) {
+        f32x4 kv;
+        if (j0 < 4 * KPRE) {
+#pragma unroll
+          for (int i = 0; i < KPRE; ++i)
+            if (j0 == 4 * i) kv = kpre[i];
+        } else {
+          kv = *(const f32x4*)(Kb + (size_t)j * p.key_stride + 4 * d4);
+        }
+        s = (q4[0] * kv[0] + q4[1] * kv[1]) + (q4[2] * kv[2] + q4[3] * kv[3]);
+      }
+      s = row16_sum(s);
+      if (d4 == 0 && j < p.nkeys) {
+        const bool masked = (j >= klen) || (p.key_mask && p.key_mask[(size_t)r * p.mask_stride + j]);
+        sc[j] = masked ? -INFINITY : s * p.scale;
+      }
+    }
+  }
+  constexpr int VPRE = 32;
+  float vpre[VPRE];
+#pragma unroll
+  for (int j = 0; j < VPRE; ++j) vpre[j] = j < p.nkeys ? Vb[(size_t)j * p.key_stride + lane] : 0.f;
+  __syncthreads();
+  float m = -INFINITY;
+  for (int j = lane; j < p.nkeys; j += 64) m = fmaxf(m, sc[j]);
+  m = wave_max(m);
+  float den = 0.f;
+  for (int j = lane; j < p.nkeys; j += 64) {
+    const float e = expf(sc[j] - m);
+    sc[j] = e;
+    den += e;
+  }
+  den = wave_sum(den);
+  __syncthreads();
+  float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+#pragma unroll
+  for (int j = 0; j < VPRE; j += 4) {
+    o0 = fmaf(sc[j], vpre[j], o0);
+    o1 = fmaf(sc[j + 1], vpre[j + 1], o1);
+    o2 = fmaf(sc[j + 2], vpre[j + 2], o2);
+    o3 = fmaf(sc[j + 3], vpre[j + 3], o3);
+  }
+  for (int j = VPRE; j < p.nkeys; ++j) o0 = fmaf(sc[j], Vb[(size_t)j * p.key_stride + lane], o0);
+  return ((o0 + o1) + (o2 + o3)) / den;
+}
+
+// Matrix-vector product against a transposed 256 x 256 matrix, split over the 4 waves of the workgroup: wave w owns
+// k in [64 w, 64 w + 64), lane l the outputs 4 l .. 4 l + 3, so a wave instruction reads one contiguous 1 KiB row; 16 rows
+// are in flight per lane.  Every thread gets y[tid] = bias[tid] + sum_k WT[k][tid] x[k]; x in LDS, part = [4][256] scratch.
+// (Register budget on purpose: in the throughput schedule this kernel has to fit into the slot ONE finished conv
+// workgroup leaves on a CU - 4 waves of <= 240 VGPRs.  Variants with 32 + 32 rows in flight over 8 waves, or with the
+// rows requested before the attention (256 VGPRs), were ~1 us faster alone and cost the overlapped pipeline 0.7-0.8 ms
+// per step, because their workgroups waited for whole CUs.)
+__device__ __forceinline__ float row_gemv256(const float* WT, const float* bias, const float* x, float* part, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const f32x4* wp = (const f32x4*)(WT + (size_t)(wave * 64) * ROW_D) + lane;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 16
+  for (int k = 0; k < 64; ++k) {
+    const f32x4 wv = wp[(size_t)k * (ROW_D / 4)];
+    const float xv = x[wave * 64 + k];
+    acc[0] = fmaf(wv[0], xv, acc[0]);
+    acc[1] = fmaf(wv[1], xv, acc[1]);
+    acc[2] = fmaf(wv[2], xv, acc[2]);
+    acc[3] = fmaf(wv[3], xv, acc[3]);
+  }
+  *(f32x4*)(part + wave * ROW_D + 4 * lane) = acc;
+  __syncthreads();
+  const float y = ((part[tid] + part[ROW_D + tid]) + (part[2 * ROW_D + tid] + part[3 * ROW_D + tid])) + (bias ? bias[tid] : 0.f);
+  __syncthreads();   // part is reused by the next projection
+  return y;
+}
+
+__global__ __launch_bounds__(256, 2) void dec_row_kernel(RowParams p) {
+  __shared__ float sc[ROW_H][MAX_KEYS];
+  __shared__ __attribute__((aligned(16))) float sx[ROW_D];
+  __shared__ __attribute__((aligned(16))) float part[4 * ROW_D];
+  __shared__ float red[8];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float resv = p.res[(size_t)r * p.ldres + tid];
+  sx[tid] = attn_head_row(p.a, r, wave, lane, sc[wave], true);
+  __syncthreads();
+  const float v = resv + row_gemv256(p.WoT, p.bo, sx, part, tid);
+  // LayerNorm over the 256 values (one per thread)
+  const float s1 = wave_sum(v);
+  if (lane == 0) red[wave] = s1;
+  __syncthreads();
+  const float mean = ((red[0] + red[1]) + (red[2] + red[3])) * (1.0f / ROW_D);
+  const float dl = v - mean;
+  const float s2 = wave_sum(dl * dl);
+  if (lane == 0) red[4 + wave] = s2;
+  __syncthreads();
+  const float rstd = rsqrtf(((red[4] + red[5]) + (red[6] + red[7])) * (1.0f / ROW_D) + 1e-5f);
+  const float xn = dl * rstd * p.ln_w[tid] + p.ln_b[tid];
+  p.xout[(size_t)r * p.ldxo + tid] = xn;
+  if (p.WqT) {
+    sx[tid] = xn;
+    __syncthreads();
+    p.qout[(size_t)r * p.ldqo + tid] = row_gemv256(p.WqT, p.bq, sx, part, tid);
+  }
+}
+
+// WT[k][n] = W[n][k] for a d x d matrix (rows n of W may be a slice of a taller matrix: ldw)
+__global__ void transpose_sq_kernel(const float* W, long ldw, int d, float* WT) {
+  __shared__ float tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  for (int i = threadIdx.y; i < 32; i += 8) tile[i][threadIdx.x] = W[(size_t)(by + i) * ldw + bx + threadIdx.x];
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += 8) WT[(size_t)(bx + i) * d + by + threadIdx.x] = tile[threadIdx.x][i];
+}
+
+// ---------------------------------------------------------------------------------------------
 // Decode-step projection  Y[R, N] = act(A[R, K] W[N, K]^T + bias)  with the producer of A fused in:
 //   PRO_PLAIN : A = X                                   (rows of a previous kernel's output)
 //   PRO_EMBED : A = E[tok[r][t]] * sqrt(d) + pe[t]       (transformer_decoder.py:89-91)
@@ -706,6 +873,7 @@ int launch_ln(const float* x, const float* y, const float* w, const float* b, fl
 // per layer sa_in, sa_out, ca_q, ca_out, l1, l2; then the classifier.
 struct PackLayout {
   size_t sa_in, sa_out, ca_q, ca_out, l1, l2;
+  size_t sa_outT, ca_qT, ca_outT;   // transposed [k][n] copies for the fused per-row sub-layer kernel
 };
 inline size_t packed_floats(int N, int K) { return (size_t)((N + DEC_T - 1) / DEC_T) * DEC_T * K; }
 inline size_t pack_layout(const ac_trm_weights* w, PackLayout* L /* [nlayers] or null */, size_t* cls_off) {
@@ -719,6 +887,9 @@ inline size_t pack_layout(const ac_trm_weights* w, PackLayout* L /* [nlayers] or
     t.ca_out = off; off += packed_floats(d, d);
     t.l1 = off; off += packed_floats(ff, d);
     t.l2 = off; off += packed_floats(d, ff);
+    t.sa_outT = off; off += (size_t)d * d;
+    t.ca_qT = off; off += (size_t)d * d;
+    t.ca_outT = off; off += (size_t)d * d;
     if (L) L[l] = t;
   }
   if (cls_off) *cls_off = off;
@@ -750,6 +921,9 @@ int decoder_step(const ac_trm_weights* w, const float* memkv, const int* mem_len
   g.M = R; g.ntb = 1;
   // pending join carried into the next projection: x_next = LayerNorm(jx + jy) * jw + jb
   const float *jx = nullptr, *jy = nullptr, *jw = nullptr, *jb = nullptr;
+  // the reference's decoder shape (d_model 256 = 4 heads of 64) takes the fused per-row sub-layer kernel: 5 launches per
+  // layer instead of 8; any other shape the general 8-launch sequence
+  const bool fused = d == ROW_D && w->nhead == ROW_H && t + 1 <= MAX_KEYS && Tm <= MAX_KEYS;
   for (int l = 0; l < w->nlayers; ++l) {
     const ac_trm_layer& L = w->layer[l];
     // ---- self attention: QKV projection with the layer input produced in its prologue ----
@@ -770,6 +944,40 @@ int decoder_step(const ac_trm_weights* w, const float* memkv, const int* mem_len
     a.key_len = nullptr; a.key_mask = mask; a.mask_stride = tok_stride;
     a.new_k = ws.qkv + d; a.new_v = ws.qkv + 2 * d; a.ld_new = 3 * d;
     a.out = ws.att; a.ldo = d; a.hd = hd; a.scale = scale;
+    if (fused) {
+      // ---- self attention + out-projection + LN1 + cross query projection: one launch, one row per workgroup ----
+      RowParams rp;
+      rp.a = a;
+      rp.res = xa; rp.ldres = d;
+      rp.WoT = pk + PL[l].sa_outT; rp.bo = L.sa_out_b; rp.ln_w = L.n1_w; rp.ln_b = L.n1_b;
+      rp.xout = xb; rp.ldxo = d;
+      rp.WqT = pk + PL[l].ca_qT; rp.bq = L.ca_in_b; rp.qout = ws.q2; rp.ldqo = d;
+      hipLaunchKernelGGL(dec_row_kernel, dim3(R), dim3(256), 0, s, rp);
+      AC_TRY(ac_check_launch());
+      // ---- cross attention + out-projection + LN2 ----
+      const float* mkf = memkv + (size_t)l * Rm * 2 * d;
+      rp.a.q = ws.q2; rp.a.ldq = d;
+      rp.a.K = mkf; rp.a.V = mkf + d; rp.a.Kw = nullptr; rp.a.Vw = nullptr;
+      rp.a.row_stride = (long)Tm * 2 * d; rp.a.key_stride = 2 * d; rp.a.row_div = row_div; rp.a.nkeys = Tm;
+      rp.a.key_len = mem_len; rp.a.key_mask = nullptr; rp.a.mask_stride = 0;
+      rp.a.new_k = nullptr; rp.a.new_v = nullptr; rp.a.ld_new = 0;
+      rp.res = xb; rp.ldres = d;
+      rp.WoT = pk + PL[l].ca_outT; rp.bo = L.ca_out_b; rp.ln_w = L.n2_w; rp.ln_b = L.n2_b;
+      rp.xout = xa; rp.ldxo = d;
+      rp.WqT = nullptr; rp.bq = nullptr; rp.qout = nullptr; rp.ldqo = 0;
+      hipLaunchKernelGGL(dec_row_kernel, dim3(R), dim3(256), 0, s, rp);
+      AC_TRY(ac_check_launch());
+      // ---- feed forward on the materialised x2 ----
+      g.X = xa; g.ldx = d; g.Wp = pk + PL[l].l1; g.bias = L.l1_b; g.Y = ws.ff; g.ldy = w->dim_ff; g.N = w->dim_ff;
+      g.K = d; g.relu = 1; g.xout = nullptr;
+      AC_TRY(launch_dec_gemm<PRO_PLAIN>(g, s));
+      g.X = ws.ff; g.ldx = w->dim_ff; g.Wp = pk + PL[l].l2; g.bias = L.l2_b; g.Y = ws.tmp; g.ldy = d;
+      g.N = d; g.K = w->dim_ff; g.relu = 0; g.xout = nullptr;
+      AC_TRY(launch_dec_gemm<PRO_PLAIN>(g, s));
+      jx = xa; jy = ws.tmp; jw = L.n3_w; jb = L.n3_b;
+      float* tsw = xa; xa = xb; xb = tsw;
+      continue;
+    }
     hipLaunchKernelGGL(attn_step_kernel, dim3(R, w->nhead), dim3(64), 0, s, a);
     AC_TRY(ac_check_launch());
     g.X = ws.att; g.ldx = d; g.Wp = pk + PL[l].sa_out; g.bias = L.sa_out_b; g.Y = ws.tmp; g.ldy = d;
@@ -876,6 +1084,14 @@ extern "C" int ac_trm_pack_step_weights(const ac_trm_weights* w, float* out, voi
     AC_TRY(pack(L.ca_out_w, d, d, out + PL[l].ca_out));
     AC_TRY(pack(L.l1_w, ff, d, out + PL[l].l1));
     AC_TRY(pack(L.l2_w, d, ff, out + PL[l].l2));
+    if (d % 32 == 0) {
+      const float* src[3] = {L.sa_out_w, L.ca_in_w, L.ca_out_w};
+      const size_t dst[3] = {PL[l].sa_outT, PL[l].ca_qT, PL[l].ca_outT};
+      for (int i = 0; i < 3; ++i) {
+        hipLaunchKernelGGL(transpose_sq_kernel, dim3(d / 32, d / 32), dim3(32, 8), 0, s, src[i], (long)d, d, out + dst[i]);
+        AC_TRY(ac_check_launch());
+      }
+    }
   }
   return pack(w->cls_w, w->vocab, d, out + cls_off);
 }

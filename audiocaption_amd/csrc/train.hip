@@ -414,7 +414,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmP p) {
   __bf16* dst_hi = isB ? sB[0] : sA[0];
   __bf16* dst_lo = isB ? sB[1] : sA[1];
   (void)ROWS;
+  // optional per-(row group, k) multiplier on A (the squeeze-excite gate of EfficientNet's projection convs), k-fast A only
+  const bool scaled = !isB && p.a_scale != nullptr;
   float pre[8][4];   // scalar registers only (every index below is a compile-time constant after unrolling)
+  float gate[8][4];
   auto ld4 = [&](float (&d)[4], const float* src, bool ok) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ok) v = *(const float4*)src;
@@ -431,6 +434,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmP p) {
         const float* src = base + (long)gr * s_row;
         ld4(pre[2 * j], src + min(gk, kend - 4), ok && gk < kend);
         ld4(pre[2 * j + 1], src + min(gk + 4, kend - 4), ok && gk + 4 < kend);
+        if (scaled) {
+          const float* gs = p.a_scale + (long)(gr / p.a_rows) * p.K;
+          ld4(gate[2 * j], gs + min(gk, kend - 4), ok && gk < kend);
+          ld4(gate[2 * j + 1], gs + min(gk + 4, kend - 4), ok && gk + 4 < kend);
+        }
       }
     } else {
       // item (4 rows, kg): rg = u % (rows / 4) (consecutive lanes -> consecutive rows), kg = u / (rows / 4): one item per
@@ -452,8 +460,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmP p) {
       for (int j = 0; j < 4; ++j) {
         const int idx = u + 128 * j, row = idx >> 2, kg = idx & 3;
         if (row >= rows) continue;
-        const float x[8] = {pre[2 * j][0], pre[2 * j][1], pre[2 * j][2], pre[2 * j][3],
-                            pre[2 * j + 1][0], pre[2 * j + 1][1], pre[2 * j + 1][2], pre[2 * j + 1][3]};
+        float x[8] = {pre[2 * j][0], pre[2 * j][1], pre[2 * j][2], pre[2 * j][3],
+                      pre[2 * j + 1][0], pre[2 * j + 1][1], pre[2 * j + 1][2], pre[2 * j + 1][3]};
+        if (scaled) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { x[e] *= gate[2 * j][e]; x[4 + e] *= gate[2 * j + 1][e]; }
+        }
         gb_u32x4 hi, lo;
         gb_split8(x, hi, lo);
         *(gb_u32x4*)(dst_hi + row * GB_ROW + kg * 8) = hi;
@@ -1307,18 +1319,20 @@ static bool gb_operand_ok(const float* base, long s_row, long s_k, int rows, int
 
 int ac_gemm_bf16x3(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc, int M,
                    int N, int K, const float* bias, int relu, float beta, int splitk, float drop_p,
-                   unsigned long long drop_seed, const unsigned long long* seed_dev, long row0, void* stream) {
-  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || relu < 0 || relu > 3) return AC_ERR_ARG;
+                   unsigned long long drop_seed, const unsigned long long* seed_dev, long row0, const float* a_scale,
+                   int a_rows, void* stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || relu < 0 || relu > 3 || (a_scale && a_rows <= 0)) return AC_ERR_ARG;
   if (splitk > 1 && (bias || relu || drop_p > 0.f || beta != 1.0f)) return AC_ERR_ARG;
   // small or oddly laid out products: the exact-f32 kernels (a split-bf16 tile would be mostly padding / latency)
   const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64) * (splitk < 1 ? 1 : splitk);
-  if ((double)M * N * K < 3.0e7 || t64 < 200 || !gb_operand_ok(A, sam, sak, M, K) || !gb_operand_ok(B, sbn, sbk, N, K))
+  if ((double)M * N * K < 3.0e7 || t64 < 200 || !gb_operand_ok(A, sam, sak, M, K) || !gb_operand_ok(B, sbn, sbk, N, K) ||
+      (a_scale && (sak != 1 || ((uintptr_t)a_scale & 15) != 0)))
     return ac_gemm(A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, bias, relu, beta, splitk, drop_p, drop_seed, seed_dev, row0,
-                   nullptr, 0, stream);
+                   a_scale, a_rows, stream);
   GemmP p;
   p.A = A; p.sam = sam; p.sak = sak; p.B = B; p.sbk = sbk; p.sbn = sbn; p.C = C; p.ldc = ldc;
   p.M = M; p.N = N; p.K = K; p.bias = bias; p.relu = relu; p.beta = beta;
-  p.a_scale = nullptr; p.a_rows = 0;
+  p.a_scale = a_scale; p.a_rows = a_rows;
   p.splitk = splitk < 1 ? 1 : splitk;
   p.drop = make_drop(drop_p, drop_seed, seed_dev);
   p.row0 = row0;

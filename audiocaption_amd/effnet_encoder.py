@@ -103,6 +103,10 @@ class _EffiNet(nn.Module):
         self.eff_net = EfficientNet()
 
 
+# 1x1 convolutions on the LDS-tiled GEMM: "bf16x3" (default) = split-bf16 operands on the bf16 MFMA, "f32" = exact f32 MFMA
+GEMM_ALGO = os.environ.get("AUDIOCAPTION_EFFB2_GEMM", "bf16x3")
+
+
 def _fold(bn):
     scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
     return scale, bn.bias.detach().float() - bn.running_mean.detach().float() * scale
@@ -185,6 +189,11 @@ class EfficientNetB2(nn.Module):
         if M >= 400000 or (M >= 100000 and Kd <= 64):
             check(lib.ac_pointwise_conv(ptr(x), ptr(w), ptr(bias), ptr(y), M, N, Kd, act, beta, ptr(a_scale), a_rows,
                                         stream()), "ac_pointwise_conv")
+        elif GEMM_ALGO == "bf16x3":
+            # the late 1x1 convolutions are matrix-bound in f32 (65-90 TFLOP/s on the exact-f32 MFMA): split-bf16
+            # operands (2^-16), f32 accumulation; small products are forwarded to the exact-f32 kernels by the library
+            check(lib.ac_gemm_bf16x3(ptr(x), Kd, 1, ptr(w), 1, Kd, ptr(y), N, M, N, Kd, ptr(bias), act, beta, 1, 0.0, 0, None,
+                                     0, ptr(a_scale), a_rows, stream()), "ac_gemm_bf16x3")
         else:
             check(lib.ac_gemm(ptr(x), Kd, 1, ptr(w), 1, Kd, ptr(y), N, M, N, Kd, ptr(bias), act, beta, 1, 0.0, 0, None, 0,
                               ptr(a_scale), a_rows, stream()), "ac_gemm")

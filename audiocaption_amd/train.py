@@ -204,7 +204,7 @@ class TrainEngine:
         if self.gemm_algo == "bf16x3":
             # split-bf16 operands (2^-16), f32 accumulation; small or unaligned products fall through to exact f32
             check(self.lib.ac_gemm_bf16x3(A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, bias, relu, beta, splitk, drop_p, seed,
-                                          self._seed_ptr, row0, s), "ac_gemm_bf16x3")
+                                          self._seed_ptr, row0, None, 0, s), "ac_gemm_bf16x3")
         else:
             check(self.lib.ac_gemm(A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, bias, relu, beta, splitk, drop_p, seed,
                                    self._seed_ptr, row0, None, 0, s), "ac_gemm")

@@ -243,14 +243,15 @@ int ac_trm_beam_reorder(const ac_trm_weights* w, int R, int max_len, int t, cons
 int ac_gemm(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc, int M, int N,
             int K, const float* bias, int relu, float beta, int splitk, float drop_p, unsigned long long drop_seed,
             const unsigned long long* seed_dev, long row0, const float* a_scale, int a_rows, void* stream);
-/* The same contract (without the a_scale operand) on split-bf16 operands: every f32 operand is split into bf16 hi + lo
+/* The same contract on split-bf16 operands: every f32 operand is split into bf16 hi + lo
  * when it is staged (16 significant bits), three bf16 MFMAs per product, f32 accumulation - 2^-16 relative operand error
  * at ~5x the f32 matrix rate.  Used for the large GEMMs of the training step (backward dY W / dY^T X over 7 392 rows,
  * teacher-forced forward).  Operands must be contiguous along k or along their row dimension with 16-byte aligned rows;
  * anything else, and products under ~3e7 multiply-adds or under 200 tiles of 64 x 64, are forwarded to ac_gemm (exact f32). */
 int ac_gemm_bf16x3(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc, int M,
                    int N, int K, const float* bias, int relu, float beta, int splitk, float drop_p,
-                   unsigned long long drop_seed, const unsigned long long* seed_dev, long row0, void* stream);
+                   unsigned long long drop_seed, const unsigned long long* seed_dev, long row0, const float* a_scale,
+                   int a_rows, void* stream);
 /* y[i] = x[i] * mask(seed, idx0 + i): F.dropout (cnn_encoder.py:432-442, nn.GRU inter-layer dropout); applying it to
  * a gradient with the same seed is its backward. */
 int ac_dropout(const float* x, float* y, long n, float p, unsigned long long seed, const unsigned long long* seed_dev,

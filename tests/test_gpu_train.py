@@ -81,12 +81,13 @@ def test_split_bf16_gemm_all_layouts(lib, M, N, K):
     b = torch.randn(N, generator=g)
     xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
     y = torch.empty(M, N, device="cuda")
-    assert lib.ac_gemm_bf16x3(P(xd), K, 1, P(wd), 1, K, P(y), N, M, N, K, P(bd), 1, 0.0, 1, 0.0, 0, None, 0, S()) == 0
+    assert lib.ac_gemm_bf16x3(P(xd), K, 1, P(wd), 1, K, P(y), N, M, N, K, P(bd), 1, 0.0, 1, 0.0, 0, None, 0, None, 0, S()) == 0
     assert rel("bf16x3: x w^T + b, relu", y, torch.relu(x.double() @ w.double().t() + b.double())) < 3e-5
     dy = torch.randn(M, N, generator=g)
     dx0 = torch.randn(M, K, generator=g)
     dx = dx0.cuda()
-    assert lib.ac_gemm_bf16x3(P(dy.cuda()), N, 1, P(wd), K, 1, P(dx), K, M, K, N, None, 0, 1.0, 1, 0.0, 0, None, 0, S()) == 0
+    assert lib.ac_gemm_bf16x3(P(dy.cuda()), N, 1, P(wd), K, 1, P(dx), K, M, K, N, None, 0, 1.0, 1, 0.0, 0, None, 0, None, 0,
+                              S()) == 0
     assert rel("bf16x3: dy w + dx0", dx, dy.double() @ w.double() + dx0.double()) < 3e-5
     dyp = torch.randn(M, N + 24, generator=g)
     xp = torch.randn(M, K + 8, generator=g)
@@ -94,7 +95,7 @@ def test_split_bf16_gemm_all_layouts(lib, M, N, K):
         dw0 = torch.randn(N, K, generator=g)
         dw = dw0.cuda()
         assert lib.ac_gemm_bf16x3(P(dyp.cuda()), 1, N + 24, P(xp.cuda()), K + 8, 1, P(dw), K, N, K, M, None, 0, 1.0, splitk,
-                                  0.0, 0, None, 0, S()) == 0
+                                  0.0, 0, None, 0, None, 0, S()) == 0
         want = dyp[:, :N].double().t() @ xp[:, :K].double() + dw0.double()
         assert rel(f"bf16x3: dy^T x split-K {splitk}", dw, want) < 3e-5
     # a layout it cannot take (rows of 4981 floats are not 16-byte aligned) is forwarded to the exact-f32 kernels
@@ -103,8 +104,18 @@ def test_split_bf16_gemm_all_layouts(lib, M, N, K):
     wc = torch.randn(V, 256, generator=g)
     dxl = torch.empty(672, 256, device="cuda")
     assert lib.ac_gemm_bf16x3(P(dl.cuda()), V, 1, P(wc.cuda()), 256, 1, P(dxl), 256, 672, 256, V, None, 0, 0.0, 1, 0.0, 0,
-                              None, 0, S()) == 0
+                              None, 0, None, 0, S()) == 0
     assert rel("forwarded: dl w_cls", dxl, dl.double() @ wc.double()) < 1e-5
+    # the squeeze-excite form of EfficientNet's projection convs: y = res + swish?(x .* gate[row group]) w^T + b
+    rows_per = 64
+    G = (M + rows_per - 1) // rows_per
+    gate = torch.rand(G, K, generator=g)
+    res = torch.randn(M, N, generator=g)
+    yg = res.clone().cuda()
+    assert lib.ac_gemm_bf16x3(P(xd), K, 1, P(wd), 1, K, P(yg), N, M, N, K, P(bd), 0, 1.0, 1, 0.0, 0, None, 0, P(gate.cuda()),
+                              rows_per, S()) == 0
+    xg = x.double() * gate.double().repeat_interleave(rows_per, 0)[:M]
+    assert rel("bf16x3: gated x w^T + b + res", yg, res.double() + xg @ w.double().t() + b.double()) < 3e-5
 
 
 def test_dropout_hash_is_the_oracles(lib):

@@ -29,7 +29,7 @@ for name, M, N, K, lay in shapes:
         sk = max(1, min(512 // blocks, K // 128))
     beta = 1.0 if sk > 1 else 0.0
     res = []
-    for fn, extra in ((lib.ac_gemm, (None, 0)), (lib.ac_gemm_bf16x3, ())):
+    for fn, extra in ((lib.ac_gemm, (None, 0)), (lib.ac_gemm_bf16x3, (None, 0))):
         call = lambda: fn(P(A), sa[0], sa[1], P(B), sb[0], sb[1], P(C), N, M, N, K, None, 0, beta, sk, 0.0, 0, None, 0, *extra, S())
         for _ in range(3):
             assert call() == 0
