@@ -713,7 +713,7 @@ __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(Conv
     // An item is 16 bytes of one pixel: 4 f32 channels (PREC 0) or 8 fp16 channels (PREC 1, copied as they are).
     constexpr int IPP = PREC == 0 ? 8 : 4;          // items per pixel and 32-channel chunk
     // >= ceil(NPIX * IPP / 256); 256-pixel blocks: TC = 16 -> 324 pixels, 8 -> 340, 4 -> 396, 2 -> 520
-    constexpr int GW_MAXIT = PREC == 0 ? 9 : (BM == 128 ? 5 : (COLT == 2 ? 9 : 7));
+    constexpr int GW_MAXIT = PREC == 0 ? (BM == 128 ? 9 : 11) : (BM == 128 ? 5 : (COLT == 2 ? 9 : 7));
     constexpr unsigned GW_NONE = 0xffffffffu, GW_OOB = 0x80000000u;
     unsigned goff[GW_MAXIT], loff[GW_MAXIT];
 #pragma unroll
@@ -860,8 +860,10 @@ __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(Conv
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8 ah[MW], al[MW];
+        constexpr bool LATE_A = PREC == 0 && MW >= 8;   // split-bf16 with 8 tiles: fragments are read tile by tile below
 #pragma unroll
         for (int m = 0; m < MW; ++m) {
+          if (LATE_A) continue;
           if (COLT && ((kx == 0 && m % (COLT ? COLT : 1) == 0 && at_left) ||
                        (kx == 2 && m % (COLT ? COLT : 1) == COLT - 1 && at_right))) continue;
           ah[m] = *(const bf16x8*)(sAh + aoff + pbase[m] + ks * 16);
@@ -872,6 +874,10 @@ __global__ __launch_bounds__(256, BM == 128 ? 3 : 2) void conv3x3_gw_kernel(Conv
           // column tile whose tap reads the zero padding beside the image: nothing to add
           if (COLT && ((kx == 0 && m % (COLT ? COLT : 1) == 0 && at_left) ||
                        (kx == 2 && m % (COLT ? COLT : 1) == COLT - 1 && at_right))) continue;
+          if (LATE_A) {
+            ah[m] = *(const bf16x8*)(sAh + aoff + pbase[m] + ks * 16);
+            al[m] = *(const bf16x8*)(sAl + aoff + pbase[m] + ks * 16);
+          }
 #pragma unroll
           for (int n = 0; n < NTW; ++n) {
             if (PREC == 0) {
@@ -1146,6 +1152,15 @@ static int conv_gw_dispatch(int prec, const float* in, const void* wfrag, const 
     if (BN == 128 && colt0 && TC == 4) {
       if (mode == MODE_FULL) return launch_conv_gw<128, MODE_FULL, 0, 1, 128, false, 9, 4>(p, s);
       if (mode == MODE_POOL) return launch_conv_gw<128, MODE_POOL, 0, 1, 128, false, 9, 4>(p, s);
+    }
+    // 8 and more columns: 256-pixel column-tile blocks (8 columns x 32 rows), a wave walks eight tiles per weight
+    // fragment - what took the fp16 tier from 5.08 to 4.32 ms, for the split-bf16 tier
+    static const bool colt0_8 = getenv("AC_GW_NO_COLT0_8") == nullptr;
+    if (BN == 128 && colt0 && colt0_8 && W >= 8 && mode != MODE_MEANW) {
+      p.tc_log2 = 3;
+      p.mt_cols = W / 8;
+      if (mode == MODE_FULL) return launch_conv_gw<128, MODE_FULL, 0, 1, 256, false, 9, 8>(p, s);
+      return launch_conv_gw<128, MODE_POOL, 0, 1, 256, false, 9, 8>(p, s);
     }
     if (BN == 128) {
       if (mode == MODE_FULL) return launch_conv_gw<128, MODE_FULL>(p, s);
