@@ -50,11 +50,19 @@ class CrnnEncoder(nn.Module):
         return self
 
     def forward(self, input_dict):
+        return self.forward_back(self.forward_front(input_dict))
+
+    # The two halves of forward(), so that a caller can put them on different streams (TransformerModel.forward_async:
+    # the matrix-bound convolutions of the NEXT batch overlap the latency-bound recurrence of this one).
+    def forward_front(self, input_dict):
         # Cnn14's own fc_emb is dead in this pipeline (the RNN recomputes it): skip its kernels.
         feats, overflow = _run_cnn(self.cnn, self._skip_fc, input_dict)
-        out = self.rnn(feats)
-        if overflow is not None:
-            out["f16_overflow"] = overflow   # fp16 range flag of the conv tier (see Cnn14Encoder.forward)
+        return {"feats": feats, "overflow": overflow}
+
+    def forward_back(self, front):
+        out = self.rnn(front["feats"])
+        if front["overflow"] is not None:
+            out["f16_overflow"] = front["overflow"]   # fp16 range flag of the conv tier (see Cnn14Encoder.forward)
         return out
 
 

@@ -102,22 +102,24 @@ __global__ __launch_bounds__(768) void gru_layer_kernel(GruParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The recurrence of ONE (clip, direction) split over TWO workgroups (two CUs).  A CU cannot hold the 786 KB recurrent
+// The recurrence of ONE (clip, direction) split over FOUR workgroups of 256 threads.  A CU cannot hold the 786 KB recurrent
 // matrix (the single-workgroup kernel above re-streams 44 % of it from L2 every step, which is its whole critical
-// path), but half of it fits in the registers of one CU: workgroup `half` owns the hidden units [128 half, 128 half +
-// 128) - the 384 gate rows r_j, z_j, n_j of those units, two threads per row with 128 k each in VGPRs - and never reads
-// a weight again after the prologue.  Per step the two halves trade their 128 new hidden values through L2 as 8-byte
-// {tag, value} granules (one relaxed agent-scope atomic store each, the value IS the flag; the consumer's 128 polling
-// threads re-read their own granule until the tag is this step's - cdna_hip_programming.md section 6 Guideline 16, form
-// R2: no fences, correct for any workgroup -> XCD placement).  Slots alternate with the step parity: a producer cannot
-// reach step s + 2 before it has consumed the partner's step s + 1, which the partner published after consuming the
-// producer's step s.
-// Partners are paired by START ORDER, not by block index (HIP promises no dispatch order): every workgroup draws a
-// ticket, tickets 2p and 2p + 1 form pair p.  At any time at most one started workgroup is without its partner, and that
-// partner is the next workgroup to start - all other resident workgroups are complete pairs that finish on their own,
-// so the scheme cannot deadlock however the blocks are dispatched; a spin that outlasts GRU_SPIN_TICKS all the same
-// (another process holding the GPU ...) raises the error word instead of hanging.
-// The 64-clip bench batch uses all 256 CUs this way (the single-workgroup kernel only 128): 175 -> ~60 us per layer.
+// path); a quarter of it fits in the registers of four waves: workgroup `part` owns the hidden units [64 part, 64 part +
+// 64); thread (unit j = tid / 4, k quarter kq = tid % 4) holds the r, z and n rows of its unit for k in [64 kq, 64 kq + 64)
+// - 192 weights in VGPRs, read once - so the three gate sums of a unit are complete after a 4-lane DPP reduction and the
+// lane kq = 0 computes the new hidden value straight away (no gate round trip through LDS).  Per step the four parts
+// trade their 64 new hidden values through L2 as 8-byte {tag, value} granules (one relaxed agent-scope atomic store each,
+// the value IS the flag; the 192 lanes kq != 0 each poll ONE granule of another part until the tag is this step's -
+// cdna_hip_programming.md section 6 Guideline 16, form R2: no fences, correct for any workgroup -> XCD placement).  Slots
+// alternate with the step parity: a producer cannot reach step s + 2 before it has consumed every partner's step s + 1,
+// which they published after consuming the producer's step s.
+// Partners are grouped by START ORDER, not by block index (HIP promises no dispatch order): every workgroup draws a
+// ticket, tickets 4g .. 4g + 3 form group g.  At any time at most one group is incomplete, and its missing members are the
+// next workgroups to start - all other resident workgroups belong to complete groups that finish on their own, so the
+// scheme cannot deadlock however the blocks are dispatched; a spin that outlasts GRU_SPIN_TICKS all the same (another
+// process holding the GPU ...) raises the error word instead of hanging.
+// One wave per SIMD and <= 242 VGPRs on purpose: a workgroup fits the slot one conv workgroup of the encoder leaves on
+// a CU, two fit a CU: the 512 workgroups of a 64-clip batch are resident together on the 256 CUs.
 // ---------------------------------------------------------------------------------------------------------------------
 struct GruSplitParams {
   const float* gx;     // [B][T][2][3H]
@@ -125,73 +127,80 @@ struct GruSplitParams {
   const float* bhh;    // [2][3H]
   const int* lens;     // [B]
   float* out;          // [B][T][2H]
-  unsigned long long* xch;   // [2B pairs][2 halves][2 slots][128] granules, zeroed before every launch
+  unsigned long long* xch;   // [2B groups][4 parts][2 slots][64] granules, zeroed before every launch
   unsigned* ticket;          // zeroed before every launch
   unsigned* error;           // set to 1 when a partner never showed up
   int B, T;
 };
-constexpr int HH = H / 2;                      // hidden units per workgroup
+constexpr int GQ = 4, HQ = H / GQ;              // parts per (clip, direction); hidden units per part
+constexpr int HQP = HQ + 4;                      // LDS pitch of a quarter of h: the four k quarters hit different banks
 constexpr long long GRU_SPIN_TICKS = 200000000;   // 2 s of the 100 MHz wall clock
 
-__global__ __launch_bounds__(768) void gru_layer_split_kernel(GruSplitParams p) {
-  __shared__ __attribute__((aligned(16))) float sh[H];
-  __shared__ float sg[3 * HH];
+__global__ __launch_bounds__(256) void gru_layer_split_kernel(GruSplitParams p) {
+  __shared__ __attribute__((aligned(16))) float sh[GQ * HQP];
   __shared__ unsigned s_ticket;
   const int n = threadIdx.x;
   if (n == 0) s_ticket = atomicAdd(p.ticket, 1u);
   __syncthreads();
-  const int pair = (int)(s_ticket >> 1), half = (int)(s_ticket & 1u);
-  const int b = pair >> 1, dir = pair & 1;
+  const int group = (int)(s_ticket >> 2), part = (int)(s_ticket & 3u);
+  const int b = group >> 1, dir = group & 1;
   if (b >= p.B) return;
   int len = p.lens[b];
   len = len < 0 ? 0 : (len > p.T ? p.T : len);
-  // thread n: local gate row rr = n / 2 (gate g = rr / 128 of hidden unit j = rr % 128), k half kh = n % 2
-  const int rr = n >> 1, kh = n & 1;
-  const int g = rr / HH, j = rr - g * HH;
-  const int row = g * H + half * HH + j;                 // row of W_hh / b_hh of this direction
-  float4 w[HH / 4];
+  const int j = n >> 2, kq = n & 3;
+  const int unit = part * HQ + j;                          // hidden unit of this thread
+  float4 w[3][HQ / 4];
   if (len > 0) {
-    const float4* wp = (const float4*)(p.whh + ((size_t)dir * 3 * H + row) * H + kh * HH);
 #pragma unroll
-    for (int q = 0; q < HH / 4; ++q) w[q] = wp[q];
+    for (int g = 0; g < 3; ++g) {
+      const float4* wp = (const float4*)(p.whh + ((size_t)dir * 3 * H + g * H + unit) * H + kq * HQ);
+#pragma unroll
+      for (int q = 0; q < HQ / 4; ++q) w[g][q] = wp[q];
+    }
   }
-  const float bias = p.bhh[dir * 3 * H + row];
-  if (n < H) sh[n] = 0.f;
-  unsigned long long* mine = p.xch + ((size_t)(pair * 2 + half) * 2) * HH;
-  unsigned long long* theirs = p.xch + ((size_t)(pair * 2 + (1 - half)) * 2) * HH;
+  const float br = p.bhh[dir * 3 * H + unit], bz = p.bhh[dir * 3 * H + H + unit], bn = p.bhh[dir * 3 * H + 2 * H + unit];
+  for (int i = n; i < GQ * HQP; i += 256) sh[i] = 0.f;
+  unsigned long long* mine = p.xch + ((size_t)(group * GQ + part) * 2) * HQ;
+  // the lanes kq = 1..3 of unit j fetch value j of part (part + kq) % 4
+  const int other = (part + kq) & 3;
+  unsigned long long* theirs = p.xch + ((size_t)(group * GQ + other) * 2) * HQ;
   __syncthreads();
   for (int step = 0; step < len; ++step) {
     const int t = dir ? (len - 1 - step) : step;
-    const float* gxp = p.gx + (((size_t)b * p.T + t) * 2 + dir) * 3 * H + half * HH;
+    const float* gxp = p.gx + (((size_t)b * p.T + t) * 2 + dir) * 3 * H + unit;
     float gr = 0.f, gz = 0.f, gn = 0.f;
-    if (n < HH) { gr = gxp[n]; gz = gxp[H + n]; gn = gxp[2 * H + n]; }
-    float acc = 0.f;
-    const float4* hp = (const float4*)(sh + kh * HH);
+    if (kq == 0) { gr = gxp[0]; gz = gxp[H]; gn = gxp[2 * H]; }
+    float ar = 0.f, az = 0.f, an = 0.f;
+    const float4* hp = (const float4*)(sh + kq * HQP);
 #pragma unroll
-    for (int q = 0; q < HH / 4; ++q) {
+    for (int q = 0; q < HQ / 4; ++q) {
       const float4 hv = hp[q];
-      acc = fmaf(w[q].x, hv.x, acc);
-      acc = fmaf(w[q].y, hv.y, acc);
-      acc = fmaf(w[q].z, hv.z, acc);
-      acc = fmaf(w[q].w, hv.w, acc);
+      ar = fmaf(w[0][q].x, hv.x, ar); ar = fmaf(w[0][q].y, hv.y, ar); ar = fmaf(w[0][q].z, hv.z, ar); ar = fmaf(w[0][q].w, hv.w, ar);
+      az = fmaf(w[1][q].x, hv.x, az); az = fmaf(w[1][q].y, hv.y, az); az = fmaf(w[1][q].z, hv.z, az); az = fmaf(w[1][q].w, hv.w, az);
+      an = fmaf(w[2][q].x, hv.x, an); an = fmaf(w[2][q].y, hv.y, an); an = fmaf(w[2][q].z, hv.z, an); an = fmaf(w[2][q].w, hv.w, an);
     }
-    acc += dpp_mov<DPP_QUAD_XOR1>(acc);                  // the two k halves of a row sit in neighbouring lanes
-    if (kh == 0) sg[rr] = acc + bias;
-    __syncthreads();
+    // the four k quarters of a unit sit in four neighbouring lanes
+    ar += dpp_mov<DPP_QUAD_XOR1>(ar); ar += dpp_mov<DPP_QUAD_XOR2>(ar);
+    az += dpp_mov<DPP_QUAD_XOR1>(az); az += dpp_mov<DPP_QUAD_XOR2>(az);
+    an += dpp_mov<DPP_QUAD_XOR1>(an); an += dpp_mov<DPP_QUAD_XOR2>(an);
+    const float hold = sh[part * HQP + j];
+    __syncthreads();                                   // every wave has read h(t-1): it may be overwritten now
     const unsigned tag = (unsigned)step + 1u;
-    if (n < HH) {
-      const float r = sigmoidf_(gr + sg[n]);
-      const float z = sigmoidf_(gz + sg[HH + n]);
-      const float c = tanhf(gn + r * sg[2 * HH + n]);
-      const float hn = (1.0f - z) * c + z * sh[half * HH + n];
-      __hip_atomic_store(mine + (step & 1) * HH + n, ((unsigned long long)tag << 32) | __float_as_uint(hn),
+    if (kq == 0) {
+      const float r = sigmoidf_(gr + ar + br);
+      const float z = sigmoidf_(gz + az + bz);
+      const float c = tanhf(gn + r * (an + bn));
+      const float hn = (1.0f - z) * c + z * hold;
+      __hip_atomic_store(mine + (step & 1) * HQ + j, ((unsigned long long)tag << 32) | __float_as_uint(hn),
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      sh[half * HH + n] = hn;
-      p.out[((size_t)b * p.T + t) * 2 * H + dir * H + half * HH + n] = hn;
-    } else if (n < 2 * HH && step + 1 < len) {
-      // the partner's half of h_t (not needed after the last step)
-      const int jj = n - HH;
-      unsigned long long* gq = theirs + (step & 1) * HH + jj;
+      sh[part * HQP + j] = hn;
+      p.out[((size_t)b * p.T + t) * 2 * H + dir * H + unit] = hn;
+    }
+    // A SEPARATE statement, not an else-branch: publishers (kq = 0) and pollers share waves, and a wave that entered the
+    // polling side first would spin while its own publishing lanes are masked off - every part waiting for every other.
+    if (kq != 0 && step + 1 < len) {
+      // another part's value j of h(t) (not needed after the last step)
+      unsigned long long* gq = theirs + (step & 1) * HQ + j;
       unsigned long long x = __hip_atomic_load(gq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if ((unsigned)(x >> 32) != tag) {
         const long long t0 = wall_clock64();
@@ -204,12 +213,12 @@ __global__ __launch_bounds__(768) void gru_layer_split_kernel(GruSplitParams p) 
           }
         } while ((unsigned)(x >> 32) != tag);
       }
-      sh[(1 - half) * HH + jj] = __uint_as_float((unsigned)x);
+      sh[other * HQP + j] = __uint_as_float((unsigned)x);
     }
     __syncthreads();
   }
-  if (n < HH)
-    for (int t = len; t < p.T; ++t) p.out[((size_t)b * p.T + t) * 2 * H + dir * H + half * HH + n] = 0.f;
+  if (kq == 0)
+    for (int t = len; t < p.T; ++t) p.out[((size_t)b * p.T + t) * 2 * H + dir * H + unit] = 0.f;
 }
 
 // fc_emb[b][c] = sum_{t < len[b]} x[b][t][c] / len[b]   (model_util.py:41-63 mean_with_lens)
@@ -272,17 +281,17 @@ extern "C" int ac_gru_layer(const float* gx, const float* whhT, const float* bhh
   return ac_check_launch();
 }
 
-// Workspace of ac_gru_layer_split in bytes: [error word, sticky][pad to 64][ticket][pad to 128][granules [2B][2][2][128] x 8].
+// Workspace of ac_gru_layer_split in bytes: [error word, sticky][pad to 64][ticket][pad to 128][granules [2B][4][2][64] x 8].
 // The error word sits at offset 0 whatever B is, so a workspace sized for a large batch can serve a small one.
 extern "C" long ac_gru_split_workspace_bytes(int B) {
   if (B <= 0) return AC_ERR_ARG;
-  return 128 + (long)B * 2 * 2 * 2 * HH * 8;
+  return 128 + (long)B * 2 * GQ * 2 * HQ * 8;
 }
 
 extern "C" int ac_gru_layer_split(const float* gx, const float* whh, const float* bhh, const int* lens, float* out,
                                   void* workspace, int B, int T, int hidden, void* stream) {
   if (!gx || !whh || !bhh || !lens || !out || !workspace || B <= 0 || T <= 0 || hidden != H) return AC_ERR_ARG;
-  const size_t gran = (size_t)B * 2 * 2 * 2 * HH * 8;
+  const size_t gran = (size_t)B * 2 * GQ * 2 * HQ * 8;
   GruSplitParams p;
   p.gx = gx; p.whh = whh; p.bhh = bhh; p.lens = lens; p.out = out; p.B = B; p.T = T;
   p.error = (unsigned*)workspace;
@@ -290,7 +299,7 @@ extern "C" int ac_gru_layer_split(const float* gx, const float* whh, const float
   p.xch = (unsigned long long*)((char*)workspace + 128);
   // granules and the ticket start from zero on EVERY launch (a memset node when captured); the error word is sticky
   if (hipMemsetAsync((char*)workspace + 64, 0, 64 + gran, (hipStream_t)stream) != hipSuccess) return AC_ERR_LAUNCH;
-  hipLaunchKernelGGL(gru_layer_split_kernel, dim3(4 * B), dim3(768), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(gru_layer_split_kernel, dim3(2 * GQ * B), dim3(256), 0, (hipStream_t)stream, p);
   return ac_check_launch();
 }
 

@@ -297,7 +297,7 @@ def gru_layer(gx, whhT, bhh, lens_i32, B, T, hidden):
 
 
 def gru_layer_split(gx, whh, bhh, lens_i32, B, T, hidden, workspace=None):
-    """The recurrence with every (clip, direction) split over two CUs (W_hh fully register resident).  ``whh``: the
+    """The recurrence with every (clip, direction) split over four 256-thread workgroups (W_hh register resident).  ``whh``: the
     UNPACKED [2][3H][H] weights.  Returns (out, workspace); ``gru_split_error(workspace)`` is its sticky error word."""
     lib = _lib.load()
     need = lib.ac_gru_split_workspace_bytes(B)

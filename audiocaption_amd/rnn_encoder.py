@@ -39,13 +39,11 @@ class RnnEncoder(nn.Module):
                               bidirectional=True, dropout=self.dropout, batch_first=True)
         self._packed = None
         self._packed_key = None
-        # "split" (default): every (clip, direction) runs on two CUs with W_hh register resident (csrc/gru.hip
-        # gru_layer_split_kernel); "single": one workgroup per (clip, direction), 44 % of W_hh re-streamed per step
-        # "auto" (default): "split" for a blocking call, "single" when the caller says the chip is shared with another
-        # stream's work (``forward_async`` passes gru_algo="single": 4 x 64 split workgroups need every CU at once and
-        # lose more to the decode chain of the previous batch than they gain - 6.04 vs 5.81 ms per step - while the
-        # blocking call gains 0.2 ms).  The two kernels differ in summation order only (~2e-6).
-        self.gru_algo = os.environ.get("AUDIOCAPTION_GRU_ALGO", "auto")
+        # "split" (default): every (clip, direction) on four workgroups of 256 threads with W_hh register resident
+        # (csrc/gru.hip gru_layer_split_kernel: 79 us per layer at 64 clips x 31 steps); "single": one 768-thread
+        # workgroup per (clip, direction), 44 % of W_hh re-streamed per step (156 us).  They differ in summation order only
+        # (~2e-6).  ``input_dict["gru_algo"]`` overrides it for one call.
+        self.gru_algo = os.environ.get("AUDIOCAPTION_GRU_ALGO", "split")
         self._split_ws = None
 
     def _pack(self):
@@ -78,7 +76,7 @@ class RnnEncoder(nn.Module):
             raise ValueError("attn_len must lie in [1, attn.size(1)]")
         lens_dev = K.upload(lens, x.device, torch.int32)
         h = K.f32c(x).reshape(B * T, -1)
-        algo = self.gru_algo if self.gru_algo != "auto" else input_dict.get("gru_algo", "split")
+        algo = input_dict.get("gru_algo", self.gru_algo)
         split = algo == "split"
         for (w_ih, b_ih, whhT, bhh, whh) in self._pack():
             gx = K.linear(h, w_ih, b_ih)                       # (B*T, 2*3H): all steps, both directions

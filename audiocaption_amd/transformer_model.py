@@ -206,11 +206,23 @@ class TransformerModel(CaptionModel):
         enc_s, dec_s = self._streams
         cur = torch.cuda.current_stream(dev)
         enc_s.wait_stream(cur)  # inputs produced on the caller's stream
+        # AUDIOCAPTION_GRU_STREAM=decode runs a composite encoder (CrnnEncoder) in two halves: the convolutions on the encoder
+        # stream, the GRU at the head of the decode chain on the decode stream.  Measured SLOWER (6.05 vs 5.83 ms per step:
+        # the recurrence's workgroups wait for conv workgroups to leave), so the default keeps the encoder on one stream.
+        split_enc = hasattr(self.encoder, "forward_front") and os.environ.get("AUDIOCAPTION_GRU_STREAM", "encoder") == "decode"
         with torch.cuda.stream(enc_s):
-            # the chip is shared with the previous batch's decode chain: the one-workgroup GRU recurrence (see RnnEncoder)
-            enc = self.encoder(dict(input_dict, gru_algo=input_dict.get("gru_algo", "single")))
+            enc = self.encoder.forward_front(input_dict) if split_enc else self.encoder(input_dict)
             enc_done = torch.cuda.Event()
             enc_done.record(enc_s)
+        if split_enc:
+            with torch.cuda.stream(dec_s):
+                dec_s.wait_event(enc_done)
+                for t in enc["feats"].values():
+                    if isinstance(t, torch.Tensor) and t.is_cuda:
+                        t.record_stream(dec_s)
+                enc = self.encoder.forward_back(enc)
+                enc_done = torch.cuda.Event()
+                enc_done.record(dec_s)
         max_length = int(input_dict.get("max_length", self.max_length))
         item = (PendingCaption(self), enc, enc_done, max_length)
         item[0]._input = input_dict
@@ -239,7 +251,7 @@ class TransformerModel(CaptionModel):
         enc_s, dec_s = self._streams
         enc_s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(enc_s):
-            enc = self.encoder(dict(input_dict, gru_algo=input_dict.get("gru_algo", "single")))
+            enc = self.encoder(input_dict)
             enc_done = torch.cuda.Event()
             enc_done.record(enc_s)
         pending = PendingCaption(self)

@@ -124,12 +124,12 @@ int ac_linear(const float* X, const float* W, const float* bias, float* Y, int M
 int ac_gru_pack_whh(const float* whh, float* packed, int hidden, void* stream);
 int ac_gru_layer(const float* gx, const float* whhT, const float* bhh, const int* lens, float* out, int B,
                  int T, int hidden, void* stream);
-/* The same layer with every (clip, direction) split over TWO workgroups, each holding its half of W_hh in registers for
- * the whole sequence (nothing is re-streamed per step); the halves trade 128 hidden values per step through L2 as
- * {tag, value} granules (agent-scope relaxed atomics).  whh = nn.GRU's weight_hh of both directions [2][3H][H], NOT
+/* The same layer with every (clip, direction) split over FOUR workgroups of 256 threads, each holding its quarter of W_hh
+ * in registers for the whole sequence (nothing is re-streamed per step); the parts trade 64 hidden values each per step
+ * through L2 as {tag, value} granules (agent-scope relaxed atomics).  whh = nn.GRU's weight_hh of both directions [2][3H][H], NOT
  * packed.  workspace: ac_gru_split_workspace_bytes(B) bytes, 8-byte aligned, owned by the caller; the call clears what
  * it needs (stream-ordered memset).  Its FIRST 4-byte word is a sticky error flag the caller zeroes once: non-zero when
- * a workgroup's partner never started within 2 s (the output is then invalid).  4*B workgroups of 768 threads. */
+ * a workgroup's partner never started within 2 s (the output is then invalid).  8*B workgroups of 256 threads. */
 long ac_gru_split_workspace_bytes(int B);
 int ac_gru_layer_split(const float* gx, const float* whh, const float* bhh, const int* lens, float* out, void* workspace,
                        int B, int T, int hidden, void* stream);

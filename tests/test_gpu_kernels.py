@@ -240,8 +240,8 @@ def test_conv3x3_first(K):
 
 @pytest.mark.parametrize("gru_algo", ["split", "single"])
 def test_gru_layer_and_pooling_vs_oracle(K, state4981, gru_algo):
-    """Both recurrence kernels: "split" (default: a (clip, direction) on two CUs, W_hh register resident, hidden halves
-    traded through L2 every step) and "single" (one workgroup, 44 % of W_hh re-streamed per step)."""
+    """Both recurrence kernels: "split" (default: a (clip, direction) on four 256-thread workgroups, W_hh register resident,
+    hidden quarters traded through L2 every step) and "single" (one workgroup, 44 % of W_hh re-streamed per step)."""
     from oracle import cpu_path as O
     import audiocaption_amd as A
     g = torch.Generator().manual_seed(11)
@@ -267,7 +267,7 @@ def test_gru_layer_and_pooling_vs_oracle(K, state4981, gru_algo):
 def test_gru_split_kernel_under_uneven_load(K):
     """The split recurrence trades data between workgroups inside one launch (8-byte {tag, value} granules, agent-scope
     relaxed atomics).  Such hand-offs have to be tested with the consumer's L1 warm and the chip unevenly loaded: a
-    second stream streams memory while 130 clips x 93 steps (520 workgroups: more than the 256 CUs hold, so partners
+    second stream streams memory while 130 clips x 93 steps (1040 workgroups: more than the 256 CUs hold, so partners
     start at different times) run, five times over the same workspace; every word against the single-workgroup kernel."""
     g = torch.Generator().manual_seed(5)
     B, T, Hh = 130, 93, 256

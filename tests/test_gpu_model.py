@@ -266,16 +266,16 @@ def test_forward_async_equals_blocking_forward(hip_model):
     wavs = [torch.from_numpy(P.synthetic_wav(3, 48000, seed=s_, varied=True)).cuda() for s_ in (1, 2, 3)]
     inputs = [{"mode": "inference", "wav": w, "wav_len": [48000, 40000, 33000], "specaug": False,
                "sample_method": "greedy", "max_length": 8} for w in wavs]
-    want = [hip_model(dict(i, gru_algo="single")) for i in inputs]     # the recurrence kernel forward_async uses
+    want = [hip_model(dict(i)) for i in inputs]
     pend = [hip_model.forward_async(dict(i)) for i in inputs]
     got = [p.result() for p in pend]
     for w, g in zip(want, got):
         assert torch.equal(w["seq"], g["seq"])
         assert torch.equal(w["logit"], g["logit"]) and torch.equal(w["attn_emb"], g["attn_emb"])
         assert torch.equal(w["sampled_logprob"], g["sampled_logprob"])
-    # the plain blocking call runs the two-CU recurrence: another summation order, the same tokens
+    # the one-workgroup recurrence kernel (gru_algo="single"): another summation order, the same tokens
     for i, g in zip(inputs, got):
-        w = hip_model(dict(i))
+        w = hip_model(dict(i, gru_algo="single"))
         assert torch.equal(w["seq"], g["seq"]) and float((w["logit"] - g["logit"]).abs().max()) < 2e-5
 
 
@@ -291,7 +291,7 @@ def test_forward_async_pair_decode_mixed_shapes(hip_model):
     inputs = [make(3, 48000, 1, [48000, 40000, 33000]), make(3, 64000, 2, [64000, 50000, 33000]),
               make(3, 64000, 3, [64000, 64000, 64000]), make(2, 64000, 4, [64000, 41000]),
               make(3, 48000, 5, [48000, 48000, 20000])]
-    want = [hip_model(dict(i, gru_algo="single")) for i in inputs]
+    want = [hip_model(dict(i)) for i in inputs]
     for pair in (True, False):
         pend = [hip_model.forward_async(dict(i), pair=pair) for i in inputs]
         for k in (4, 0, 2, 1, 3):   # out of order
@@ -314,7 +314,7 @@ def test_forward_async_beam_equals_blocking(hip_model):
         w = torch.from_numpy(P.synthetic_wav(3, 48000, seed=s_, varied=True)).cuda()
         inputs.append({"mode": "inference", "wav": w, "wav_len": lens, "specaug": False, "sample_method": "beam",
                        "beam_size": 3, "max_length": 8})
-    want = [hip_model(dict(i, gru_algo="single")) for i in inputs]
+    want = [hip_model(dict(i)) for i in inputs]
     pend = [hip_model.forward_async(dict(i)) for i in inputs]
     for k in (1, 0, 2):
         g = pend[k].result()
