@@ -52,7 +52,7 @@ SIGNATURES = {
     "ac_gru_pack_whh": (_I, [_P, _P, _I, _P]),
     "ac_gru_layer": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ac_gru_split_workspace_bytes": (_L, [_I]),
-    "ac_gru_layer_split": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "ac_gru_layer_split": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ac_mean_with_lens": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "ac_add_layernorm": (_I, [_P, _P, _P, _P, _P, _I, _I, _L, _L, _L, _P]),
     "ac_trm_memory": (_I, [_WP, _P, _I, _I, _P, _P, _P]),

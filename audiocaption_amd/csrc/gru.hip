@@ -127,6 +127,7 @@ struct GruSplitParams {
   const float* bhh;    // [2][3H]
   const int* lens;     // [B]
   float* out;          // [B][T][2H]
+  float* save;         // optional [B][T][2][4H]: r, z, n, W_hn h + b_hn per cell, for the backward pass (training)
   unsigned long long* xch;   // [2B groups][4 parts][2 slots][64] granules, zeroed before every launch
   unsigned* ticket;          // zeroed before every launch
   unsigned* error;           // set to 1 when a partner never showed up
@@ -189,8 +190,13 @@ __global__ __launch_bounds__(256) void gru_layer_split_kernel(GruSplitParams p) 
     if (kq == 0) {
       const float r = sigmoidf_(gr + ar + br);
       const float z = sigmoidf_(gz + az + bz);
-      const float c = tanhf(gn + r * (an + bn));
+      const float ghn = an + bn;
+      const float c = tanhf(gn + r * ghn);
       const float hn = (1.0f - z) * c + z * hold;
+      if (p.save) {
+        float* sv = p.save + (((size_t)b * p.T + t) * 2 + dir) * 4 * H + unit;
+        sv[0] = r; sv[H] = z; sv[2 * H] = c; sv[3 * H] = ghn;
+      }
       __hip_atomic_store(mine + (step & 1) * HQ + j, ((unsigned long long)tag << 32) | __float_as_uint(hn),
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       sh[part * HQP + j] = hn;
@@ -289,11 +295,11 @@ extern "C" long ac_gru_split_workspace_bytes(int B) {
 }
 
 extern "C" int ac_gru_layer_split(const float* gx, const float* whh, const float* bhh, const int* lens, float* out,
-                                  void* workspace, int B, int T, int hidden, void* stream) {
+                                  float* save, void* workspace, int B, int T, int hidden, void* stream) {
   if (!gx || !whh || !bhh || !lens || !out || !workspace || B <= 0 || T <= 0 || hidden != H) return AC_ERR_ARG;
   const size_t gran = (size_t)B * 2 * GQ * 2 * HQ * 8;
   GruSplitParams p;
-  p.gx = gx; p.whh = whh; p.bhh = bhh; p.lens = lens; p.out = out; p.B = B; p.T = T;
+  p.gx = gx; p.whh = whh; p.bhh = bhh; p.lens = lens; p.out = out; p.save = save; p.B = B; p.T = T;
   p.error = (unsigned*)workspace;
   p.ticket = (unsigned*)((char*)workspace + 64);
   p.xch = (unsigned long long*)((char*)workspace + 128);

@@ -304,7 +304,7 @@ def gru_layer_split(gx, whh, bhh, lens_i32, B, T, hidden, workspace=None):
     if workspace is None or workspace.numel() * 8 < need or workspace.device != gx.device:
         workspace = torch.zeros((need + 7) // 8, device=gx.device, dtype=torch.int64)
     out = torch.empty(B, T, 2 * hidden, device=gx.device, dtype=torch.float32)
-    check(lib.ac_gru_layer_split(ptr(gx), ptr(whh), ptr(bhh), ptr(lens_i32), ptr(out), ptr(workspace), B, T, hidden,
+    check(lib.ac_gru_layer_split(ptr(gx), ptr(whh), ptr(bhh), ptr(lens_i32), ptr(out), None, ptr(workspace), B, T, hidden,
                                  stream()), "ac_gru_layer_split")
     return out, workspace
 

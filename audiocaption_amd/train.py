@@ -19,6 +19,7 @@ Here the whole step is HIP kernels driven from this file through the C ABI (csrc
 through the same engine and returns ``logit`` attached to torch.autograd by ONE bridge node, so the reference's
 runner (``loss.backward()``, any torch optimizer) works unchanged.
 """
+import os
 import random
 
 import torch
@@ -136,6 +137,9 @@ def allreduce_flat_gradients(flat_grad, process_group=None, async_op=False):
     return work if async_op else world
 
 
+_WS_POISON = os.environ.get("AUDIOCAPTION_WS_POISON", "0") == "1"
+
+
 class _Ws:
     """Named device buffers shared by every batch shape of an engine: a buffer is re-allocated only when a shape needs
     more than it holds, and ``gen`` counts those re-allocations (captured graphs hold raw addresses and are re-captured
@@ -153,6 +157,8 @@ class _Ws:
         b = self.t.get(name)
         if b is None or b.numel() < n:
             b = torch.empty(max(n, 1), device=self.device, dtype=torch.float32)
+            if _WS_POISON:
+                b.fill_(float("nan"))      # development aid: a read of a cell no kernel wrote shows up as NaN
             self.t[name] = b
             self.gen += 1
         return b.data_ptr()
@@ -191,8 +197,8 @@ class TrainEngine:
         self._phase = "forward"
         # GEMMs of the step: "bf16x3" = split-bf16 operands on the bf16 MFMA for the large products (the backward over
         # all rows, teacher forcing), "f32" = exact f32 MFMA everywhere
-        import os
         self.gemm_algo = os.environ.get("AUDIOCAPTION_TRAIN_GEMM", "bf16x3")
+        self.gru_algo = os.environ.get("AUDIOCAPTION_GRU_ALGO", "split")   # forward recurrence kernel (see RnnEncoder)
 
     # ---- small launch helpers (raw addresses; s = stream handle) ------------------------------------------
     def _gemm(self, s, A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, bias=None, relu=0, beta=0.0, splitk=1, drop_p=0.0,
@@ -400,11 +406,19 @@ class TrainEngine:
             b_ih, b_hh = fp.p(f"{pre}bias_ih_l{l}"), fp.p(f"{pre}bias_hh_l{l}")
             gx = ws.f(f"gx{l}", rows_g, 6 * H)
             self._lin(s, x_in, w_ih, b_ih, gx, rows_g, 6 * H, in_dim)
-            whhT = ws.f(f"whhT{l}", 2 * 3 * H * H)
-            check(lib.ac_gru_pack_whh(w_hh, whhT, H, s), "ac_gru_pack_whh")
             out = ws.f(f"gru_out{l}", rows_g, 2 * H)
             save = ws.f(f"gru_save{l}", rows_g, 2 * 4 * H)
-            check(lib.ac_gru_layer_train(gx, whhT, b_hh, lens_p, out, save, B, Tq, H, s), "ac_gru_layer_train")
+            if self.gru_algo == "split":
+                # four workgroups per (clip, direction), W_hh register resident, straight from the flat parameter buffer
+                xch = ws.f("gru_xch", (lib.ac_gru_split_workspace_bytes(B) + 3) // 4)
+                if not st.get("gru_xch_zeroed"):
+                    ws.tensor("gru_xch")[:1].zero_()       # the sticky error word (first word of the workspace)
+                    st["gru_xch_zeroed"] = True
+                check(lib.ac_gru_layer_split(gx, w_hh, b_hh, lens_p, out, save, xch, B, Tq, H, s), "ac_gru_layer_split")
+            else:
+                whhT = ws.f(f"whhT{l}", 2 * 3 * H * H)
+                check(lib.ac_gru_pack_whh(w_hh, whhT, H, s), "ac_gru_pack_whh")
+                check(lib.ac_gru_layer_train(gx, whhT, b_hh, lens_p, out, save, B, Tq, H, s), "ac_gru_layer_train")
             nxt = out
             if l < nl - 1 and p_rnn > 0:
                 nxt = ws.f(f"gru_drop{l}", rows_g, 2 * H)

@@ -129,10 +129,12 @@ int ac_gru_layer(const float* gx, const float* whhT, const float* bhh, const int
  * through L2 as {tag, value} granules (agent-scope relaxed atomics).  whh = nn.GRU's weight_hh of both directions [2][3H][H], NOT
  * packed.  workspace: ac_gru_split_workspace_bytes(B) bytes, 8-byte aligned, owned by the caller; the call clears what
  * it needs (stream-ordered memset).  Its FIRST 4-byte word is a sticky error flag the caller zeroes once: non-zero when
- * a workgroup's partner never started within 2 s (the output is then invalid).  8*B workgroups of 256 threads. */
+ * a workgroup's partner never started within 2 s (the output is then invalid).  8*B workgroups of 256 threads.
+ * save (may be NULL): [B][T][2][4H] = (r, z, n, W_hn h + b_hn) per cell, what ac_gru_layer_bwd needs (ac_gru_layer_train's
+ * layout): the training forward. */
 long ac_gru_split_workspace_bytes(int B);
-int ac_gru_layer_split(const float* gx, const float* whh, const float* bhh, const int* lens, float* out, void* workspace,
-                       int B, int T, int hidden, void* stream);
+int ac_gru_layer_split(const float* gx, const float* whh, const float* bhh, const int* lens, float* out, float* save,
+                       void* workspace, int B, int T, int hidden, void* stream);
 /* mean_with_lens (model_util.py:41-63); add_max != 0 adds max_with_lens (cnn_encoder.py:451-453). */
 int ac_mean_with_lens(const float* x, const int* lens, float* out, int B, int T, int C, int add_max,
                       void* stream);

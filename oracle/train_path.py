@@ -155,13 +155,30 @@ def _mha_train(q_in, k_in, v_in, w, b, wo, bo, nhead, mask_add, pmask):
     return F.linear(o, wo, bo)
 
 
+KINK = 1e-5
+
+
+def _relu_at_kinks(pre, theirs):
+    """ReLU whose gate, where the pre-activation is within KINK of zero, is taken from ``theirs`` (the activation the
+    implementation under test kept for the same cells; None = plain ReLU).  The derivative of ReLU jumps at zero: a
+    pre-activation of +-1e-6 - inside the forward tolerance - switches a whole gradient path on or off, so a gradient
+    comparison has to put both sides on the same side of every such kink.  Values are unchanged to within KINK."""
+    gate = pre > 0
+    if theirs is not None:
+        gate = torch.where(pre.detach().abs() < KINK, theirs.reshape(pre.shape) > 0, gate)
+    return pre * gate
+
+
 def decoder_pass(state, word, attn_emb, attn_emb_len, pad_idx, base_seed, p, row0, mrow0, seq0, pl, prefix="decoder.",
-                 nlayers=2, nhead=4):
-    """One decoder call of the training loop on tokens ``word`` (N, L); returns the (N, L, d) outputs."""
+                 nlayers=2, nhead=4, relu_gates=None):
+    """One decoder call of the training loop on tokens ``word`` (N, L); returns the (N, L, d) outputs.
+    relu_gates: optional {"mem": (N*Tm, d), "ffn": [per layer (all rows of all passes, F)]} activations of the
+    implementation under test, consulted only at ReLU kinks (see ``_relu_at_kinks``)."""
     d = state[prefix + "word_embedding.weight"].shape[1]
     N, L = word.shape
     Tm = attn_emb.shape[1]
-    a = F.relu(F.linear(attn_emb, state[prefix + "attn_proj.0.weight"], state[prefix + "attn_proj.0.bias"]))
+    a = _relu_at_kinks(F.linear(attn_emb, state[prefix + "attn_proj.0.weight"], state[prefix + "attn_proj.0.bias"]),
+                       relu_gates["mem"] if relu_gates else None)
     a = a * _mask_t(op_seed(base_seed, OP_MEM), mrow0 * d, (N, Tm, d), p)
     mem = F.layer_norm(a, (d,), state[prefix + "attn_proj.3.weight"], state[prefix + "attn_proj.3.bias"])
     x = state[prefix + "word_embedding.weight"][word] * _mask_t(op_seed(base_seed, OP_EMB_A), row0 * d, (N, L, d), p)
@@ -190,15 +207,20 @@ def decoder_pass(state, word, attn_emb, attn_emb_len, pad_idx, base_seed, p, row
                         state[lp + "multihead_attn.in_proj_bias"], state[lp + "multihead_attn.out_proj.weight"],
                         state[lp + "multihead_attn.out_proj.bias"], nhead, mem_mask, pmask(op + 2, Tm, Tm))
         x = F.layer_norm(x + ca * rowmask(op + 3), (d,), state[lp + "norm2.weight"], state[lp + "norm2.bias"])
-        hdn = F.relu(F.linear(x, state[lp + "linear1.weight"], state[lp + "linear1.bias"]))
-        hdn = hdn * rowmask(op + 4, hdn.shape[-1])
+        pre = F.linear(x, state[lp + "linear1.weight"], state[lp + "linear1.bias"])
+        dm = rowmask(op + 4, pre.shape[-1])
+        theirs = None
+        if relu_gates:      # kept AFTER dropout there: a dropped cell says nothing (and carries no gradient either)
+            theirs = relu_gates["ffn"][l][row0:row0 + N * L].reshape(pre.shape)
+            theirs = torch.where(dm > 0, theirs, pre.detach())
+        hdn = _relu_at_kinks(pre, theirs) * dm
         ff = F.linear(hdn, state[lp + "linear2.weight"], state[lp + "linear2.bias"])
         x = F.layer_norm(x + ff * rowmask(op + 5), (d,), state[lp + "norm3.weight"], state[lp + "norm3.bias"])
     return x
 
 
 def train_forward(state, attn_emb, attn_emb_len, cap, use_cap, base_seed=0, p_dec=0.2, start_idx=O.START_IDX,
-                  pad_idx=O.PAD_IDX, teacher_forcing=False, prefix="decoder."):
+                  pad_idx=O.PAD_IDX, teacher_forcing=False, prefix="decoder.", relu_gates=None):
     """Scheduled-sampling forward.  cap (N, Tc) int64; use_cap[t] = the draw ``random.random() < ss_ratio`` of
     step t (transformer_model.py:44).  Returns logit (N, Tc-1, V) and seq (N, Tc-1) (the greedy tokens).
     teacher_forcing=True is ``seq_forward``: one pass over cap[:, :-1], every position classified."""
@@ -207,7 +229,8 @@ def train_forward(state, attn_emb, attn_emb_len, cap, use_cap, base_seed=0, p_de
     Tm = attn_emb.shape[1]
     cls = state[prefix + "classifier.weight"]
     if teacher_forcing:
-        x = decoder_pass(state, cap[:, :-1], attn_emb, attn_emb_len, pad_idx, base_seed, p_dec, 0, 0, 0, T, prefix)
+        x = decoder_pass(state, cap[:, :-1], attn_emb, attn_emb_len, pad_idx, base_seed, p_dec, 0, 0, 0, T, prefix,
+                         relu_gates=relu_gates)
         logit = F.linear(x, cls)
         return {"logit": logit, "seq": logit.argmax(-1)}
     seq = torch.zeros(N, T, dtype=torch.long)
@@ -220,7 +243,7 @@ def train_forward(state, attn_emb, attn_emb_len, cap, use_cap, base_seed=0, p_de
         else:
             word = torch.cat([torch.full((N, 1), start_idx, dtype=torch.long), seq[:, :t]], dim=1)
         x = decoder_pass(state, word, attn_emb, attn_emb_len, pad_idx, base_seed, p_dec, row0, t * N * Tm, t * N, T,
-                         prefix)
+                         prefix, relu_gates=relu_gates)
         logit_t = F.linear(x[:, -1], cls)
         seq[:, t] = logit_t.detach().argmax(-1)
         logits.append(logit_t)
@@ -247,14 +270,16 @@ def trainable_keys(state):
 
 
 def train_step_grads(state, cnn_attn, attn_len, cap, cap_len, use_cap, base_seed=0, p_dec=0.2, p_rnn=0.5,
-                     smoothing=0.1, teacher_forcing=False):
-    """Loss and gradients of one batch given the (frozen) Cnn14 output ``cnn_attn`` (B, T', 2048)."""
+                     smoothing=0.1, teacher_forcing=False, relu_gates=None):
+    """Loss and gradients of one batch given the (frozen) Cnn14 output ``cnn_attn`` (B, T', 2048).
+    relu_gates: see ``decoder_pass``."""
     keys = trainable_keys(state)
     st = dict(state)
     for k in keys:
         st[k] = state[k].detach().clone().requires_grad_(True)
     attn_emb = gru_train_forward(st, cnn_attn, attn_len, base_seed, p_rnn)
-    out = train_forward(st, attn_emb, attn_len, cap, use_cap, base_seed, p_dec, teacher_forcing=teacher_forcing)
+    out = train_forward(st, attn_emb, attn_len, cap, use_cap, base_seed, p_dec, teacher_forcing=teacher_forcing,
+                        relu_gates=relu_gates)
     loss = label_smoothing_loss(out["logit"], cap[:, 1:], torch.as_tensor(cap_len) - 1, smoothing)
     grads = torch.autograd.grad(loss, [st[k] for k in keys], allow_unused=True)
     g = {k: (gr if gr is not None else torch.zeros_like(st[k])) for k, gr in zip(keys, grads)}

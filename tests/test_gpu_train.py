@@ -298,6 +298,23 @@ def test_gru_layer_train_forward_backward(lib):
     dwhh = torch.einsum("btdn,btdk->dnk", dgh.cpu().double(), hprev.cpu().double())
     assert rel("gru dW_hh", dwhh, whr.grad) < 2e-5
     assert rel("gru db_hh", dgh.cpu().double().sum((0, 1)), bhr.grad) < 2e-5
+    # the 4-way split forward (what the engine runs) leaves the same gates for the same backward: the cells of valid
+    # steps agree with the single-workgroup kernel's, the cells of padded steps are never written by either
+    out_s = torch.full_like(out, float("nan"))
+    save_s = torch.full_like(save, float("nan"))
+    xch = torch.zeros((lib.ac_gru_split_workspace_bytes(B) + 7) // 8, device=dev, dtype=torch.int64)
+    assert lib.ac_gru_layer_split(P(gx_d), P(whh_d), P(bhh_d), P(lens_d), P(out_s), P(save_s), P(xch), B, T, H, S()) == 0
+    assert int(xch.view(torch.int32)[0]) == 0
+    assert rel("split gru out", out_s, out_ref) < 1e-5
+    for b, n in enumerate(lens):
+        assert float((save_s[b, :n] - save[b, :n]).abs().max()) < 1e-5
+        assert torch.isnan(save_s[b, n:]).all()
+    dgx_s, dgh_s, hprev_s = torch.empty_like(dgx), torch.empty_like(dgh), torch.empty_like(hprev)
+    assert lib.ac_gru_layer_bwd(P(dout.to(dev)), P(out_s), P(save_s), P(whh_d), P(lens_d), P(dgx_s), P(dgh_s), P(hprev_s),
+                                B, T, H, S()) == 0
+    assert rel("split gru dgx", dgx_s, gxr.grad) < 2e-5
+    dwhh = torch.einsum("btdn,btdk->dnk", dgh_s.cpu().double(), hprev_s.cpu().double())
+    assert rel("split gru dW_hh", dwhh, whr.grad) < 2e-5
 
 
 def test_label_smoothing_loss_vs_reference_value_and_autograd(lib, golden_dir, state4981):
@@ -516,7 +533,15 @@ def test_training_step_with_dropout_vs_oracle(train_model, state4981):
     assert rel("cnn attn (dropout)", cnn_attn, o_cnn) < 1e-4
     # (2) the rest from the HIP Cnn14 output
     lens = OT.O.cnn14_feat_len(wav_len)
-    o = OT.train_step_grads(state4981, cnn_attn, lens, cap, cap_len, use_cap, base_seed=seed, p_dec=0.2, p_rnn=0.5)
+    # ReLU kinks: a pre-activation within 1e-5 of zero lies on either side depending on the last bits of the forward (the
+    # 4-way split GRU kernel and the single-workgroup one differ by 1e-6 there), and its side switches a whole gradient
+    # path.  The oracle takes the side the HIP forward took for exactly those cells (oracle/train_path.py _relu_at_kinks).
+    ws_, R_ = sv["ws"], sv["lay"]["R"]
+    rows_m = sv["N"] * sv["Tq"]
+    gates = {"mem": ws_.tensor("mem_a")[:rows_m * 256].view(rows_m, 256).cpu(),
+             "ffn": [ws_.tensor(f"hdn{l}")[:R_ * sv["F"]].view(R_, sv["F"]).cpu() for l in range(model.decoder.nlayers)]}
+    o = OT.train_step_grads(state4981, cnn_attn, lens, cap, cap_len, use_cap, base_seed=seed, p_dec=0.2, p_rnn=0.5,
+                            relu_gates=gates)
     assert rel("logit", out["logit"], o["logit"]) < 5e-5
     assert torch.equal(out["seq"].cpu(), o["seq"])
     logit = out["logit"]
@@ -527,11 +552,13 @@ def test_training_step_with_dropout_vs_oracle(train_model, state4981):
                       1.0 / count, None)
     assert abs(float(loss) - float(o["loss"])) < 2e-5 * float(o["loss"])
     eng.backward(dlogit)
-    worst = 0.0
+    worst, bad = 0.0, []
     for key, view in zip(eng.flat.names, eng.flat.grad_views):
         d = rel(key, view, o["grads"][key])
         worst = max(worst, d)
-        assert d < 2e-4, key
+        if not d < 2e-4:
+            bad.append((key, d))
+    assert not bad, bad
     print(f"worst relative gradient difference vs the oracle (dropout on): {worst:.3e}")
 
 
