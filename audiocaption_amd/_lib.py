@@ -101,6 +101,8 @@ SIGNATURES = {
     "ac_effnet_stem": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ac_effnet_depthwise": (_I, [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ac_effnet_se_gate": (_I, [_P, _F, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "ac_effnet_se_gate_t": (_I, [_P, _F, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "ac_effnet_expand_depthwise": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     # waveform ingest (csrc/ingest.hip)
     "ac_ingest_resample": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
 }
@@ -169,6 +171,7 @@ def load():
     return lib
 
 
+AC_ERR_ARG, AC_ERR_LAUNCH = -1, -2
 _ERR = {-1: "AC_ERR_ARG (arguments rejected)", -2: "AC_ERR_LAUNCH (HIP launch failed)"}
 
 

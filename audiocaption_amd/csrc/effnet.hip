@@ -191,6 +191,59 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* pool, float i
   }
 }
 
+// ---- the same gate with the second weight matrix TRANSPOSED (w2t [S][C]) and both phases bandwidth-shaped -----------
+// One workgroup per clip.  Phase 1: a wave owns squeezed units s, s + 4, ...: 16-byte loads of w1[s] across the lanes
+// (two rows in flight), DPP wave sum.  Phase 2: a thread owns channel quads; for every s one coalesced 16-byte load of
+// w2t[s] (four in flight), sq[s] broadcast from LDS.  se_gate_kernel above walks w2 [C][S] with one dependent scalar
+// load per (channel, s) - an S-long latency chain per thread - and the two-GEMM form it was replaced by costs two ~20 us
+// launches per block for 128 x S x C products of a few MFLOP.
+__global__ __launch_bounds__(256) void se_gate_t_kernel(const float* pool, float inv_count, const float* w1, const float* b1,
+                                                        const float* w2t, const float* b2, float* gate, int C, int S) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // mean [C] | squeezed [S]
+  float* mean = sm;
+  float* sq = sm + C;
+  const int b = blockIdx.x;
+  const int C4 = C >> 2;
+  for (int c4 = threadIdx.x; c4 < C4; c4 += 256)
+    ((f32x4*)mean)[c4] = ((const f32x4*)(pool + (long)b * C))[c4] * inv_count;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int s = wave; s < S; s += 8) {
+    const int s2 = min(s + 4, S - 1);
+    const f32x4* r0 = (const f32x4*)(w1 + (long)s * C);
+    const f32x4* r1 = (const f32x4*)(w1 + (long)s2 * C);
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    for (int c4 = lane; c4 < C4; c4 += 64) {
+      const f32x4 m = ((const f32x4*)mean)[c4];
+      a0 += r0[c4] * m;
+      a1 += r1[c4] * m;
+    }
+    const float t0 = wave_sum((a0[0] + a0[1]) + (a0[2] + a0[3]));
+    const float t1 = wave_sum((a1[0] + a1[1]) + (a1[2] + a1[3]));
+    if (lane == 0) {
+      sq[s] = swishf(t0 + b1[s]);
+      if (s + 4 < S) sq[s + 4] = swishf(t1 + b1[s + 4]);
+    }
+  }
+  __syncthreads();
+  for (int c4 = threadIdx.x; c4 < C4; c4 += 256) {
+    f32x4 a = ((const f32x4*)b2)[c4];
+    const f32x4* col = (const f32x4*)w2t + c4;
+    int s = 0;
+    for (; s + 4 <= S; s += 4) {
+      const f32x4 v0 = col[(long)s * C4], v1 = col[(long)(s + 1) * C4], v2 = col[(long)(s + 2) * C4], v3 = col[(long)(s + 3) * C4];
+      a += v0 * sq[s];
+      a += v1 * sq[s + 1];
+      a += v2 * sq[s + 2];
+      a += v3 * sq[s + 3];
+    }
+    for (; s < S; ++s) a += col[(long)s * C4] * sq[s];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = 1.0f / (1.0f + expf(-a[j]));
+    ((f32x4*)(gate + (long)b * C))[c4] = a;
+  }
+}
+
 // ---- 1x1 convolution = thin GEMM y[M][N] = act((x .* gate) W^T + b) (+ y), M = clips * positions in the millions,
 // K, N <= 2112.  HBM-bound: every wave owns 32 rows and reads its A fragments straight from global memory exactly
 // once per pass (lane l: 4 consecutive k of row l & 31 at k offset 4 * (l >> 5) of every 8-k group - one 16-byte load
@@ -344,6 +397,16 @@ int ac_effnet_se_gate(const float* pool, float inv_count, const float* w1, const
   if (!pool || !w1 || !b1 || !w2 || !b2 || !gate || B <= 0 || C <= 0 || S <= 0 || C + S > 12000) return AC_ERR_ARG;
   hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(256), (size_t)(C + S) * sizeof(float), (hipStream_t)stream, pool,
                      inv_count, w1, b1, w2, b2, gate, C, S);
+  return ac_check_launch();
+}
+
+int ac_effnet_se_gate_t(const float* pool, float inv_count, const float* w1, const float* b1, const float* w2t,
+                        const float* b2, float* gate, int B, int C, int S, void* stream) {
+  if (!pool || !w1 || !b1 || !w2t || !b2 || !gate || B <= 0 || C <= 0 || S <= 0 || (C & 3) || C + S > 12000 ||
+      ((uintptr_t)pool & 15) || ((uintptr_t)w1 & 15) || ((uintptr_t)w2t & 15) || ((uintptr_t)b2 & 15) || ((uintptr_t)gate & 15))
+    return AC_ERR_ARG;
+  hipLaunchKernelGGL(se_gate_t_kernel, dim3(B), dim3(256), (size_t)(C + S) * sizeof(float), (hipStream_t)stream, pool,
+                     inv_count, w1, b1, w2t, b2, gate, C, S);
   return ac_check_launch();
 }
 

@@ -107,6 +107,19 @@ class _EffiNet(nn.Module):
 GEMM_ALGO = os.environ.get("AUDIOCAPTION_EFFB2_GEMM", "bf16x3")
 
 
+# MBConv expand -> depthwise -> squeeze sums as ONE kernel (csrc/effnet_fused.hip) for the blocks with at least
+# FUSE_MIN_ROWS positions in the batch.  Measured per block at 128 clips x 10 s (tools/effb2_block_bench.py): the four
+# blocks at 501 x 32 and 250 x 16 positions per clip run 1.25-1.45x faster fused (the 6x expanded tensor is neither
+# written nor read back); from 125 x 8 positions down the fused kernel's LDS-resident band is too small to keep the
+# vector ALUs busy and the two-kernel chain is as fast or faster.  "0" keeps the chain everywhere.
+FUSE_EXPAND_DW = os.environ.get("AUDIOCAPTION_EFFB2_FUSE", "1") != "0"
+FUSE_MIN_ROWS = int(os.environ.get("AUDIOCAPTION_EFFB2_FUSE_MIN_ROWS", "400000"))
+
+
+# squeeze-excite gate: "kernel" = ac_effnet_se_gate_t (one launch per block), "gemm" = two small ac_gemm launches
+SE_GATE = os.environ.get("AUDIOCAPTION_EFFB2_SE", "kernel")
+
+
 def _fold(bn):
     scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
     return scale, bn.bias.detach().float() - bn.running_mean.detach().float() * scale
@@ -165,7 +178,8 @@ class EfficientNetB2(nn.Module):
                 d["se"] = (blk._se_reduce.weight.detach().float().reshape(blk._se_reduce.weight.shape[0], -1).contiguous(),
                            blk._se_reduce.bias.detach().float().contiguous(),
                            blk._se_expand.weight.detach().float().reshape(blk.mid, -1).contiguous(),
-                           blk._se_expand.bias.detach().float().contiguous())
+                           blk._se_expand.bias.detach().float().contiguous(),
+                           blk._se_expand.weight.detach().float().reshape(blk.mid, -1).t().contiguous())   # [S][C]
                 d["project"] = pointwise(blk._project_conv, blk._bn2)
                 pk["blocks"].append(d)
             pk["head"] = pointwise(net._conv_head, net._bn1)
@@ -237,25 +251,41 @@ class EfficientNetB2(nn.Module):
         for blk, d in zip(net._blocks, pk["blocks"]):
             rows = B * T * F
             xin = cur
-            if blk.expand != 1:
-                w, b = d["expand"]
-                self._gemm(xin, w, b, mid_buf, rows, blk.mid, blk.cin, act=2)
-                xmid = mid_buf
-            else:
-                xmid = xin
             wd, sc, sh = d["dw"]
             pb, pa = blk.pad
             To, Fo = (T + pb + pa - blk.k) // blk.stride + 1, (F + pb + pa - blk.k) // blk.stride + 1
             pool[:B * blk.mid].zero_()
-            check(lib.ac_effnet_depthwise(ptr(xmid), ptr(wd), ptr(sc), ptr(sh), ptr(dw_buf), ptr(pool), 1.0 / (To * Fo), B,
-                                          T, F, blk.mid, blk.k, blk.stride, pb, pa, s), "ac_effnet_depthwise")
+            fused = False
+            if blk.expand != 1 and FUSE_EXPAND_DW and rows >= FUSE_MIN_ROWS:
+                # expand -> depthwise -> squeeze sums in one kernel: the expanded tensor (6x the block input) stays in LDS
+                w, b = d["expand"]
+                rc = lib.ac_effnet_expand_depthwise(ptr(xin), ptr(w), ptr(b), ptr(wd), ptr(sc), ptr(sh), ptr(dw_buf),
+                                                    ptr(pool), 1.0 / (To * Fo), B, T, F, blk.cin, blk.mid, blk.k,
+                                                    blk.stride, pb, pa, s)
+                if rc != _lib.AC_ERR_ARG:      # AC_ERR_ARG: one row band does not fit the LDS budget -> two-kernel chain
+                    check(rc, "ac_effnet_expand_depthwise")
+                    fused = True
+            if not fused:
+                if blk.expand != 1:
+                    w, b = d["expand"]
+                    self._gemm(xin, w, b, mid_buf, rows, blk.mid, blk.cin, act=2)
+                    xmid = mid_buf
+                else:
+                    xmid = xin
+                check(lib.ac_effnet_depthwise(ptr(xmid), ptr(wd), ptr(sc), ptr(sh), ptr(dw_buf), ptr(pool), 1.0 / (To * Fo),
+                                              B, T, F, blk.mid, blk.k, blk.stride, pb, pa, s), "ac_effnet_depthwise")
             # squeeze-excite gate for all clips at once: two small GEMMs (swish, then sigmoid, in the epilogues)
-            w1, b1, w2, b2 = d["se"]
+            w1, b1, w2, b2, w2t = d["se"]
             Sq = w1.shape[0]
-            check(lib.ac_gemm(ptr(pool), blk.mid, 1, ptr(w1), 1, blk.mid, ptr(sq_buf), Sq, B, Sq, blk.mid, ptr(b1), 2, 0.0,
-                              1, 0.0, 0, None, 0, None, 0, s), "ac_gemm(se reduce)")
-            check(lib.ac_gemm(ptr(sq_buf), Sq, 1, ptr(w2), 1, Sq, ptr(gate), blk.mid, B, blk.mid, Sq, ptr(b2), 3, 0.0, 1,
-                              0.0, 0, None, 0, None, 0, s), "ac_gemm(se expand)")
+            if SE_GATE == "kernel":
+                # one launch, a workgroup per clip (pool already holds the means: pool_scale above)
+                check(lib.ac_effnet_se_gate_t(ptr(pool), 1.0, ptr(w1), ptr(b1), ptr(w2t), ptr(b2), ptr(gate), B, blk.mid,
+                                              Sq, s), "ac_effnet_se_gate_t")
+            else:
+                check(lib.ac_gemm(ptr(pool), blk.mid, 1, ptr(w1), 1, blk.mid, ptr(sq_buf), Sq, B, Sq, blk.mid, ptr(b1), 2,
+                                  0.0, 1, 0.0, 0, None, 0, None, 0, s), "ac_gemm(se reduce)")
+                check(lib.ac_gemm(ptr(sq_buf), Sq, 1, ptr(w2), 1, Sq, ptr(gate), blk.mid, B, blk.mid, Sq, ptr(b2), 3, 0.0,
+                                  1, 0.0, 0, None, 0, None, 0, s), "ac_gemm(se expand)")
             w, b = d["project"]
             rows_o = B * To * Fo
             if blk.skip:

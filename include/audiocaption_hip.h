@@ -386,6 +386,20 @@ int ac_effnet_depthwise(const float* x, const float* w, const float* scale, cons
 /* gate[b][c] = sigmoid(w2 swish(w1 (pool[b] * inv_count) + b1) + b2), w1 [S][C], w2 [C][S]. */
 int ac_effnet_se_gate(const float* pool, float inv_count, const float* w1, const float* b1, const float* w2,
                       const float* b2, float* gate, int B, int C, int S, void* stream);
+/* The same gate with the second matrix transposed, w2t [S][C] (= _se_expand.weight^T): one launch per block, both
+ * phases read their weights with coalesced 16-byte loads.  C % 4 == 0, 16-byte aligned pointers. */
+int ac_effnet_se_gate_t(const float* pool, float inv_count, const float* w1, const float* b1, const float* w2t,
+                        const float* b2, float* gate, int B, int C, int S, void* stream);
+/* MBConv head in one kernel (csrc/effnet_fused.hip): _expand_conv + _bn0 + swish -> _depthwise_conv + _bn1 + swish ->
+ * squeeze sums, the expanded tensor staying in LDS.  x [B][T][F][Cin]; we [Cmid][Cin] / be [Cmid] = the expand
+ * convolution with BatchNorm folded in (as for ac_pointwise_conv); wd [k time][k mel][Cmid], scale / shift [Cmid] = the
+ * depthwise convolution and its folded BatchNorm (as for ac_effnet_depthwise); y [B][To][Fo][Cmid] (NULL: only the
+ * squeeze sums); pool [B][Cmid] += pool_scale * sum of y over positions (zero it first).  Cin % 8 == 0, Cmid % 4 == 0,
+ * k = 3 / 5, stride 1 / 2, 16-byte aligned pointers.  AC_ERR_ARG when one input row band does not fit the LDS budget
+ * (the caller then runs the two-kernel chain). */
+int ac_effnet_expand_depthwise(const float* x, const float* we, const float* be, const float* wd, const float* scale,
+                               const float* shift, float* y, float* pool, float pool_scale, int B, int T, int F, int Cin,
+                               int Cmid, int k, int stride, int pad_before, int pad_after, void* stream);
 
 /* ===================================== waveform ingest =====================================
  * B clips stored back to back in src (float16 when src_half, else float32; clip b = src[src_off[b] .. src_off[b+1]))

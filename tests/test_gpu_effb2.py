@@ -2,6 +2,9 @@
 oracle/effb2_path.py.  PARITY UNPINNED: the oracle restates the published efficientnet_pytorch / torchaudio algorithms
 (not vendored by the reference); what IS checked here is that the HIP path computes exactly that restatement."""
 import ctypes
+import os
+import subprocess
+import sys
 
 import pytest
 import torch
@@ -78,6 +81,82 @@ def test_depthwise_kernel_and_squeeze_sums(lib, k, stride, pad):
     assert rel("squeeze sums", pool, ref.sum(dim=(2, 3))) < 1e-5
 
 
+@pytest.mark.parametrize("k,stride,pad,Fm,cin,mid", [(3, 1, (1, 1), 16, 24, 144), (3, 2, (0, 1), 32, 16, 96),
+                                                     (5, 2, (2, 2), 10, 24, 144), (5, 1, (2, 2), 4, 88, 528),
+                                                     (3, 2, (1, 1), 8, 48, 288), (5, 1, (2, 2), 2, 208, 1248)])
+@pytest.mark.parametrize("lds_kb", [None, "40"])
+def test_fused_expand_depthwise_vs_torch(lib, k, stride, pad, Fm, cin, mid, lds_kb):
+    """ac_effnet_expand_depthwise (expand 1x1 + BN + swish -> depthwise + BN + swish -> squeeze sums in one kernel, the
+    expanded tensor in LDS) against F.conv2d on the CPU: band seams (several bands per clip), partial last band, partial
+    32-channel chunk (144, 528), the zero padding of the EXPANDED tensor (swish(bias) != 0 must not leak into it)."""
+    g = torch.Generator().manual_seed(k * 100 + stride * 10 + Fm)
+    B, T = 3, 45
+    x = torch.randn(B, T, Fm, cin, generator=g)
+    we = torch.randn(mid, cin, generator=g) / cin ** 0.5
+    be = torch.randn(mid, generator=g) * 0.5 + 0.3
+    w = torch.randn(mid, 1, k, k, generator=g) * 0.3          # [C][1][k mel][k time]
+    sc, sh = torch.rand(mid, generator=g) + 0.5, torch.randn(mid, generator=g) * 0.1
+    e = F.linear(x, we, be)
+    e = e * torch.sigmoid(e)                                  # [B][T][F][mid]
+    en = e.permute(0, 3, 2, 1)                                # (B, C, F, T)
+    ref = F.conv2d(F.pad(en, (pad[0], pad[1], pad[0], pad[1])), w, stride=stride, groups=mid)
+    ref = ref * sc[None, :, None, None] + sh[None, :, None, None]
+    ref = ref * torch.sigmoid(ref)
+    ref_cl = ref.permute(0, 3, 2, 1).contiguous()
+    wp = w[:, 0].permute(2, 1, 0).contiguous().cuda()        # [k time][k mel][C]
+    dev_in = [t.cuda() for t in (x, we, be)] + [wp, sc.cuda(), sh.cuda()]     # kept alive: P() only takes addresses
+    args = tuple(P(t) for t in dev_in)
+    if lds_kb is not None:
+        # the LDS budget is read once per process: the small-band geometry (many band seams) runs in a child process
+        child = subprocess.run([sys.executable, "-c", _FUSED_CHILD, str(k), str(stride), str(pad[0]), str(pad[1]), str(Fm),
+                                str(cin), str(mid)], env=dict(os.environ, AUDIOCAPTION_EDW_LDS_KB=lds_kb),
+                               capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        print(child.stdout[-2000:], child.stderr[-2000:])
+        assert child.returncode == 0
+        return
+    y = torch.full(ref_cl.shape, float("nan"), device="cuda")
+    pool = torch.zeros(B, mid, device="cuda")
+    assert lib.ac_effnet_expand_depthwise(*args, P(y), P(pool), 1.0, B, T, Fm, cin, mid, k, stride, pad[0], pad[1], S()) == 0
+    assert rel(f"fused expand+depthwise k{k} s{stride} F{Fm}", y, ref_cl) < 1e-5
+    assert rel("squeeze sums", pool, ref.sum(dim=(2, 3))) < 1e-5
+    pool2 = torch.zeros(B, mid, device="cuda")               # sums only
+    assert lib.ac_effnet_expand_depthwise(*args, None, P(pool2), 1.0, B, T, Fm, cin, mid, k, stride, pad[0], pad[1], S()) == 0
+    assert rel("squeeze sums (y = NULL)", pool2, ref.sum(dim=(2, 3))) < 1e-5
+
+
+_FUSED_CHILD = r"""
+import ctypes, sys, torch, torch.nn.functional as F
+from audiocaption_amd import _lib, build
+build.build(); lib = _lib.load()
+k, stride, p0, p1, Fm, cin, mid = map(int, sys.argv[1:8])
+P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+g = torch.Generator().manual_seed(7)
+B, T = 2, 45
+x = torch.randn(B, T, Fm, cin, generator=g)
+we = torch.randn(mid, cin, generator=g) / cin ** 0.5
+be = torch.randn(mid, generator=g) * 0.5 + 0.3
+w = torch.randn(mid, 1, k, k, generator=g) * 0.3
+sc, sh = torch.rand(mid, generator=g) + 0.5, torch.randn(mid, generator=g) * 0.1
+e = F.linear(x, we, be); e = e * torch.sigmoid(e)
+ref = F.conv2d(F.pad(e.permute(0, 3, 2, 1), (p0, p1, p0, p1)), w, stride=stride, groups=mid)
+ref = ref * sc[None, :, None, None] + sh[None, :, None, None]
+ref = ref * torch.sigmoid(ref)
+ref_cl = ref.permute(0, 3, 2, 1).contiguous()
+y = torch.full(ref_cl.shape, float("nan"), device="cuda")
+pool = torch.zeros(B, mid, device="cuda")
+dev_in = [t.cuda() for t in (x, we, be, w[:, 0].permute(2, 1, 0).contiguous(), sc, sh)]   # kept alive: P() takes addresses
+rc = lib.ac_effnet_expand_depthwise(*[P(t) for t in dev_in], P(y), P(pool), 1.0, B, T, Fm, cin, mid, k, stride, p0, p1,
+                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+if rc == -1:
+    print("band does not fit this LDS budget: AC_ERR_ARG (the caller keeps the two-kernel chain)"); sys.exit(0)
+assert rc == 0, rc
+d = float((y.cpu() - ref_cl).abs().max()) / float(ref_cl.abs().max())
+dp = float((pool.cpu() - ref.sum(dim=(2, 3))).abs().max()) / float(ref.sum(dim=(2, 3)).abs().max())
+print("small-band geometry: y", d, "pool", dp)
+assert d < 1e-5 and dp < 1e-5
+"""
+
+
 def test_se_gate_and_gated_projection(lib):
     g = torch.Generator().manual_seed(3)
     B, HW, C, Sq, Co = 3, 35, 96, 4, 24
@@ -91,6 +170,23 @@ def test_se_gate_and_gated_projection(lib):
     assert lib.ac_effnet_se_gate(P(pool.cuda()), 1.0 / HW, P(w1.cuda()), P(b1.cuda()), P(w2.cuda()), P(b2.cuda()), P(gate),
                                  B, C, Sq, S()) == 0
     assert rel("se gate", gate, gate_ref) < 1e-5
+    # the transposed-weight kernel the encoder uses (one launch per block), also at the widths of the late blocks
+    gate_t = torch.empty(B, C, device="cuda")
+    dev_in = [t.cuda() for t in (pool, w1, b1, w2.t().contiguous(), b2)]
+    assert lib.ac_effnet_se_gate_t(P(dev_in[0]), 1.0 / HW, P(dev_in[1]), P(dev_in[2]), P(dev_in[3]), P(dev_in[4]), P(gate_t),
+                                   B, C, Sq, S()) == 0
+    assert rel("se gate (w2 transposed)", gate_t, gate_ref) < 1e-5
+    for Cb, Sb in ((1248, 52), (2112, 88), (16, 4), (528, 22)):
+        pb_ = torch.randn(5, Cb, generator=g)
+        w1b, b1b = torch.randn(Sb, Cb, generator=g) / Cb ** 0.5, torch.randn(Sb, generator=g) * 0.1
+        w2b, b2b = torch.randn(Cb, Sb, generator=g) * 0.3, torch.randn(Cb, generator=g) * 0.1
+        sqb = F.linear(pb_ * 0.25, w1b, b1b)
+        want = torch.sigmoid(F.linear(sqb * torch.sigmoid(sqb), w2b, b2b))
+        got = torch.empty(5, Cb, device="cuda")
+        dev_b = [t.cuda() for t in (pb_, w1b, b1b, w2b.t().contiguous(), b2b)]
+        assert lib.ac_effnet_se_gate_t(P(dev_b[0]), 0.25, P(dev_b[1]), P(dev_b[2]), P(dev_b[3]), P(dev_b[4]), P(got), 5, Cb,
+                                       Sb, S()) == 0
+        assert rel(f"se gate C={Cb} S={Sb}", got, want) < 1e-5
     # 1x1 projection of the gated tensor with a residual: y = res + (x * gate) W^T + b
     w, b = torch.randn(Co, C, generator=g) * 0.1, torch.randn(Co, generator=g)
     res = torch.randn(B * HW, Co, generator=g)
