@@ -59,6 +59,14 @@ __device__ __forceinline__ float wave_max(float v) {
   return fmaxf(fmaxf(lane_read(v, 0), lane_read(v, 16)), fmaxf(lane_read(v, 32), lane_read(v, 48)));
 }
 
+// swish / sigmoid on the transcendental unit: v_exp_f32 and v_rcp_f32 (1 ulp each), 6 instructions instead of the ~25 of
+// expf + an IEEE division.  EfficientNet applies one swish per activation, which made the accurate form the largest VALU
+// item of its streaming kernels.  exp2 overflows to +inf for v < -88 (rcp(inf) = 0: the result is -0, the limit).
+__device__ __forceinline__ float ac_sigmoid_fast(float v) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896f * v));
+}
+__device__ __forceinline__ float ac_swish_fast(float v) { return v * ac_sigmoid_fast(v); }
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter
 // (s_waitcnt vmcnt(0)), which would force every global prefetch in flight to land at each barrier.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }

@@ -12,7 +12,7 @@
 
 namespace {
 
-__device__ __forceinline__ float swishf(float v) { return v / (1.0f + expf(-v)); }
+__device__ __forceinline__ float swishf(float v) { return ac_swish_fast(v); }
 
 // ---- AmplitudeToDB(top_db): clamp at (max over the whole batch) - top_db (torchaudio packs the batch axis) ----------
 __global__ __launch_bounds__(256) void block_max_kernel(const float* x, long n, float* partial) {
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* pool, float i
   for (int c = threadIdx.x; c < C; c += 256) {
     float a = b2[c];
     for (int s = 0; s < S; ++s) a = fmaf(w2[(long)c * S + s], sq[s], a);
-    gate[(long)b * C + c] = 1.0f / (1.0f + expf(-a));
+    gate[(long)b * C + c] = ac_sigmoid_fast(a);
   }
 }
 
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void se_gate_t_kernel(const float* pool, float
     }
     for (; s < S; ++s) a += col[(long)s * C4] * sq[s];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) a[j] = 1.0f / (1.0f + expf(-a[j]));
+    for (int j = 0; j < 4; ++j) a[j] = ac_sigmoid_fast(a[j]);
     ((f32x4*)(gate + (long)b * C))[c4] = a;
   }
 }

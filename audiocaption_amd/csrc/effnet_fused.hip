@@ -34,10 +34,7 @@
 
 namespace {
 
-// v / (1 + e^-v) on the transcendental unit: v_exp_f32 + v_rcp_f32 (1 ulp each)
-__device__ __forceinline__ float swish_fast(float v) {
-  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896f * v));
-}
+__device__ __forceinline__ float swish_fast(float v) { return ac_swish_fast(v); }
 
 struct EdP {
   const float* x; const float* we; const float* be; const float* wd; const float* scale; const float* shift;

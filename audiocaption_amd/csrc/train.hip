@@ -158,8 +158,8 @@ __global__ __launch_bounds__(256) void gemm_general_kernel(GemmP p) {
     } else {
       float v = acc[r] + bias;
       if (p.relu == 1) v = fmaxf(v, 0.f);
-      else if (p.relu == 2) v = v / (1.0f + expf(-v));
-      else if (p.relu == 3) v = 1.0f / (1.0f + expf(-v));
+      else if (p.relu == 2) v = ac_swish_fast(v);
+      else if (p.relu == 3) v = ac_sigmoid_fast(v);
       v *= p.drop.mask((uint64_t)(p.row0 + m) * (uint64_t)p.N + (uint64_t)n);
       if (p.beta != 0.f) v += p.beta * *c;
       *c = v;
@@ -270,8 +270,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
         } else {
           float v = acc[i][j][r] + bias;
           if (p.relu == 1) v = fmaxf(v, 0.f);
-          else if (p.relu == 2) v = v / (1.0f + expf(-v));
-          else if (p.relu == 3) v = 1.0f / (1.0f + expf(-v));
+          else if (p.relu == 2) v = ac_swish_fast(v);
+          else if (p.relu == 3) v = ac_sigmoid_fast(v);
           v *= p.drop.mask((uint64_t)(p.row0 + m) * (uint64_t)p.N + (uint64_t)n);
           if (p.beta != 0.f) v += p.beta * *c;
           *c = v;
@@ -343,8 +343,8 @@ __global__ __launch_bounds__(256) void gemm_kk_kernel(GemmP p) {
     if (m >= p.M) continue;
     float v = ((acc[r] + red[0][row][col]) + (red[1][row][col] + red[2][row][col])) + bias;
     if (p.relu == 1) v = fmaxf(v, 0.f);
-    else if (p.relu == 2) v = v / (1.0f + expf(-v));
-    else if (p.relu == 3) v = 1.0f / (1.0f + expf(-v));
+    else if (p.relu == 2) v = ac_swish_fast(v);
+    else if (p.relu == 3) v = ac_sigmoid_fast(v);
     v *= p.drop.mask((uint64_t)(p.row0 + m) * (uint64_t)p.N + (uint64_t)n);
     float* c = p.C + (long)m * p.ldc + n;
     if (p.beta != 0.f) v += p.beta * *c;
@@ -542,8 +542,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmP p) {
         } else {
           float v = acc[a][b][r] + bias;
           if (p.relu == 1) v = fmaxf(v, 0.f);
-          else if (p.relu == 2) v = v / (1.0f + expf(-v));
-          else if (p.relu == 3) v = 1.0f / (1.0f + expf(-v));
+          else if (p.relu == 2) v = ac_swish_fast(v);
+          else if (p.relu == 3) v = ac_sigmoid_fast(v);
           v *= p.drop.mask((uint64_t)(p.row0 + m) * (uint64_t)p.N + (uint64_t)n);
           if (p.beta != 0.f) v += p.beta * *cp;
           *cp = v;
