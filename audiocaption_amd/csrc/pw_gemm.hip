@@ -1,0 +1,271 @@
+// 1x1 convolution / linear layer with STATIC weights on the split-bf16 matrix path, activation-stationary:
+//   y[M][N] = act((x[M][K] .* gate[m / gate_rows][K]) W[N][K]^T + bias) + beta * y
+// for the matrix-bound 1x1 convolutions of the EfficientNet-B2 encoder (MBConv expand / project / head at 8 k - 32 k
+// rows against 88 ... 2112 channels; efficientnet_pytorch==0.7.1 _expand_conv / _project_conv / _conv_head with the
+// BatchNorm folded in, call sites hf_wrapper.py:229-241) and the decoder's teacher-forced projections.
+//
+// Why not ac_gemm_bf16x3 (csrc/train.hip): that kernel splits BOTH f32 operands into bf16 hi + lo while staging them
+// into LDS, per 64 x 64 or 128 x 128 output tile - ~150 VALU instructions per thread and 32-k chunk next to 24 MFMAs,
+// repeated for every tile that touches an operand element (N / 128 times per activation).  Here
+//   * the weights are split and laid out in MFMA FRAGMENT ORDER once, when the model is packed
+//     ([K/16 k-steps][N/32 tiles][hi, lo][64 lanes][8 bf16]): a wave's B fragment is one contiguous 1 KiB read straight
+//     from L2 into registers - no LDS, no conversion, the next k-step's fragments requested under the current MFMAs;
+//   * a workgroup owns 32 MW rows and a 256-column group: its four waves walk ALL its rows for two 32-column tiles each
+//     (1 x 4 wave grid: a weight fragment feeds 3 MW MFMAs), so an activation is split N / 256 times, not N / 128, by
+//     ~40 VALU instructions per thread and chunk next to 24 MFMAs (MW = 2; 128-row tiles measured slower everywhere);
+//   * global loads run two 32-k steps ahead of their use (two register sets of activations, a ring of four weight
+//     k-steps): at 12-24 MFMAs per wave and step a single step does not cover the L2 latency;
+//   * the accumulator is the TRANSPOSED tile (weights as the MFMA row operand): a lane ends up with 4 consecutive
+//     channels of one row, so bias / swish / residual work on 16-byte words and the stores are 16 bytes wide.
+// Arithmetic: x = hi + lo (bf16, RNE), products lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_bf16, f32 accumulation -
+// 2^-16 relative operand error, the same as the split-bf16 conv tier and ac_gemm_bf16x3.
+#include "ac_common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef __bf16 pg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned pg_u32x2 __attribute__((ext_vector_type(2)));
+constexpr int PG_ROW = 40;   // bf16 per LDS row: 32 k + 8 pad (80 B: a lane's 16-byte fragment reads stay conflict-light)
+
+struct PwgP {
+  const float* x; const pg_bf16x8* wf; const float* bias; float* y; const float* gate;
+  int M, N, K, KC, NT32, act, gate_rows;
+  float beta;
+};
+
+__device__ __forceinline__ unsigned pg_cvt_pk_bf16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+// 4 floats -> 4 bf16 hi (2 dwords) + 4 bf16 lo
+__device__ __forceinline__ void pg_split4(const f32x4 x, pg_u32x2& hi, pg_u32x2& lo) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const unsigned h = pg_cvt_pk_bf16(x[2 * i], x[2 * i + 1]);
+    const float h0 = __builtin_bit_cast(float, h << 16), h1 = __builtin_bit_cast(float, h & 0xffff0000u);
+    hi[i] = h;
+    lo[i] = pg_cvt_pk_bf16(x[2 * i] - h0, x[2 * i + 1] - h1);
+  }
+}
+
+template <int MW>
+__global__ __launch_bounds__(256, 2) void pw_bf16x3_kernel(PwgP p) {
+  constexpr int BM = 32 * MW;
+  constexpr int NI = BM / 32;                      // float4 staging items per thread and chunk
+  __shared__ __attribute__((aligned(16))) __bf16 sA[2][2][BM * PG_ROW];   // [buffer][hi, lo]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * BM;
+  const int nt0 = blockIdx.y * 8 + wave * 2;       // this wave's two 32-column tiles
+  const bool on0 = nt0 < p.NT32, on1 = nt0 + 1 < p.NT32;
+  // ---- staging: item j of this thread = float4 (row, 4 k) of the chunk ----
+  const float* xrow[NI];
+  const float* grow[NI];
+  bool rok[NI];
+  int sdst[NI];
+  const int kq = tid & 7;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int row = (tid >> 3) + 32 * j;
+    const int m = m0 + row;
+    rok[j] = m < p.M;
+    const int mc = rok[j] ? m : p.M - 1;
+    xrow[j] = p.x + (long)mc * p.K + kq * 4;
+    grow[j] = p.gate ? p.gate + (long)(mc / p.gate_rows) * p.K + kq * 4 : nullptr;
+    sdst[j] = row * PG_ROW + kq * 4;
+  }
+  // Two register sets of staged activations: chunk c + 2 is requested at the top of step c and split into LDS at the end
+  // of step c + 1, so a global load has two steps of MFMAs to land (a step is only 12 MW MFMAs per wave).
+  f32x4 preA[NI], pgA[NI], preB[NI], pgB[NI];
+  auto request = [&](int c, f32x4 (&pre)[NI], f32x4 (&pg)[NI]) {
+    const bool kok = c < p.KC && c * 32 + kq * 4 < p.K;   // K % 4 == 0: a quad is inside or outside as a whole
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      pre[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      pg[j] = f32x4{1.f, 1.f, 1.f, 1.f};
+      if (kok && rok[j]) {
+        pre[j] = *(const f32x4*)(xrow[j] + c * 32);
+        if (p.gate) pg[j] = *(const f32x4*)(grow[j] + c * 32);
+      }
+    }
+  };
+  auto commit = [&](int buf, const f32x4 (&pre)[NI], const f32x4 (&pg)[NI]) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      pg_u32x2 hi, lo;
+      pg_split4(pre[j] * pg[j], hi, lo);
+      *(pg_u32x2*)(sA[buf][0] + sdst[j]) = hi;
+      *(pg_u32x2*)(sA[buf][1] + sdst[j]) = lo;
+    }
+  };
+  // ---- weight fragments: (k-step kk, tile nt, plane) = 64 lanes x 16 B at ((kk * NT32 + nt) * 2 + plane) * 64; a ring
+  // of four k-steps in registers, k-step kk + 3 requested while kk runs ----
+  const pg_bf16x8* wbase = p.wf + (size_t)min(nt0, p.NT32 - 1) * 2 * 64 + lane;
+  const size_t w_kstep = (size_t)p.NT32 * 2 * 64;
+  const int w_t1 = on1 ? 2 * 64 : 0;
+  const int nks = p.KC * 2;
+  auto w_load = [&](int kk, pg_bf16x8 (&w)[2][2]) {
+    const pg_bf16x8* q = wbase + (size_t)min(kk, nks - 1) * w_kstep;
+    w[0][0] = q[0];
+    w[0][1] = q[64];
+    w[1][0] = q[w_t1];
+    w[1][1] = q[w_t1 + 64];
+  };
+
+  f32x16 acc[MW][2];
+#pragma unroll
+  for (int a = 0; a < MW; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  const int frag = (lane & 31) * PG_ROW + 8 * (lane >> 5);
+  pg_bf16x8 w0[2][2], w1[2][2], w2[2][2], w3[2][2];
+  auto kstep = [&](int buf, int ks, const pg_bf16x8 (&wc)[2][2]) {
+    pg_bf16x8 ah[MW], al[MW];
+#pragma unroll
+    for (int a = 0; a < MW; ++a) {
+      ah[a] = *(const pg_bf16x8*)(sA[buf][0] + a * 32 * PG_ROW + frag + ks * 16);
+      al[a] = *(const pg_bf16x8*)(sA[buf][1] + a * 32 * PG_ROW + frag + ks * 16);
+    }
+#pragma unroll
+    for (int a = 0; a < MW; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        // weights as the row operand: acc = D[n][m]
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[b][0], al[a], acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[b][1], ah[a], acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[b][0], ah[a], acc[a][b], 0, 0, 0);
+      }
+  };
+  request(0, preA, pgA);
+  request(1, preB, pgB);
+  if (on0) {
+    w_load(0, w0);
+    w_load(1, w1);
+    w_load(2, w2);
+  }
+  commit(0, preA, pgA);
+  __syncthreads();
+  for (int c = 0; c < p.KC; c += 2) {
+    // ---- step c (LDS buffer 0): chunk c + 2 -> set A, chunk c + 1 (set B) -> buffer 1 ----
+    request(c + 2, preA, pgA);
+    if (on0) {
+      w_load(2 * c + 3, w3);
+      kstep(0, 0, w0);
+      w_load(2 * c + 4, w0);
+      kstep(0, 1, w1);
+    }
+    if (c + 1 >= p.KC) break;
+    commit(1, preB, pgB);          // buffer 1: its readers finished before the previous barrier
+    __syncthreads();
+    // ---- step c + 1 (LDS buffer 1): chunk c + 3 -> set B, chunk c + 2 (set A) -> buffer 0 ----
+    request(c + 3, preB, pgB);
+    if (on0) {
+      w_load(2 * c + 5, w1);
+      kstep(1, 0, w2);
+      w_load(2 * c + 6, w2);
+      kstep(1, 1, w3);
+    }
+    if (c + 2 < p.KC) {
+      commit(0, preA, pgA);
+      __syncthreads();
+    }
+  }
+  // ---- epilogue: lane = row m0 + 32 a + (lane & 31), registers 4 g .. 4 g + 3 = channels 8 g + 4 (lane >> 5) + 0..3 ----
+  if (!on0) return;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    if (b == 1 && !on1) break;
+    const int nb = (nt0 + b) * 32 + 4 * (lane >> 5);
+#pragma unroll
+    for (int a = 0; a < MW; ++a) {
+      const int m = m0 + a * 32 + (lane & 31);
+      if (m >= p.M) continue;
+      float* yr = p.y + (long)m * p.N;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = nb + 8 * g;
+        if (n >= p.N) continue;                       // N % 4 == 0: a quad is inside or outside as a whole
+        f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
+        if (p.bias) v += *(const f32x4*)(p.bias + n);
+        if (p.act == 2) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = ac_swish_fast(v[q]);
+        } else if (p.act == 1) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+        }
+        if (p.beta != 0.f) v += p.beta * *(const f32x4*)(yr + n);
+        *(f32x4*)(yr + n) = v;
+      }
+    }
+  }
+}
+
+// ---- weight packing: W [N][K] f32 -> fragment order, split into bf16 hi / lo (RNE); K, N padded with zeros ----
+__global__ void pw_pack_kernel(const float* w, __bf16* out, int N, int K, int NT32, int KS) {
+  const long total = (long)KS * NT32 * 2 * 64 * 8;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+    const int e = (int)(i & 7);
+    const int lane = (int)((i >> 3) & 63);
+    const int plane = (int)((i >> 9) & 1);
+    const long t = i >> 10;
+    const int nt = (int)(t % NT32), kk = (int)(t / NT32);
+    const int n = nt * 32 + (lane & 31), k = kk * 16 + 8 * (lane >> 5) + e;
+    float v = (n < N && k < K) ? w[(long)n * K + k] : 0.f;
+    const __bf16 h = (__bf16)v;
+    out[i] = plane == 0 ? h : (__bf16)(v - (float)h);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// bytes of the packed weights of an N x K layer
+long ac_pw_gemm_packed_bytes(int N, int K) {
+  if (N <= 0 || K <= 0) return 0;
+  return (long)((K + 31) / 32) * 2 * ((N + 31) / 32) * 2 * 64 * 16;
+}
+
+int ac_pw_gemm_pack(const float* w, void* wfrag, int N, int K, void* stream) {
+  if (!w || !wfrag || N <= 0 || K <= 0) return AC_ERR_ARG;
+  const int NT32 = (N + 31) / 32, KS = (K + 31) / 32 * 2;
+  const long total = (long)KS * NT32 * 2 * 64 * 8;
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pw_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)wfrag, N, K, NT32, KS);
+  return ac_check_launch();
+}
+
+int ac_pw_gemm_bf16x3(const float* x, const void* wfrag, const float* bias, float* y, long M, int N, int K, int act,
+                      float beta, const float* gate, int gate_rows, void* stream) {
+  if (!x || !wfrag || !y || M <= 0 || M > 2147483647L || N <= 0 || K <= 0 || (K & 3) || (N & 3) || act < 0 || act > 2 ||
+      (gate && gate_rows <= 0) || ((uintptr_t)x & 15) || ((uintptr_t)wfrag & 15) || ((uintptr_t)y & 15) ||
+      (bias && ((uintptr_t)bias & 15)) || (gate && ((uintptr_t)gate & 15)))
+    return AC_ERR_ARG;
+  PwgP p;
+  p.x = x; p.wf = (const pg_bf16x8*)wfrag; p.bias = bias; p.y = y; p.gate = gate;
+  p.M = (int)M; p.N = N; p.K = K; p.KC = (K + 31) / 32; p.NT32 = (N + 31) / 32; p.act = act; p.gate_rows = gate ? gate_rows : 1;
+  p.beta = beta;
+  const unsigned gy = (unsigned)((p.NT32 + 7) / 8);
+  hipStream_t st = (hipStream_t)stream;
+  // rows per workgroup: 32 (most workgroups, the shortest dependent chain per step) up to 16 k rows, 64 above (a weight
+  // fragment then feeds 6 MFMAs; measured per shape with tools/pw_gemm_bench.py)
+  int mw = M >= 16384 ? 2 : 1;
+  {
+    static int forced = -1;
+    if (forced < 0) {
+      const char* e = getenv("AUDIOCAPTION_PW_MW");
+      forced = e ? atoi(e) : 0;
+    }
+    if (forced == 1 || forced == 2) mw = forced;
+  }
+  if (mw == 2) hipLaunchKernelGGL(pw_bf16x3_kernel<2>, dim3((unsigned)((M + 63) / 64), gy), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(pw_bf16x3_kernel<1>, dim3((unsigned)((M + 31) / 32), gy), dim3(256), 0, st, p);
+  return ac_check_launch();
+}
+
+}  // extern "C"

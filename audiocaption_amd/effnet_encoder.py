@@ -103,8 +103,9 @@ class _EffiNet(nn.Module):
         self.eff_net = EfficientNet()
 
 
-# 1x1 convolutions on the LDS-tiled GEMM: "bf16x3" (default) = split-bf16 operands on the bf16 MFMA, "f32" = exact f32 MFMA
-GEMM_ALGO = os.environ.get("AUDIOCAPTION_EFFB2_GEMM", "bf16x3")
+# matrix-bound 1x1 convolutions: "pw" (default) = ac_pw_gemm_bf16x3 (weights pre-split in MFMA fragment order, activations
+# split once per 256 output channels), "bf16x3" = ac_gemm_bf16x3 (both operands split per tile), "f32" = exact f32 MFMA
+GEMM_ALGO = os.environ.get("AUDIOCAPTION_EFFB2_GEMM", "pw")
 
 
 # MBConv expand -> depthwise -> squeeze sums as ONE kernel (csrc/effnet_fused.hip) for the blocks with at least
@@ -160,8 +161,15 @@ class EfficientNetB2(nn.Module):
 
         def pointwise(conv, bn):
             sc, sh = _fold(bn)
-            w = conv.weight.detach().float().reshape(conv.weight.shape[0], -1) * sc[:, None]   # BN folded into rows
-            return w.contiguous(), sh.contiguous()
+            w = (conv.weight.detach().float().reshape(conv.weight.shape[0], -1) * sc[:, None]).contiguous()   # BN folded
+            wfrag = None
+            if w.is_cuda and GEMM_ALGO == "pw":
+                # split into bf16 hi + lo and laid out in MFMA fragment order once (csrc/pw_gemm.hip)
+                lib = _lib.load()
+                n, k = w.shape
+                wfrag = torch.empty(lib.ac_pw_gemm_packed_bytes(n, k), device=w.device, dtype=torch.uint8)
+                check(lib.ac_pw_gemm_pack(ptr(w), ptr(wfrag), n, k, stream()), "ac_pw_gemm_pack")
+            return w, sh.contiguous(), wfrag
 
         with torch.no_grad():
             sc, sh = _fold(net._bn0)
@@ -195,7 +203,7 @@ class EfficientNetB2(nn.Module):
         return b
 
     @staticmethod
-    def _gemm(x, w, bias, y, M, N, Kd, act=0, beta=0.0, a_scale=None, a_rows=0):
+    def _gemm(x, w, bias, y, M, N, Kd, act=0, beta=0.0, a_scale=None, a_rows=0, wfrag=None):
         lib = _lib.load()
         # two kernels for the same contract (tools/pointwise_bench.py): the full-resolution stages (>= 0.4 M rows against
         # a few KB of weights) are HBM-bound -> the streaming kernel that reads each activation once; everything later
@@ -203,7 +211,11 @@ class EfficientNetB2(nn.Module):
         if M >= 400000 or (M >= 100000 and Kd <= 64):
             check(lib.ac_pointwise_conv(ptr(x), ptr(w), ptr(bias), ptr(y), M, N, Kd, act, beta, ptr(a_scale), a_rows,
                                         stream()), "ac_pointwise_conv")
-        elif GEMM_ALGO == "bf16x3":
+        elif wfrag is not None and GEMM_ALGO == "pw":
+            # matrix-bound layers: activation-stationary split-bf16 kernel over weights pre-split in fragment order
+            check(lib.ac_pw_gemm_bf16x3(ptr(x), ptr(wfrag), ptr(bias), ptr(y), M, N, Kd, act, beta, ptr(a_scale), a_rows,
+                                        stream()), "ac_pw_gemm_bf16x3")
+        elif GEMM_ALGO in ("bf16x3", "pw"):
             # the late 1x1 convolutions are matrix-bound in f32 (65-90 TFLOP/s on the exact-f32 MFMA): split-bf16
             # operands (2^-16), f32 accumulation; small products are forwarded to the exact-f32 kernels by the library
             check(lib.ac_gemm_bf16x3(ptr(x), Kd, 1, ptr(w), 1, Kd, ptr(y), N, M, N, Kd, ptr(bias), act, beta, 1, 0.0, 0, None,
@@ -258,7 +270,7 @@ class EfficientNetB2(nn.Module):
             fused = False
             if blk.expand != 1 and FUSE_EXPAND_DW and rows >= FUSE_MIN_ROWS:
                 # expand -> depthwise -> squeeze sums in one kernel: the expanded tensor (6x the block input) stays in LDS
-                w, b = d["expand"]
+                w, b, _ = d["expand"]
                 rc = lib.ac_effnet_expand_depthwise(ptr(xin), ptr(w), ptr(b), ptr(wd), ptr(sc), ptr(sh), ptr(dw_buf),
                                                     ptr(pool), 1.0 / (To * Fo), B, T, F, blk.cin, blk.mid, blk.k,
                                                     blk.stride, pb, pa, s)
@@ -267,8 +279,8 @@ class EfficientNetB2(nn.Module):
                     fused = True
             if not fused:
                 if blk.expand != 1:
-                    w, b = d["expand"]
-                    self._gemm(xin, w, b, mid_buf, rows, blk.mid, blk.cin, act=2)
+                    w, b, wf = d["expand"]
+                    self._gemm(xin, w, b, mid_buf, rows, blk.mid, blk.cin, act=2, wfrag=wf)
                     xmid = mid_buf
                 else:
                     xmid = xin
@@ -286,19 +298,19 @@ class EfficientNetB2(nn.Module):
                                   0.0, 1, 0.0, 0, None, 0, None, 0, s), "ac_gemm(se reduce)")
                 check(lib.ac_gemm(ptr(sq_buf), Sq, 1, ptr(w2), 1, Sq, ptr(gate), blk.mid, B, blk.mid, Sq, ptr(b2), 3, 0.0,
                                   1, 0.0, 0, None, 0, None, 0, s), "ac_gemm(se expand)")
-            w, b = d["project"]
+            w, b, wf = d["project"]
             rows_o = B * To * Fo
             if blk.skip:
                 # x <- x + project(gate * dw): accumulate in place on the block input
-                self._gemm(dw_buf, w, b, xin, rows_o, blk.cout, blk.mid, beta=1.0, a_scale=gate, a_rows=To * Fo)
+                self._gemm(dw_buf, w, b, xin, rows_o, blk.cout, blk.mid, beta=1.0, a_scale=gate, a_rows=To * Fo, wfrag=wf)
             else:
-                self._gemm(dw_buf, w, b, nxt, rows_o, blk.cout, blk.mid, a_scale=gate, a_rows=To * Fo)
+                self._gemm(dw_buf, w, b, nxt, rows_o, blk.cout, blk.mid, a_scale=gate, a_rows=To * Fo, wfrag=wf)
                 cur, nxt = nxt, cur
             T, F = To, Fo
-        w, b = pk["head"]
+        w, b, wf = pk["head"]
         rows = B * T * F
         Ch = w.shape[0]
-        self._gemm(cur, w, b, mid_buf, rows, Ch, w.shape[1], act=2)
+        self._gemm(cur, w, b, mid_buf, rows, Ch, w.shape[1], act=2, wfrag=wf)
         attn = torch.empty(B, T, Ch, device=dev, dtype=torch.float32)
         K.rows_mean_w(mid_buf, attn, B, T, T, F, Ch)            # mean over mel: 'b c f t -> b t c'
         return attn

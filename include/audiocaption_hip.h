@@ -386,6 +386,16 @@ int ac_effnet_depthwise(const float* x, const float* w, const float* scale, cons
 /* gate[b][c] = sigmoid(w2 swish(w1 (pool[b] * inv_count) + b1) + b2), w1 [S][C], w2 [C][S]. */
 int ac_effnet_se_gate(const float* pool, float inv_count, const float* w1, const float* b1, const float* w2,
                       const float* b2, float* gate, int B, int C, int S, void* stream);
+/* 1x1 convolution / linear layer with static weights on the split-bf16 matrix path (csrc/pw_gemm.hip), the same contract
+ * as ac_pointwise_conv: y[M][N] = act((x[M][K] .* gate[m / gate_rows][K]) w^T + bias) + beta * y, for the matrix-bound
+ * layers (thousands of rows against hundreds of channels).  The weights are split into bf16 hi + lo and laid out in MFMA
+ * fragment order ONCE by ac_pw_gemm_pack (w [N][K] f32 -> wfrag, ac_pw_gemm_packed_bytes(N, K) bytes, 16-byte aligned);
+ * activations are split when staged; three bf16 MFMAs per product, f32 accumulation (2^-16 relative operand error).
+ * K % 4 == 0, N % 4 == 0, act 0 none / 1 ReLU / 2 swish, 16-byte aligned pointers. */
+long ac_pw_gemm_packed_bytes(int N, int K);
+int ac_pw_gemm_pack(const float* w, void* wfrag, int N, int K, void* stream);
+int ac_pw_gemm_bf16x3(const float* x, const void* wfrag, const float* bias, float* y, long M, int N, int K, int act,
+                      float beta, const float* gate, int gate_rows, void* stream);
 /* The same gate with the second matrix transposed, w2t [S][C] (= _se_expand.weight^T): one launch per block, both
  * phases read their weights with coalesced 16-byte loads.  C % 4 == 0, 16-byte aligned pointers. */
 int ac_effnet_se_gate_t(const float* pool, float inv_count, const float* w1, const float* b1, const float* w2t,

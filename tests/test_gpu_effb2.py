@@ -216,6 +216,36 @@ def test_se_gate_and_gated_projection(lib):
     assert rel("swish epilogue", y2, ref2) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(8192, 1248, 208), (8200, 208, 1248), (4097, 352, 2112), (1344, 768, 256), (300, 88, 528),
+                                   (32256, 120, 720), (70, 1408, 352)])
+def test_pw_gemm_bf16x3_vs_float64(lib, M, N, K):
+    """ac_pw_gemm_bf16x3 (activation-stationary split-bf16 1x1 convolution over weights pre-split in MFMA fragment order,
+    csrc/pw_gemm.hip) against float64 on EfficientNet-B2's matrix-bound shapes: the three tile heights, K and N that are
+    not multiples of 32 (zero-padded fragments), column groups with one and two tiles per wave, row tails; plain, swish,
+    and the squeeze-excite form y = res + (x .* gate[clip]) w^T + b.  2^-16 relative operand error: 3e-5 of the
+    largest output (the bar of ac_gemm_bf16x3)."""
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+    wfrag = torch.empty(lib.ac_pw_gemm_packed_bytes(N, K), device="cuda", dtype=torch.uint8)
+    assert lib.ac_pw_gemm_pack(P(wd), P(wfrag), N, K, S()) == 0
+    y = torch.full((M, N), float("nan"), device="cuda")
+    assert lib.ac_pw_gemm_bf16x3(P(xd), P(wfrag), P(bd), P(y), M, N, K, 0, 0.0, None, 0, S()) == 0
+    ref = x.double() @ w.double().t() + b.double()
+    assert rel("pw gemm: x w^T + b", y, ref) < 3e-5
+    assert lib.ac_pw_gemm_bf16x3(P(xd), P(wfrag), P(bd), P(y), M, N, K, 2, 0.0, None, 0, S()) == 0
+    assert rel("pw gemm: swish", y, ref * torch.sigmoid(ref)) < 3e-5
+    rows_per = 64
+    gate = torch.rand((M + rows_per - 1) // rows_per, K, generator=g)
+    res = torch.randn(M, N, generator=g)
+    yg, gd = res.clone().cuda(), gate.cuda()
+    assert lib.ac_pw_gemm_bf16x3(P(xd), P(wfrag), P(bd), P(yg), M, N, K, 0, 1.0, P(gd), rows_per, S()) == 0
+    xg = x.double() * gate.double().repeat_interleave(rows_per, 0)[:M]
+    assert rel("pw gemm: gated x w^T + b + res", yg, res.double() + xg @ w.double().t() + b.double()) < 3e-5
+
+
 def test_logmel_htk_top_db_vs_oracle(effb2_model):
     from audiocaption_amd import procedural as Pr
     from oracle import effb2_path as E
