@@ -104,6 +104,9 @@ SIGNATURES = {
     "ac_pw_gemm_packed_bytes": (_L, [_I, _I]),
     "ac_pw_gemm_pack": (_I, [_P, _P, _I, _I, _P]),
     "ac_pw_gemm_bf16x3": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _F, _P, _I, _P]),
+    "ac_pw_gemm_bf16x3_ex": (_I, [_P, _L, _P, _P, _P, _L, _L, _I, _I, _I, _F, _P, _I, _F, _U64, _P, _L, _P]),
+    "ac_pw_gemm_pack_strided": (_I, [_P, _L, _L, _P, _I, _I, _P]),
+    "ac_pw_gemm_pack_table": (_I, [_P, _I, _P]),
     "ac_effnet_se_gate_t": (_I, [_P, _F, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ac_effnet_expand_depthwise": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     # waveform ingest (csrc/ingest.hip)

@@ -20,6 +20,7 @@
 // Arithmetic: x = hi + lo (bf16, RNE), products lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_bf16, f32 accumulation -
 // 2^-16 relative operand error, the same as the split-bf16 conv tier and ac_gemm_bf16x3.
 #include "ac_common.h"
+#include "ac_drop.h"
 #include <stdlib.h>
 
 namespace {
@@ -30,8 +31,10 @@ constexpr int PG_ROW = 40;   // bf16 per LDS row: 32 k + 8 pad (80 B: a lane's 1
 
 struct PwgP {
   const float* x; const pg_bf16x8* wf; const float* bias; float* y; const float* gate;
+  long ldx, ldy, row0;                                     // row strides in floats; row0: dropout index of row 0
   int M, N, K, KC, NT32, act, gate_rows;
   float beta;
+  Drop drop;                                               // inverted dropout on the output (training forward), off: thresh 0
 };
 
 __device__ __forceinline__ unsigned pg_cvt_pk_bf16(float lo, float hi) {
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void pw_bf16x3_kernel(PwgP p) {
     const int m = m0 + row;
     rok[j] = m < p.M;
     const int mc = rok[j] ? m : p.M - 1;
-    xrow[j] = p.x + (long)mc * p.K + kq * 4;
+    xrow[j] = p.x + (long)mc * p.ldx + kq * 4;
     grow[j] = p.gate ? p.gate + (long)(mc / p.gate_rows) * p.K + kq * 4 : nullptr;
     sdst[j] = row * PG_ROW + kq * 4;
   }
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void pw_bf16x3_kernel(PwgP p) {
     for (int a = 0; a < MW; ++a) {
       const int m = m0 + a * 32 + (lane & 31);
       if (m >= p.M) continue;
-      float* yr = p.y + (long)m * p.N;
+      float* yr = p.y + (long)m * p.ldy;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int n = nb + 8 * g;
@@ -197,6 +200,10 @@ __global__ __launch_bounds__(256, 2) void pw_bf16x3_kernel(PwgP p) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
         }
+        if (p.drop.thresh != 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] *= p.drop.mask((uint64_t)(p.row0 + m) * (uint64_t)p.N + (uint64_t)(n + q));
+        }
         if (p.beta != 0.f) v += p.beta * *(const f32x4*)(yr + n);
         *(f32x4*)(yr + n) = v;
       }
@@ -204,8 +211,17 @@ __global__ __launch_bounds__(256, 2) void pw_bf16x3_kernel(PwgP p) {
   }
 }
 
-// ---- weight packing: W [N][K] f32 -> fragment order, split into bf16 hi / lo (RNE); K, N padded with zeros ----
-__global__ void pw_pack_kernel(const float* w, __bf16* out, int N, int K, int NT32, int KS) {
+// ---- weight packing: W(n, k) = w[n * s_n + k * s_k] f32 -> fragment order, split into bf16 hi / lo (RNE); K, N padded
+// with zeros.  One launch packs a whole table of layers (blockIdx.y = layer): the training step repacks every weight
+// after each optimiser update. ----
+struct PwPackDesc {
+  const float* w; __bf16* out;
+  long s_n, s_k;
+  int N, K;
+};
+__global__ void pw_pack_kernel(const PwPackDesc* table) {
+  const PwPackDesc d = table[blockIdx.y];
+  const int NT32 = (d.N + 31) / 32, KS = (d.K + 31) / 32 * 2;
   const long total = (long)KS * NT32 * 2 * 64 * 8;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
     const int e = (int)(i & 7);
@@ -214,9 +230,24 @@ __global__ void pw_pack_kernel(const float* w, __bf16* out, int N, int K, int NT
     const long t = i >> 10;
     const int nt = (int)(t % NT32), kk = (int)(t / NT32);
     const int n = nt * 32 + (lane & 31), k = kk * 16 + 8 * (lane >> 5) + e;
-    float v = (n < N && k < K) ? w[(long)n * K + k] : 0.f;
+    const float v = (n < d.N && k < d.K) ? d.w[(long)n * d.s_n + (long)k * d.s_k] : 0.f;
     const __bf16 h = (__bf16)v;
-    out[i] = plane == 0 ? h : (__bf16)(v - (float)h);
+    d.out[i] = plane == 0 ? h : (__bf16)(v - (float)h);
+  }
+}
+__global__ void pw_pack_one_kernel(PwPackDesc d) {
+  const int NT32 = (d.N + 31) / 32, KS = (d.K + 31) / 32 * 2;
+  const long total = (long)KS * NT32 * 2 * 64 * 8;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+    const int e = (int)(i & 7);
+    const int lane = (int)((i >> 3) & 63);
+    const int plane = (int)((i >> 9) & 1);
+    const long t = i >> 10;
+    const int nt = (int)(t % NT32), kk = (int)(t / NT32);
+    const int n = nt * 32 + (lane & 31), k = kk * 16 + 8 * (lane >> 5) + e;
+    const float v = (n < d.N && k < d.K) ? d.w[(long)n * d.s_n + (long)k * d.s_k] : 0.f;
+    const __bf16 h = (__bf16)v;
+    d.out[i] = plane == 0 ? h : (__bf16)(v - (float)h);
   }
 }
 
@@ -230,24 +261,40 @@ long ac_pw_gemm_packed_bytes(int N, int K) {
   return (long)((K + 31) / 32) * 2 * ((N + 31) / 32) * 2 * 64 * 16;
 }
 
-int ac_pw_gemm_pack(const float* w, void* wfrag, int N, int K, void* stream) {
+int ac_pw_gemm_pack_strided(const float* w, long s_n, long s_k, void* wfrag, int N, int K, void* stream) {
   if (!w || !wfrag || N <= 0 || K <= 0) return AC_ERR_ARG;
-  const int NT32 = (N + 31) / 32, KS = (K + 31) / 32 * 2;
-  const long total = (long)KS * NT32 * 2 * 64 * 8;
+  PwPackDesc d;
+  d.w = w; d.out = (__bf16*)wfrag; d.s_n = s_n; d.s_k = s_k; d.N = N; d.K = K;
+  const long total = ac_pw_gemm_packed_bytes(N, K) / 2;
   long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(pw_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)wfrag, N, K, NT32, KS);
+  hipLaunchKernelGGL(pw_pack_one_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d);
   return ac_check_launch();
 }
 
-int ac_pw_gemm_bf16x3(const float* x, const void* wfrag, const float* bias, float* y, long M, int N, int K, int act,
-                      float beta, const float* gate, int gate_rows, void* stream) {
+int ac_pw_gemm_pack(const float* w, void* wfrag, int N, int K, void* stream) {
+  return ac_pw_gemm_pack_strided(w, K, 1, wfrag, N, K, stream);
+}
+
+// table: `count` records of 40 bytes in DEVICE memory - {const float* w, void* wfrag, long s_n, long s_k, int N, int K}
+// (the layout of PwPackDesc); one launch packs them all.
+int ac_pw_gemm_pack_table(const void* table, int count, void* stream) {
+  if (!table || count <= 0 || count > 65535) return AC_ERR_ARG;
+  hipLaunchKernelGGL(pw_pack_kernel, dim3(64, (unsigned)count), dim3(256), 0, (hipStream_t)stream, (const PwPackDesc*)table);
+  return ac_check_launch();
+}
+
+int ac_pw_gemm_bf16x3_ex(const float* x, long ldx, const void* wfrag, const float* bias, float* y, long ldy, long M, int N,
+                         int K, int act, float beta, const float* gate, int gate_rows, float drop_p,
+                         unsigned long long drop_seed, const unsigned long long* seed_dev, long row0, void* stream) {
   if (!x || !wfrag || !y || M <= 0 || M > 2147483647L || N <= 0 || K <= 0 || (K & 3) || (N & 3) || act < 0 || act > 2 ||
+      ldx < K || ldy < N || (ldx & 3) || (ldy & 3) || drop_p < 0.f || drop_p >= 1.f ||
       (gate && gate_rows <= 0) || ((uintptr_t)x & 15) || ((uintptr_t)wfrag & 15) || ((uintptr_t)y & 15) ||
       (bias && ((uintptr_t)bias & 15)) || (gate && ((uintptr_t)gate & 15)))
     return AC_ERR_ARG;
   PwgP p;
   p.x = x; p.wf = (const pg_bf16x8*)wfrag; p.bias = bias; p.y = y; p.gate = gate;
+  p.ldx = ldx; p.ldy = ldy; p.row0 = row0; p.drop = make_drop(drop_p, drop_seed, seed_dev);
   p.M = (int)M; p.N = N; p.K = K; p.KC = (K + 31) / 32; p.NT32 = (N + 31) / 32; p.act = act; p.gate_rows = gate ? gate_rows : 1;
   p.beta = beta;
   const unsigned gy = (unsigned)((p.NT32 + 7) / 8);
@@ -266,6 +313,11 @@ int ac_pw_gemm_bf16x3(const float* x, const void* wfrag, const float* bias, floa
   if (mw == 2) hipLaunchKernelGGL(pw_bf16x3_kernel<2>, dim3((unsigned)((M + 63) / 64), gy), dim3(256), 0, st, p);
   else hipLaunchKernelGGL(pw_bf16x3_kernel<1>, dim3((unsigned)((M + 31) / 32), gy), dim3(256), 0, st, p);
   return ac_check_launch();
+}
+
+int ac_pw_gemm_bf16x3(const float* x, const void* wfrag, const float* bias, float* y, long M, int N, int K, int act,
+                      float beta, const float* gate, int gate_rows, void* stream) {
+  return ac_pw_gemm_bf16x3_ex(x, K, wfrag, bias, y, N, M, N, K, act, beta, gate, gate_rows, 0.f, 0ull, nullptr, 0, stream);
 }
 
 }  // extern "C"

@@ -197,7 +197,13 @@ class TrainEngine:
         self._phase = "forward"
         # GEMMs of the step: "bf16x3" = split-bf16 operands on the bf16 MFMA for the large products (the backward over
         # all rows, teacher forcing), "f32" = exact f32 MFMA everywhere
-        self.gemm_algo = os.environ.get("AUDIOCAPTION_TRAIN_GEMM", "bf16x3")
+        # "pw" (default) = "bf16x3" with the products against a WEIGHT matrix (x W^T and dy W, two thirds of the GEMM time)
+        # on ac_pw_gemm_bf16x3: weights re-split into MFMA fragment order once per iteration (one launch for the whole
+        # table), activations split once per 256 output columns; the same three-product arithmetic, bit-identical results
+        self.gemm_algo = os.environ.get("AUDIOCAPTION_TRAIN_GEMM", "pw")
+        self._pw = {}          # (weight address, N, K, transposed) -> packed-fragment tensor
+        self._pw_table = None  # device copy of the pack records (ac_pw_gemm_pack_table)
+        self._pw_hold = []     # tables captured graphs may still reference
         self.gru_algo = os.environ.get("AUDIOCAPTION_GRU_ALGO", "split")   # forward recurrence kernel (see RnnEncoder)
 
     # ---- small launch helpers (raw addresses; s = stream handle) ------------------------------------------
@@ -207,7 +213,7 @@ class TrainEngine:
         if hook is not None:
             info = {"phase": self._phase, "M": M, "N": N, "K": K, "flops": 2.0 * M * N * K}
             hook("pre", info)
-        if self.gemm_algo == "bf16x3":
+        if self.gemm_algo in ("bf16x3", "pw"):
             # split-bf16 operands (2^-16), f32 accumulation; small or unaligned products fall through to exact f32
             check(self.lib.ac_gemm_bf16x3(A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, bias, relu, beta, splitk, drop_p, seed,
                                           self._seed_ptr, row0, None, 0, s), "ac_gemm_bf16x3")
@@ -217,13 +223,78 @@ class TrainEngine:
         if hook is not None:
             hook("post", info)
 
+    # ---- products against a weight matrix on the activation-stationary kernel (csrc/pw_gemm.hip) ----
+    def _pw_frag(self, s, W, N, K, transposed):
+        """Packed fragments of W[N][K] (transposed: of W^T, for dy W).  A new layer is packed on the spot and joins the table
+        that ``_pw_pack_all`` repacks at the start of every iteration."""
+        key = (W, N, K, transposed)
+        frag = self._pw.get(key)
+        if frag is None:
+            n, k = (K, N) if transposed else (N, K)
+            frag = torch.empty(self.lib.ac_pw_gemm_packed_bytes(n, k), device=self.flat.flat.device, dtype=torch.uint8)
+            self._pw[key] = frag
+            self._pw_table = None
+            s_n, s_k = (1, K) if transposed else (K, 1)
+            check(self.lib.ac_pw_gemm_pack_strided(W, s_n, s_k, frag.data_ptr(), n, k, s), "ac_pw_gemm_pack_strided")
+        return frag.data_ptr()
+
+    def _pw_pack_all(self, s):
+        """Re-split every registered weight (they changed in the optimiser step): one launch over a device-resident table."""
+        if self.gemm_algo != "pw" or not self._pw:
+            return
+        self._pw_build()
+        table, count = self._pw_table
+        check(self.lib.ac_pw_gemm_pack_table(table.data_ptr(), count, s), "ac_pw_gemm_pack_table")
+
+    def _pw_build(self):
+        """The device-resident table of pack records; built outside any graph capture (it is a host upload)."""
+        if self._pw_table is None and self._pw:
+            import struct
+            rec = b""
+            for (W, N, K, transposed), frag in self._pw.items():
+                n, k = (K, N) if transposed else (N, K)
+                s_n, s_k = (1, K) if transposed else (K, 1)
+                rec += struct.pack("<QQqqii", W, frag.data_ptr(), s_n, s_k, n, k)
+            table = torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(self.flat.flat.device)
+            self._pw_table = (table, len(self._pw))
+            self._pw_hold.append(table)     # a captured graph may still replay an older table
+
+    @staticmethod
+    def _pw_ok(M, N, K, ldx, ldy, *ptrs):
+        # enough 32-row x 256-column workgroups to occupy the chip: the few-row products of the free-running passes stay
+        # on the small-tile exact-f32 kernels ac_gemm_bf16x3 forwards them to
+        return (float(M) * N * K >= 3.0e7 and ((M + 31) // 32) * ((N + 255) // 256) >= 128 and N % 4 == 0 and K % 4 == 0 and
+                ldx % 4 == 0 and ldy % 4 == 0 and all(q is None or q % 16 == 0 for q in ptrs))
+
     def _lin(self, s, x, W, b, y, M, N, K, ldx=None, ldy=None, relu=0, drop_p=0.0, seed=0, row0=0):
         """y[M][N] = x[M][K] W[N][K]^T + b"""
-        self._gemm(s, x, ldx or K, 1, W, 1, K, y, ldy or N, M, N, K, b, relu, 0.0, 1, drop_p, seed, row0)
+        ldx, ldy = ldx or K, ldy or N
+        if self.gemm_algo == "pw" and self._pw_ok(M, N, K, ldx, ldy, x, W, b, y):
+            hook = GEMM_HOOK
+            if hook is not None:
+                info = {"phase": self._phase, "M": M, "N": N, "K": K, "flops": 2.0 * M * N * K}
+                hook("pre", info)
+            check(self.lib.ac_pw_gemm_bf16x3_ex(x, ldx, self._pw_frag(s, W, N, K, False), b, y, ldy, M, N, K, relu, 0.0, None,
+                                                0, drop_p, seed, self._seed_ptr, row0, s), "ac_pw_gemm_bf16x3_ex")
+            if hook is not None:
+                hook("post", info)
+            return
+        self._gemm(s, x, ldx, 1, W, 1, K, y, ldy, M, N, K, b, relu, 0.0, 1, drop_p, seed, row0)
 
     def _lin_dx(self, s, dy, W, dx, M, N, K, beta=0.0, lddy=None, lddx=None):
         """dx[M][K] (+)= dy[M][N] W[N][K]"""
-        self._gemm(s, dy, lddy or N, 1, W, K, 1, dx, lddx or K, M, K, N, None, 0, beta)
+        lddy, lddx = lddy or N, lddx or K
+        if self.gemm_algo == "pw" and self._pw_ok(M, K, N, lddy, lddx, dy, W, dx):
+            hook = GEMM_HOOK
+            if hook is not None:
+                info = {"phase": self._phase, "M": M, "N": K, "K": N, "flops": 2.0 * M * N * K}
+                hook("pre", info)
+            check(self.lib.ac_pw_gemm_bf16x3_ex(dy, lddy, self._pw_frag(s, W, N, K, True), None, dx, lddx, M, K, N, 0, beta,
+                                                None, 0, 0.0, 0, None, 0, s), "ac_pw_gemm_bf16x3_ex")
+            if hook is not None:
+                hook("post", info)
+            return
+        self._gemm(s, dy, lddy, 1, W, K, 1, dx, lddx, M, K, N, None, 0, beta)
 
     @staticmethod
     def _splitk(M, N, K):
@@ -244,6 +315,7 @@ class TrainEngine:
         if self.flat is None or not self.flat.intact() or self.flat.flat.device != device:
             self.flat = FlatParams(self.model)
             self._states = {}
+            self._pw, self._pw_table = {}, None
             _lib.bump_param_generation(self.flat.params)
 
     @staticmethod
@@ -380,6 +452,7 @@ class TrainEngine:
         teacher_forcing = st["teacher_forcing"]
         small = st["small"].data_ptr()
         self._seed_ptr = small
+        self._pw_pack_all(s)        # the optimiser moved the weights since the last iteration
         lens_p, ucap, mvalid = small + 8, small + 4 * (2 + 2 * N), small + 4 * (2 + 2 * N + max(T, 1))
         R, S, passes = lay["R"], lay["S"], lay["passes"]
         NP = len(passes)
@@ -796,6 +869,7 @@ class TrainEngine:
         parts = ["fwd0"] + [("pass", t) for t in st["free_ts"]] + (["tail_head", "gru"] if world > 1 else ["tail"])
         graphs = st.setdefault("graphs", {})
         eager = (not use_graph) or st["steps"] < 2      # first iteration of this shape: eager (also the warm-up)
+        self._pw_build()                                # (the eager iteration registered the layers; never inside a capture)
         works = []
         for part in parts:
             if eager:

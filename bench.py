@@ -265,10 +265,14 @@ def bench_train(args, ranks, steps, warmup, with_rccl=False):
         fl_b, ms_b = sum(i["flops"] for _, i in bwd), sum(t for t, _ in bwd)
         fl_f, ms_f = sum(i["flops"] for _, i in fwd), sum(t for t, _ in fwd)
         big = max(bwd, key=lambda x: x[1]["flops"])
-        split = engine.gemm_algo == "bf16x3"
+        split = engine.gemm_algo in ("bf16x3", "pw")
         peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
         roof = {"bound": "mfma",
-                "kernel": ("gemm_bf16x3_kernel (ac_gemm_bf16x3: operands split into bf16 hi + lo at staging, three "
+                "kernel": ("pw_bf16x3_kernel for dy W (ac_pw_gemm_bf16x3: weights re-split into MFMA fragment order once per "
+                           "iteration, activations split once per 256 columns) + gemm_bf16x3_kernel for dy^T x (ac_gemm_bf16x3: "
+                           "both operands split into bf16 hi + lo at staging); three v_mfma_f32_32x32x16_bf16 per product, f32 "
+                           "accumulation; small / unaligned products on the exact-f32 kernels" if engine.gemm_algo == "pw" else
+                           "gemm_bf16x3_kernel (ac_gemm_bf16x3: operands split into bf16 hi + lo at staging, three "
                            "v_mfma_f32_32x32x16_bf16 per product, f32 accumulation; small / unaligned products on the exact-f32 "
                            "kernels)" if split else "gemm_general / gemm_nt / gemm_kk (ac_gemm, exact f32 v_mfma_f32_32x32x2_f32)")
                           + f": the {len(bwd)} dgrad + wgrad launches of one backward pass",
@@ -295,7 +299,7 @@ def bench_train(args, ranks, steps, warmup, with_rccl=False):
         "value": world * B * steps / elapsed, "unit": "clips/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16x3 frozen convolutions and large GEMMs (split-bf16 operands, f32 accumulation), f32 elsewhere"
-                 if engine.gemm_algo == "bf16x3" else "bf16x3 frozen convolutions, f32 everything trained",
+                 if engine.gemm_algo in ("bf16x3", "pw") else "bf16x3 frozen convolutions, f32 everything trained",
         "data": "synthetic",
         "config": {"workload": f"training step, batch {B} per GPU ({world * B} global), {args.seconds:g} s @ 32 kHz clips, "
                                f"captions of {cap_len} tokens, vocab {vocab}, scheduled sampling 0.85, dropout on "
@@ -458,11 +462,9 @@ def _decoder_rooflines(model, dev, B, vocab, max_length):
     P = lambda t: ctypes.c_void_p(t.data_ptr())
     M = B * 21
     shapes = [("self-attn qkv", 3 * d, d), ("attn out", d, d), ("ffn1", ffn, d), ("ffn2", d, ffn), ("classifier", vocab, d)]
-    rows, tot_flops, tot_us = [], 0.0, 0.0
-    for name, N, Kd in shapes:
-        x, w = torch.randn(M, Kd, device=dev), torch.randn(N, Kd, device=dev)
-        b, y = torch.randn(N, device=dev), torch.empty(M, N, device=dev)
-        call = lambda: lib.ac_gemm(P(x), Kd, 1, P(w), 1, Kd, P(y), N, M, N, Kd, P(b), 0, 0.0, 1, 0.0, 0, None, 0, None, 0, S)
+    rows, tot_flops, tot_us, tot_us_f32 = [], 0.0, 0.0, 0.0
+
+    def time_call(call):
         for _ in range(3):
             call()
         e0.record()
@@ -470,11 +472,23 @@ def _decoder_rooflines(model, dev, B, vocab, max_length):
             call()
         e1.record()
         torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / 20
+        return e0.elapsed_time(e1) * 1e3 / 20
+
+    for name, N, Kd in shapes:
+        x, w = torch.randn(M, Kd, device=dev), torch.randn(N, Kd, device=dev)
+        b, y = torch.randn(N, device=dev), torch.empty(M, N, device=dev)
+        wfrag = torch.empty(lib.ac_pw_gemm_packed_bytes(N, Kd), device=dev, dtype=torch.uint8)
+        lib.ac_pw_gemm_pack(P(w), P(wfrag), N, Kd, S)
+        # the kernel the training step's x W^T products run on (weights re-split once per iteration), and the exact-f32 one
+        us = time_call(lambda: lib.ac_pw_gemm_bf16x3(P(x), P(wfrag), P(b), P(y), M, N, Kd, 0, 0.0, None, 0, S))
+        us_f32 = time_call(lambda: lib.ac_gemm(P(x), Kd, 1, P(w), 1, Kd, P(y), N, M, N, Kd, P(b), 0, 0.0, 1, 0.0, 0, None, 0,
+                                               None, 0, S))
         fl = 2.0 * M * N * Kd
-        rows.append({"gemm": f"{name} ({M} x {N} x {Kd})", "us": us, "tflops": fl / us / 1e6})
+        rows.append({"gemm": f"{name} ({M} x {N} x {Kd})", "us": us, "tflops": fl / us / 1e6, "us_exact_f32": us_f32,
+                     "tflops_exact_f32": fl / us_f32 / 1e6})
         tot_flops += fl * (nl if name != "classifier" else 1)
         tot_us += us * (nl if name != "classifier" else 1)
+        tot_us_f32 += us_f32 * (nl if name != "classifier" else 1)
     return {
         "decode_step": {"bound": "latency (weight stream)", "us_per_step": step_us, "rows": B,
                         "weight_bytes_per_step": step_bytes, "achieved": step_bytes / (step_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
@@ -483,10 +497,17 @@ def _decoder_rooflines(model, dev, B, vocab, max_length):
                         "note": "one KV-cached greedy step over the whole batch, from the replayed HIP graph: a dependent "
                                 "chain of small kernels; neither HBM nor the matrix cores are the limit at 64 rows"},
         "teacher_forced_gemms": {"bound": "mfma", "rows": M, "achieved": tot_flops / tot_us / 1e6, "peak": FP32_MFMA_PEAK_TFLOPS,
-                                 "unit": "TFLOP/s", "frac": tot_flops / tot_us / 1e6 / FP32_MFMA_PEAK_TFLOPS, "dtype": "f32",
+                                 "unit": "TFLOP/s", "frac": tot_flops / tot_us / 1e6 / FP32_MFMA_PEAK_TFLOPS, "dtype": "bf16x3",
+                                 "mfma_issue_frac_of_bf16_peak": 3.0 * tot_flops / tot_us / 1e6 / BF16_MFMA_PEAK_TFLOPS,
+                                 "exact_f32": {"achieved": tot_flops / tot_us_f32 / 1e6,
+                                               "frac": tot_flops / tot_us_f32 / 1e6 / FP32_MFMA_PEAK_TFLOPS},
                                  "per_gemm": rows,
-                                 "note": "the training GEMM (ac_gemm, exact f32 MFMA) on the decoder's layer shapes at "
-                                         "M = batch x 21 caption positions; layer GEMMs weighted x2 layers"},
+                                 "note": "ALGORITHMIC f32 FLOPs of the decoder's layer GEMMs at M = batch x 21 caption "
+                                         "positions (layer GEMMs weighted x2 layers) over the time of ac_pw_gemm_bf16x3 - "
+                                         "the kernel the training step's x W^T / dy W products run on: split-bf16 "
+                                         "operands, three bf16 MFMAs per product, f32 accumulation - against the f32 MFMA "
+                                         "peak (there is no TF32 on gfx950: this is the rate an exact-f32 decoder could "
+                                         "reach); exact_f32 = the same shapes on ac_gemm (v_mfma_f32_32x32x2_f32)"},
     }
 
 

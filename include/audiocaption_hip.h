@@ -396,6 +396,17 @@ long ac_pw_gemm_packed_bytes(int N, int K);
 int ac_pw_gemm_pack(const float* w, void* wfrag, int N, int K, void* stream);
 int ac_pw_gemm_bf16x3(const float* x, const void* wfrag, const float* bias, float* y, long M, int N, int K, int act,
                       float beta, const float* gate, int gate_rows, void* stream);
+/* The same with row strides (ldx, ldy in floats, multiples of 4) and inverted dropout on the output (mask = the counter
+ * hash of ac_gemm: element index (row0 + m) * N + n, seed + (*seed_dev << 16)): the training step's x W^T (+ bias, ReLU,
+ * dropout) and dy W (beta = 1) products (run.py:77-148 through transformer_model.py:20-32), whose weights change every
+ * iteration - ac_pw_gemm_pack_strided packs W(n, k) = w[n * s_n + k * s_k] (W^T for the input-gradient product), and
+ * ac_pw_gemm_pack_table repacks a whole device-resident table of layers in ONE launch: `count` records
+ * {const float* w; void* wfrag; long s_n; long s_k; int N; int K;} (40 bytes each). */
+int ac_pw_gemm_bf16x3_ex(const float* x, long ldx, const void* wfrag, const float* bias, float* y, long ldy, long M, int N,
+                         int K, int act, float beta, const float* gate, int gate_rows, float drop_p,
+                         unsigned long long drop_seed, const unsigned long long* seed_dev, long row0, void* stream);
+int ac_pw_gemm_pack_strided(const float* w, long s_n, long s_k, void* wfrag, int N, int K, void* stream);
+int ac_pw_gemm_pack_table(const void* table, int count, void* stream);
 /* The same gate with the second matrix transposed, w2t [S][C] (= _se_expand.weight^T): one launch per block, both
  * phases read their weights with coalesced 16-byte loads.  C % 4 == 0, 16-byte aligned pointers. */
 int ac_effnet_se_gate_t(const float* pool, float inv_count, const float* w1, const float* b1, const float* w2t,
