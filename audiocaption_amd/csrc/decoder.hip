@@ -17,6 +17,8 @@
 // 64-lane wavefront shuffles.
 #include "ac_common.h"
 #include "../../include/audiocaption_hip.h"
+#include <stdlib.h>
+#include <string.h>
 
 extern "C" int ac_linear(const float* X, const float* W, const float* bias, float* Y, int M, int N, int K,
                          long ldx, long ldw, long ldy, int relu, void* stream);
@@ -744,6 +746,98 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(const float* lp, int bea
   }
 }
 
+// The two kernels above as ONE pass per row (beam <= 8, V <= 256 NV): the logits of a row live in registers (one global
+// read instead of five sweeps), lp = log_softmax(log_softmax(x) / temp) + cum is never written - the row only publishes
+// its own best `beam` candidates (the clip's best `beam` are among the per-row best `beam`), picked by `beam` rounds of a
+// workgroup arg-max over the registers.  Same arithmetic in the same order as beam_logprob_kernel (the second maximum
+// is the image of the first: the map is increasing), same tie rule as beam_topk_kernel: identical results.
+template <int NV>
+__global__ __launch_bounds__(256) void beam_row_topk_kernel(const float* logit, const float* cum, float temp, int beam, int V,
+                                                            float* cand_val, int* cand_idx) {
+  __shared__ float sh[4];
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  __shared__ int s_win;
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* row = logit + (size_t)r * V;
+  float x[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) x[k] = tid + 256 * k < V ? row[tid + 256 * k] : -INFINITY;
+  float m = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) m = fmaxf(m, x[k]);
+  m = block_max256(m, sh);
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+    if (tid + 256 * k < V) s += expf(x[k] - m);
+  s = block_sum256(s, sh);
+  const float lse1 = m + logf(s);
+  const float inv_t = 1.0f / temp;
+  const float m2 = (m - lse1) * inv_t;
+  float s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+    if (tid + 256 * k < V) s2 += expf((x[k] - lse1) * inv_t - m2);
+  s2 = block_sum256(s2, sh);
+  const float lse2 = m2 + logf(s2);
+  const float cr = cum[r];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) x[k] = tid + 256 * k < V ? cr + ((x[k] - lse1) * inv_t - lse2) : -INFINITY;
+  unsigned taken = 0u;
+  const int flat0 = (r % beam) * V;           // index of the row's first entry in the clip's flattened scores
+  for (int j = 0; j < beam; ++j) {
+    float v = -INFINITY;
+    int idx = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+      if (!((taken >> k) & 1u) && tid + 256 * k < V) argmax_merge(v, idx, x[k], tid + 256 * k);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(v, o, 64);
+      const int oi = __shfl_xor(idx, o, 64);
+      argmax_merge(v, idx, ov, oi);
+    }
+    __syncthreads();
+    if (lane == 0) { sv[wave] = v; si[wave] = idx; }
+    __syncthreads();
+    if (tid == 0) {
+      v = sv[0]; idx = si[0];
+      for (int w = 1; w < 4; ++w) argmax_merge(v, idx, sv[w], si[w]);
+      s_win = idx;
+      cand_val[(size_t)r * beam + j] = v;
+      cand_idx[(size_t)r * beam + j] = flat0 + idx;
+    }
+    __syncthreads();
+    const int win = s_win;
+    if ((win & 255) == tid) taken |= 1u << (win >> 8);
+  }
+}
+
+// per clip: the `beam` best of the nrows x beam row candidates (<= 64: one per lane), lowest flattened index wins ties
+__global__ __launch_bounds__(64) void beam_merge_kernel(const float* cand_val, const int* cand_idx, int beam, int nrows,
+                                                       float* top_val, int* top_idx) {
+  const int clip = blockIdx.x, lane = threadIdx.x;
+  const int n = nrows * beam;
+  float v = lane < n ? cand_val[(size_t)clip * beam * beam + lane] : -INFINITY;
+  int idx = lane < n ? cand_idx[(size_t)clip * beam * beam + lane] : 0x7fffffff;
+  for (int j = 0; j < beam; ++j) {
+    float bv = v;
+    int bi = idx;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      argmax_merge(bv, bi, ov, oi);
+    }
+    if (lane == 0) {
+      top_val[clip * beam + j] = bv;
+      top_idx[clip * beam + j] = bi;
+    }
+    if (idx == bi) { v = -INFINITY; idx = 0x7fffffff; }
+  }
+}
+
 // Per-clip beam bookkeeping of base.py:290-323 on the device (one workgroup per clip, thread 0 does the serial part):
 // re-gather the token rows by the chosen previous beams, append the new words, record the beams that END this step
 // (in beam order, score = logprob / (t + 1)), apply the -1000 trick to their cumulative scores and retire the clip
@@ -1164,6 +1258,18 @@ extern "C" int ac_trm_beam_step(const ac_trm_weights* w, const float* memkv, con
   AC_TRY(decoder_step(w, memkv, mem_len, R, beam, Tm, max_len, t, tokens, key_mask, max_len + 1,
                       ws.cache[t & 1], ws, &fin, s));
   AC_TRY(classifier_step(w, fin, R, nullptr, 0, ws.lg, V, s));
+  static const bool two_kernels = getenv("AUDIOCAPTION_BEAM_TOPK") && !strcmp(getenv("AUDIOCAPTION_BEAM_TOPK"), "scan");
+  if (beam <= 8 && V <= 8192 && !two_kernels) {
+    // scores + per-row candidates in one pass over registers, then a one-wave merge per clip; the candidates (2 x R x
+    // beam words) go into the QKV scratch of the decoder step, which is dead until the next step starts
+    float* cand_val = ws.qkv;
+    int* cand_idx = (int*)(cand_val + (size_t)R * beam);
+    if (V <= 5120) hipLaunchKernelGGL(beam_row_topk_kernel<20>, dim3(R), dim3(256), 0, s, ws.lg, cum_logprob, temp, beam, V, cand_val, cand_idx);
+    else hipLaunchKernelGGL(beam_row_topk_kernel<32>, dim3(R), dim3(256), 0, s, ws.lg, cum_logprob, temp, beam, V, cand_val, cand_idx);
+    AC_TRY(ac_check_launch());
+    hipLaunchKernelGGL(beam_merge_kernel, dim3(B), dim3(64), 0, s, cand_val, cand_idx, beam, t == 0 ? 1 : beam, top_val, top_idx);
+    return ac_check_launch();
+  }
   // lp is written over the qkv/ff scratch?  No: it needs R*V floats, reuse a second logits-sized area.
   float* lp = ws.lg;  // in place: every element is read before it is written by the same thread
   hipLaunchKernelGGL(beam_logprob_kernel, dim3(R), dim3(256), 0, s, ws.lg, cum_logprob, temp, lp, V);

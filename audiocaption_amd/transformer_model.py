@@ -14,6 +14,8 @@ call per step (the reference loops over clips, base.py:266) with the reference's
 (done beams, -1000 trick, length-normalised score, early exit) done on the host from one small
 device->host copy per step.
 """
+import ctypes
+
 import numpy as np
 import os
 
@@ -356,39 +358,93 @@ class TransformerModel(CaptionModel):
         n_best_size = int(input_dict.get("n_best_size", beam))
         V = self.vocab_size
         R = B * beam
-        mem_len = K.upload(input_dict["attn_emb_len"], dev, torch.int32)
-        memkv = dec.memory(attn_emb)
-        ws = dec.workspace(R, max_length, dev)
+        A = attn_emb.shape[2]
 
         # Everything per step stays on the device: decoder step + scores + per-clip top-k (ac_trm_beam_step), the
         # per-clip bookkeeping of base.py:290-323 (ac_trm_beam_update) and the KV-cache re-gather
-        # (ac_trm_beam_reorder).  The host only asks now and then whether any clip is still searching.
+        # (ac_trm_beam_reorder).  The host only asks after steps 8, 12 and 16 whether any clip is still searching, so the
+        # ~14 launches x max_length steps are four fixed launch sequences: like the greedy chain they are captured per
+        # shape (second use) into HIP graphs over static buffers and replayed - a host-launched chain of ~280 small
+        # dependent kernels cannot keep up once it shares the device with the next batches' encoders.
         lib = _lib.load()
         ld = max_length + 1
         cap = beam * max_length                    # upper bound of finished beams per clip
-        i32 = dict(device=dev, dtype=torch.int32)
-        tok = [torch.full((R, ld), self.end_idx, **i32) for _ in range(2)]
-        tok[0][:, 0] = self.start_idx
-        mask = torch.zeros(R, ld, device=dev, dtype=torch.uint8)
-        if self.start_idx == self.pad_idx or self.end_idx == self.pad_idx:
-            mask = (tok[0] == self.pad_idx).to(torch.uint8)
-        cum = torch.zeros(B * beam, device=dev, dtype=torch.float32)
-        active = torch.ones(B, **i32)
-        done_cnt = torch.zeros(B, **i32)
-        done_seq = torch.empty(B, cap, max_length, **i32)
-        done_score = torch.empty(B, cap, device=dev, dtype=torch.float32)
-        src_row = torch.empty(R, **i32)
-        n_active = torch.full((1,), B, **i32)
-        for t in range(max_length):
-            top_val, top_idx = dec.beam_step(memkv, mem_len, B, beam, Tm, max_length, t, temp, tok[t & 1], mask, cum, ws)
-            check(lib.ac_trm_beam_update(ptr(top_val), ptr(top_idx), ptr(tok[t & 1]), ptr(tok[(t + 1) & 1]), ptr(mask),
-                                         ptr(cum), ptr(active), ptr(done_cnt), ptr(done_seq), ptr(done_score),
-                                         ptr(src_row), ptr(n_active), B, beam, V, max_length, t, self.end_idx,
-                                         self.pad_idx, cap, stream()), "ac_trm_beam_update")
-            if t in (7, 11, 15) and int(n_active.item()) == 0:   # every clip has its `beam` finished beams
+        use_graph = os.environ.get("AUDIOCAPTION_DECODE_GRAPH", "1") != "0"
+        key = (dev, B, Tm, A, beam, max_length, temp, self.start_idx, self.end_idx, self.pad_idx, dec._weights_key())
+        if getattr(self, "_beam_state", None) is None:
+            self._beam_state = {}
+        states = self._beam_state
+        st = states.pop(key, None)
+        if st is None:
+            i32 = dict(device=dev, dtype=torch.int32)
+            f32 = dict(device=dev, dtype=torch.float32)
+            tok0 = torch.full((R, ld), self.end_idx, **i32)
+            tok0[:, 0] = self.start_idx
+            mask0 = torch.zeros(R, ld, device=dev, dtype=torch.uint8)
+            if self.start_idx == self.pad_idx or self.end_idx == self.pad_idx:
+                mask0 = (tok0 == self.pad_idx).to(torch.uint8)
+            ws_n = lib.ac_trm_workspace_floats(ctypes.byref(dec.weights()), R, max_length)
+            st = {"uses": 0, "graphs": {},
+                  "attn_emb": torch.empty(B, Tm, A, **f32), "mem_len": torch.empty(B, **i32),
+                  "memkv": torch.empty(dec.nlayers, B * Tm, 2 * dec.d_model, **f32),
+                  "tmp": torch.empty(B * Tm, dec.d_model, **f32), "ws": torch.empty(ws_n, **f32),
+                  "tok0": tok0, "tok1": torch.full((R, ld), self.end_idx, **i32), "mask0": mask0,
+                  "tok": [torch.empty(R, ld, **i32) for _ in range(2)],
+                  "mask": torch.empty(R, ld, device=dev, dtype=torch.uint8),
+                  "cum": torch.empty(R, **f32), "active": torch.empty(B, **i32), "done_cnt": torch.empty(B, **i32),
+                  "done_seq": torch.empty(B, cap, max_length, **i32), "done_score": torch.empty(B, cap, **f32),
+                  "src_row": torch.empty(R, **i32), "n_active": torch.empty(1, **i32),
+                  "top_val": torch.empty(B, beam, **f32), "top_idx": torch.empty(B, beam, **i32)}
+        states[key] = st                       # most recently used last
+        while len(states) > 4:
+            states.pop(next(iter(states)))
+        st["uses"] += 1
+        st["attn_emb"].copy_(K.f32c(attn_emb))
+        st["mem_len"].copy_(K.upload(input_dict["attn_emb_len"], dev, torch.int32))
+        tok, mask, cum, active = st["tok"], st["mask"], st["cum"], st["active"]
+        done_cnt, done_seq, done_score = st["done_cnt"], st["done_seq"], st["done_score"]
+        src_row, n_active, ws = st["src_row"], st["n_active"], st["ws"]
+        w = ctypes.byref(dec.weights())
+
+        def segment(t0, t1):
+            """Steps t0 .. t1 - 1 on the current stream (capturable: fixed launches over the static buffers)."""
+            if t0 == 0:
+                tok[0].copy_(st["tok0"])
+                tok[1].copy_(st["tok1"])
+                mask.copy_(st["mask0"])
+                cum.zero_()
+                active.fill_(1)
+                done_cnt.zero_()
+                n_active.fill_(B)
+                check(lib.ac_trm_memory(w, ptr(st["attn_emb"]), B, Tm, ptr(st["memkv"]), ptr(st["tmp"]), stream()),
+                      "ac_trm_memory")
+            for t in range(t0, t1):
+                check(lib.ac_trm_beam_step(w, ptr(st["memkv"]), ptr(st["mem_len"]), B, beam, Tm, max_length, t, float(temp),
+                                           ptr(tok[t & 1]), ptr(mask), ptr(cum), ptr(st["top_val"]), ptr(st["top_idx"]),
+                                           ptr(ws), stream()), "ac_trm_beam_step")
+                check(lib.ac_trm_beam_update(ptr(st["top_val"]), ptr(st["top_idx"]), ptr(tok[t & 1]), ptr(tok[(t + 1) & 1]),
+                                             ptr(mask), ptr(cum), ptr(active), ptr(done_cnt), ptr(done_seq),
+                                             ptr(done_score), ptr(src_row), ptr(n_active), B, beam, V, max_length, t,
+                                             self.end_idx, self.pad_idx, cap, stream()), "ac_trm_beam_update")
+                if t + 1 < max_length:
+                    check(lib.ac_trm_beam_reorder(w, R, max_length, t, ptr(src_row), ptr(ws), stream()),
+                          "ac_trm_beam_reorder")
+
+        bounds = [b for b in (0, 8, 12, 16) if b < max_length] + [max_length]
+        for t0, t1 in zip(bounds[:-1], bounds[1:]):
+            if t0 > 0 and int(n_active.item()) == 0:   # every clip has its `beam` finished beams (base.py:318-323)
                 break
-            if t + 1 < max_length:
-                dec.beam_reorder(R, max_length, t, src_row, ws)
+            if not use_graph or st["uses"] < 2:
+                segment(t0, t1)
+            else:
+                graph = st["graphs"].get(t0)
+                if graph is None:
+                    torch.cuda.synchronize(dev)
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        segment(t0, t1)
+                    st["graphs"][t0] = graph
+                graph.replay()
         counts = done_cnt.cpu().numpy()
         seqs = done_seq.cpu().numpy()
         scores = done_score.cpu().numpy()

@@ -283,8 +283,12 @@ def greedy_decode(state, attn_emb, attn_emb_len, max_length=20, prefix="decoder.
 # beam search (base.py:254-361, transformer_model.py:59-86)
 # ----------------------------------------------------------------------------------------
 def beam_search(state, attn_emb, attn_emb_len, beam_size=3, max_length=20, temp=1.0, prefix="decoder.",
-                start_idx=START_IDX, end_idx=END_IDX, pad_idx=PAD_IDX):
+                start_idx=START_IDX, end_idx=END_IDX, pad_idx=PAD_IDX, n_best=False, n_best_size=None):
+    """base.py:254-361.  n_best: "seq" is (B, n_best_size, max_length), the finished beams of a clip by descending
+    length-normalised score (base.py:258-263,354-358)."""
     B = attn_emb.shape[0]
+    n_best_size = beam_size if n_best_size is None else n_best_size
+    nbest_seq = torch.full((B, n_best_size, max_length), end_idx, dtype=torch.long)
     V = state[prefix + "classifier.weight"].shape[0]
     lens = torch.as_tensor(attn_emb_len)
     out_seq = torch.full((B, max_length), end_idx, dtype=torch.long)
@@ -322,7 +326,9 @@ def beam_search(state, attn_emb, attn_emb_len, beam_size=3, max_length=20, temp=
         best = done[0]["seq"]
         out_seq[i, :len(best)] = best
         scores[i] = done[0]["score"]
-    return {"seq": out_seq, "score": scores}
+        for j, d in enumerate(done[:n_best_size]):
+            nbest_seq[i, j, :len(d["seq"])] = d["seq"]
+    return {"seq": nbest_seq if n_best else out_seq, "score": scores}
 
 
 # ----------------------------------------------------------------------------------------

@@ -185,6 +185,33 @@ def test_g5_beam_tokens_identical_to_reference(hip_model, golden_dir):
         np.testing.assert_array_equal(out["seq"].numpy(), g[f"seq_beam{k}"])
 
 
+def test_beam_search_graph_replay_and_n_best(hip_model, state4981, golden_dir):
+    """The beam search runs as four captured launch sequences (steps 0-7, 8-11, 12-15, 16-19) from the second use of a
+    shape on: the first (eager), second (capture) and third (replay) call return the reference fixture's ids, also after a
+    call with another shape in between; n_best returns the finished beams by descending score as base.py:354-358 does
+    (checked against the oracle), its first row being the plain result."""
+    from oracle import cpu_path as O
+    g4 = _load(golden_dir, "g4_greedy.npz")
+    g = _load(golden_dir, "g5_beam.npz")
+    enc = {"attn_emb": torch.from_numpy(g4["attn_emb"]).cuda(), "attn_emb_len": torch.from_numpy(g4["attn_emb_len"]),
+           "fc_emb": torch.from_numpy(g4["fc_emb"]).cuda()}
+    req = {"mode": "inference", "sample_method": "beam", "beam_size": 3, "max_length": 20}
+    for i in range(4):
+        out = hip_model.forward_decoder(dict(req), enc)
+        np.testing.assert_array_equal(out["seq"].numpy(), g["seq_beam3"])
+        if i == 1:   # another shape (two clips) between capture and replay
+            enc2 = {k: v[:2] for k, v in enc.items()}
+            out2 = hip_model.forward_decoder(dict(req), enc2)
+            np.testing.assert_array_equal(out2["seq"].numpy(), g["seq_beam3"][:2])
+    for nb in (3, 2):
+        outn = hip_model.forward_decoder(dict(req, n_best=True, n_best_size=nb), enc)
+        assert tuple(outn["seq"].shape) == (enc["attn_emb"].shape[0], nb, 20)
+        want = O.beam_search(state4981, torch.from_numpy(g4["attn_emb"]), torch.from_numpy(g4["attn_emb_len"]), beam_size=3,
+                             max_length=20, n_best=True, n_best_size=nb)["seq"]
+        np.testing.assert_array_equal(outn["seq"].numpy(), want.numpy())
+        np.testing.assert_array_equal(outn["seq"][:, 0].numpy(), g["seq_beam3"])
+
+
 def test_wav_to_tokens_vs_oracle(hip_model, state4981, conv_tier):
     """Whole path from ragged waveforms, B=4 (the reference's own smoke shapes, cnn_encoder.py:845-849)."""
     tol = TIER_TOL[conv_tier]
