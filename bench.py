@@ -420,7 +420,7 @@ def bench_effb2(args, ranks, steps, warmup):
         "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 (1x1 convolutions on split-bf16 operands, f32 accumulation)"
-                 if os.environ.get("AUDIOCAPTION_EFFB2_GEMM", "bf16x3") == "bf16x3" else "f32", "data": "synthetic",
+                 if os.environ.get("AUDIOCAPTION_EFFB2_GEMM", "pw") in ("bf16x3", "pw") else "f32", "data": "synthetic",
         "config": {"workload": f"EffB2-Trm, batch {B} per GPU, {args.seconds:g} s @ 16 kHz synthetic clips, "
                                + (f"beam search (beam {args.beam})" if args.beam > 0 else "greedy")
                                + f", max_length {args.max_length}, vocab {vocab} (BASELINE configs[2]; configs[4] with "

@@ -332,10 +332,13 @@ def test_forward_async_pair_decode_mixed_shapes(hip_model):
     assert torch.equal(again["seq"], want[0]["seq"])
 
 
-def test_forward_async_beam_equals_blocking(hip_model):
+@pytest.mark.parametrize("group", ["1", "2"])
+def test_forward_async_beam_equals_blocking(hip_model, monkeypatch, group):
     """Beam search through forward_async (encoders submitted up front, the host-driven searches run at result() on the
-    decode stream) returns what the blocking call returns."""
+    decode stream) returns what the blocking call returns - also when consecutive submissions share one search
+    (AUDIOCAPTION_BEAM_GROUP=2: results asked for out of order, a group of two and a single)."""
     from audiocaption_amd import procedural as P
+    monkeypatch.setenv("AUDIOCAPTION_BEAM_GROUP", group)
     inputs = []
     for s_, lens in ((11, [48000, 40000, 33000]), (12, [48000, 48000, 21000]), (13, [30000, 48000, 47000])):
         w = torch.from_numpy(P.synthetic_wav(3, 48000, seed=s_, varied=True)).cuda()
