@@ -323,6 +323,59 @@ __global__ __launch_bounds__(256, 2) void dec_row_kernel(RowParams p) {
   }
 }
 
+// Both attention sub-layers of a decoder layer for one row in ONE launch: self attention -> out-projection -> LN1 -> cross
+// query projection (dec_row_kernel with WqT) and then, with the query still in LDS, cross attention -> out-projection ->
+// LN2 (dec_row_kernel on the audio memory).  Everything after the QKV projection is row-local, so the second launch only
+// bought a kernel boundary and a global round trip of the 256-float query.  The same functions in the same order: the
+// same bits as the two launches.
+__global__ __launch_bounds__(256, 2) void dec_row2_kernel(RowParams p1, RowParams p2) {
+  __shared__ float sc[ROW_H][MAX_KEYS];
+  __shared__ __attribute__((aligned(16))) float sx[ROW_D];
+  __shared__ __attribute__((aligned(16))) float sq[ROW_D];
+  __shared__ __attribute__((aligned(16))) float part[4 * ROW_D];
+  __shared__ float red[8];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float xn;
+  {
+    const float resv = p1.res[(size_t)r * p1.ldres + tid];
+    sx[tid] = attn_head_row(p1.a, r, wave, lane, sc[wave], true);
+    __syncthreads();
+    const float v = resv + row_gemv256(p1.WoT, p1.bo, sx, part, tid);
+    const float s1 = wave_sum(v);
+    if (lane == 0) red[wave] = s1;
+    __syncthreads();
+    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) * (1.0f / ROW_D);
+    const float dl = v - mean;
+    const float s2 = wave_sum(dl * dl);
+    if (lane == 0) red[4 + wave] = s2;
+    __syncthreads();
+    const float rstd = rsqrtf(((red[4] + red[5]) + (red[6] + red[7])) * (1.0f / ROW_D) + 1e-5f);
+    xn = dl * rstd * p1.ln_w[tid] + p1.ln_b[tid];
+    p1.xout[(size_t)r * p1.ldxo + tid] = xn;
+    sx[tid] = xn;
+    __syncthreads();
+    sq[tid] = row_gemv256(p1.WqT, p1.bq, sx, part, tid);
+    __syncthreads();
+  }
+  AttnParams a2 = p2.a;
+  a2.q = sq;            // the cross query of this row, still in LDS
+  a2.ldq = 0;
+  sx[tid] = attn_head_row(a2, r, wave, lane, sc[wave], true);
+  __syncthreads();
+  const float v = xn + row_gemv256(p2.WoT, p2.bo, sx, part, tid);
+  const float s1 = wave_sum(v);
+  __syncthreads();      // red[] of the first half has been read by every thread
+  if (lane == 0) red[wave] = s1;
+  __syncthreads();
+  const float mean = ((red[0] + red[1]) + (red[2] + red[3])) * (1.0f / ROW_D);
+  const float dl = v - mean;
+  const float s2 = wave_sum(dl * dl);
+  if (lane == 0) red[4 + wave] = s2;
+  __syncthreads();
+  const float rstd = rsqrtf(((red[4] + red[5]) + (red[6] + red[7])) * (1.0f / ROW_D) + 1e-5f);
+  p2.xout[(size_t)r * p2.ldxo + tid] = dl * rstd * p2.ln_w[tid] + p2.ln_b[tid];
+}
+
 // WT[k][n] = W[n][k] for a d x d matrix (rows n of W may be a slice of a taller matrix: ldw)
 __global__ void transpose_sq_kernel(const float* W, long ldw, int d, float* WT) {
   __shared__ float tile[32][33];
@@ -1046,8 +1099,12 @@ int decoder_step(const ac_trm_weights* w, const float* memkv, const int* mem_len
       rp.WoT = pk + PL[l].sa_outT; rp.bo = L.sa_out_b; rp.ln_w = L.n1_w; rp.ln_b = L.n1_b;
       rp.xout = xb; rp.ldxo = d;
       rp.WqT = pk + PL[l].ca_qT; rp.bq = L.ca_in_b; rp.qout = ws.q2; rp.ldqo = d;
-      hipLaunchKernelGGL(dec_row_kernel, dim3(R), dim3(256), 0, s, rp);
-      AC_TRY(ac_check_launch());
+      static const bool two_launches = getenv("AUDIOCAPTION_DEC_ROW") && !strcmp(getenv("AUDIOCAPTION_DEC_ROW"), "split");
+      const RowParams rp_self = rp;
+      if (two_launches) {
+        hipLaunchKernelGGL(dec_row_kernel, dim3(R), dim3(256), 0, s, rp);
+        AC_TRY(ac_check_launch());
+      }
       // ---- cross attention + out-projection + LN2 ----
       const float* mkf = memkv + (size_t)l * Rm * 2 * d;
       rp.a.q = ws.q2; rp.a.ldq = d;
@@ -1059,7 +1116,8 @@ int decoder_step(const ac_trm_weights* w, const float* memkv, const int* mem_len
       rp.WoT = pk + PL[l].ca_outT; rp.bo = L.ca_out_b; rp.ln_w = L.n2_w; rp.ln_b = L.n2_b;
       rp.xout = xa; rp.ldxo = d;
       rp.WqT = nullptr; rp.bq = nullptr; rp.qout = nullptr; rp.ldqo = 0;
-      hipLaunchKernelGGL(dec_row_kernel, dim3(R), dim3(256), 0, s, rp);
+      if (two_launches) hipLaunchKernelGGL(dec_row_kernel, dim3(R), dim3(256), 0, s, rp);
+      else hipLaunchKernelGGL(dec_row2_kernel, dim3(R), dim3(256), 0, s, rp_self, rp);   // both sub-layers, one launch
       AC_TRY(ac_check_launch());
       // ---- feed forward on the materialised x2 ----
       g.X = xa; g.ldx = d; g.Wp = pk + PL[l].l1; g.bias = L.l1_b; g.Y = ws.ff; g.ldy = w->dim_ff; g.N = w->dim_ff;

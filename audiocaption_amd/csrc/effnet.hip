@@ -9,6 +9,7 @@
 // each activation is read once; the squeeze-excite mean is accumulated by the depthwise kernel that produces the
 // tensor (LDS atomics per workgroup, one global atomic per channel per workgroup).
 #include "ac_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -379,7 +380,13 @@ int ac_effnet_depthwise(const float* x, const float* w, const float* scale, cons
   // output rows per workgroup: every thread (one channel group) should walk >= 2 rows when there are enough of them
   const int C4 = C / 4;
   const int rstep = C4 < 256 ? 256 / C4 : 1;
-  int rpb = rstep * 2;
+  static int mult = 0;
+  if (!mult) {
+    const char* e = getenv("AUDIOCAPTION_DW_ROWS");
+    mult = e ? atoi(e) : 4;   // measured at 128 clips: 2 -> 4 rows per thread -6...-16 us on the 63 x 4 and 32 x 2 stages, 8 and 16 slower
+    if (mult < 1) mult = 1;
+  }
+  int rpb = rstep * mult;
   if (rpb > p.To) rpb = p.To;
   p.pos_per_block = rpb;
   dim3 grid((p.To + rpb - 1) / rpb, B);

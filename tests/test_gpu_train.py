@@ -24,7 +24,20 @@ def S():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_KEEP = []   # P() only takes an address: temporaries such as ``x.cuda()`` are kept alive until the next test starts
+
+
+@pytest.fixture(autouse=True)
+def _drop_kept_tensors():
+    _KEEP.clear()
+    yield
+    _KEEP.clear()
+
+
 def P(t):
+    if t is None:
+        return None
+    _KEEP.append(t)
     return ctypes.c_void_p(t.data_ptr())
 
 
