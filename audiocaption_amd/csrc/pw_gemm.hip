@@ -53,6 +53,43 @@ __device__ __forceinline__ void pg_split4(const f32x4 x, pg_u32x2& hi, pg_u32x2&
   }
 }
 
+// ---- epilogue: lane = row m0 + 32 a + (lane & 31), registers 4 g .. 4 g + 3 = channels 8 g + 4 (lane >> 5) + 0..3 ----
+template <int MW>
+__device__ __forceinline__ void pw_epilogue(const PwgP& p, f32x16 (&acc)[MW][2], int m0, int nt0, bool on0, bool on1, int lane) {
+  if (!on0) return;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    if (b == 1 && !on1) break;
+    const int nb = (nt0 + b) * 32 + 4 * (lane >> 5);
+#pragma unroll
+    for (int a = 0; a < MW; ++a) {
+      const int m = m0 + a * 32 + (lane & 31);
+      if (m >= p.M) continue;
+      float* yr = p.y + (long)m * p.ldy;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = nb + 8 * g;
+        if (n >= p.N) continue;                       // N % 4 == 0: a quad is inside or outside as a whole
+        f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
+        if (p.bias) v += *(const f32x4*)(p.bias + n);
+        if (p.act == 2) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = ac_swish_fast(v[q]);
+        } else if (p.act == 1) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+        }
+        if (p.drop.thresh != 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] *= p.drop.mask((uint64_t)(p.row0 + m) * (uint64_t)p.N + (uint64_t)(n + q));
+        }
+        if (p.beta != 0.f) v += p.beta * *(const f32x4*)(yr + n);
+        *(f32x4*)(yr + n) = v;
+      }
+    }
+  }
+}
+
 template <int MW>
 __global__ __launch_bounds__(256, 2) void pw_bf16x3_kernel(PwgP p) {
   constexpr int BM = 32 * MW;
@@ -176,39 +213,120 @@ __global__ __launch_bounds__(256, 2) void pw_bf16x3_kernel(PwgP p) {
       __syncthreads();
     }
   }
-  // ---- epilogue: lane = row m0 + 32 a + (lane & 31), registers 4 g .. 4 g + 3 = channels 8 g + 4 (lane >> 5) + 0..3 ----
-  if (!on0) return;
+  pw_epilogue<MW>(p, acc, m0, nt0, on0, on1, lane);
+}
+
+// ---- long K with few workgroups (K >= 512 and at most one workgroup per CU: the decoder's 256 x 1024 second FFN matrix at
+// a thousand rows, EfficientNet's 1248 / 2112 -> 208 / 352 projections at 8 k rows): a 32-k step is then a serialised
+// chain - split, LDS write, barrier, fragment reads, 12 MFMAs - of ~1500 clocks with nothing else on the CU to hide it.
+// Same kernel with 128-k LDS buffers: one barrier per EIGHT k-steps (48 MFMAs per wave), 32-row tiles. ----
+constexpr int PG_ROWL = 136;   // bf16 per LDS row: 128 k + 8 pad
+
+__global__ __launch_bounds__(256, 2) void pw_bf16x3_longk_kernel(PwgP p) {
+  constexpr int NI = 4;                            // float4 staging items per thread and 128-k chunk (32 rows x 32 quads)
+  __shared__ __attribute__((aligned(16))) __bf16 sA[2][2][32 * PG_ROWL];   // [buffer][hi, lo]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * 32;
+  const int nt0 = blockIdx.y * 8 + wave * 2;
+  const bool on0 = nt0 < p.NT32, on1 = nt0 + 1 < p.NT32;
+  // staging: item j = float4 (row, k quad kq + 8 j... ) - a wave covers 8 rows x 32 consecutive floats per item
+  const int row = tid >> 3, kq = tid & 7;
+  const int m = m0 + row;
+  const bool rok = m < p.M;
+  const int mc = rok ? m : p.M - 1;
+  const float* xrow = p.x + (long)mc * p.ldx + kq * 4;
+  const float* grow = p.gate ? p.gate + (long)(mc / p.gate_rows) * p.K + kq * 4 : nullptr;
+  const int sdst = row * PG_ROWL + kq * 4;
+  const int KC4 = (p.K + 127) / 128;
+  f32x4 preA[NI], pgA[NI], preB[NI], pgB[NI];
+  auto request = [&](int c, f32x4 (&pre)[NI], f32x4 (&pg)[NI]) {
 #pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    if (b == 1 && !on1) break;
-    const int nb = (nt0 + b) * 32 + 4 * (lane >> 5);
-#pragma unroll
-    for (int a = 0; a < MW; ++a) {
-      const int m = m0 + a * 32 + (lane & 31);
-      if (m >= p.M) continue;
-      float* yr = p.y + (long)m * p.ldy;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = nb + 8 * g;
-        if (n >= p.N) continue;                       // N % 4 == 0: a quad is inside or outside as a whole
-        f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
-        if (p.bias) v += *(const f32x4*)(p.bias + n);
-        if (p.act == 2) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = ac_swish_fast(v[q]);
-        } else if (p.act == 1) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
-        }
-        if (p.drop.thresh != 0) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] *= p.drop.mask((uint64_t)(p.row0 + m) * (uint64_t)p.N + (uint64_t)(n + q));
-        }
-        if (p.beta != 0.f) v += p.beta * *(const f32x4*)(yr + n);
-        *(f32x4*)(yr + n) = v;
+    for (int j = 0; j < NI; ++j) {
+      const int k = c * 128 + j * 32 + kq * 4;
+      pre[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      pg[j] = f32x4{1.f, 1.f, 1.f, 1.f};
+      if (c < KC4 && k < p.K && rok) {
+        pre[j] = *(const f32x4*)(xrow + c * 128 + j * 32);
+        if (p.gate) pg[j] = *(const f32x4*)(grow + c * 128 + j * 32);
       }
     }
+  };
+  auto commit = [&](int buf, const f32x4 (&pre)[NI], const f32x4 (&pg)[NI]) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      pg_u32x2 hi, lo;
+      pg_split4(pre[j] * pg[j], hi, lo);
+      *(pg_u32x2*)(sA[buf][0] + sdst + j * 32) = hi;
+      *(pg_u32x2*)(sA[buf][1] + sdst + j * 32) = lo;
+    }
+  };
+  const pg_bf16x8* wbase = p.wf + (size_t)min(nt0, p.NT32 - 1) * 2 * 64 + lane;
+  const size_t w_kstep = (size_t)p.NT32 * 2 * 64;
+  const int w_t1 = on1 ? 2 * 64 : 0;
+  const int nks = p.KC * 2;                        // k-steps the packed weights hold (K rounded up to 32)
+  auto w_load = [&](int kk, pg_bf16x8 (&w)[2][2]) {
+    const pg_bf16x8* q = wbase + (size_t)min(kk, nks - 1) * w_kstep;
+    w[0][0] = q[0];
+    w[0][1] = q[64];
+    w[1][0] = q[w_t1];
+    w[1][1] = q[w_t1 + 64];
+  };
+  f32x16 acc[1][2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][b][r] = 0.f;
+  const int frag = (lane & 31) * PG_ROWL + 8 * (lane >> 5);
+  pg_bf16x8 w0[2][2], w1[2][2], w2[2][2], w3[2][2];
+  auto kstep = [&](int buf, int ks, int kk, const pg_bf16x8 (&wc)[2][2]) {
+    if (kk >= nks) return;                          // beyond the packed k-steps (K % 128 != 0): zeros anyway
+    const pg_bf16x8 ah = *(const pg_bf16x8*)(sA[buf][0] + frag + ks * 16);
+    const pg_bf16x8 al = *(const pg_bf16x8*)(sA[buf][1] + frag + ks * 16);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[b][0], al, acc[0][b], 0, 0, 0);
+      acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[b][1], ah, acc[0][b], 0, 0, 0);
+      acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[b][0], ah, acc[0][b], 0, 0, 0);
+    }
+  };
+  // one 128-k chunk from LDS buffer `buf`: eight k-steps, the weight ring three k-steps ahead.  (A ring of eight - every
+  // fragment requested a whole chunk ahead - and LDS fragment reads one k-step ahead were measured: no gain, then 256 VGPRs
+  // and spills.)
+  auto chunk = [&](int buf, int c) {
+    if (!on0) return;
+    const int k0 = 8 * c;
+    w_load(k0 + 3, w3); kstep(buf, 0, k0 + 0, w0);
+    w_load(k0 + 4, w0); kstep(buf, 1, k0 + 1, w1);
+    w_load(k0 + 5, w1); kstep(buf, 2, k0 + 2, w2);
+    w_load(k0 + 6, w2); kstep(buf, 3, k0 + 3, w3);
+    w_load(k0 + 7, w3); kstep(buf, 4, k0 + 4, w0);
+    w_load(k0 + 8, w0); kstep(buf, 5, k0 + 5, w1);
+    w_load(k0 + 9, w1); kstep(buf, 6, k0 + 6, w2);
+    w_load(k0 + 10, w2); kstep(buf, 7, k0 + 7, w3);
+  };
+  request(0, preA, pgA);
+  request(1, preB, pgB);
+  if (on0) {
+    w_load(0, w0);
+    w_load(1, w1);
+    w_load(2, w2);
   }
+  commit(0, preA, pgA);
+  __syncthreads();
+  for (int c = 0; c < KC4; c += 2) {
+    request(c + 2, preA, pgA);
+    chunk(0, c);
+    if (c + 1 >= KC4) break;
+    commit(1, preB, pgB);
+    __syncthreads();
+    request(c + 3, preB, pgB);
+    chunk(1, c + 1);
+    if (c + 2 < KC4) {
+      commit(0, preA, pgA);
+      __syncthreads();
+    }
+  }
+  pw_epilogue<1>(p, acc, m0, nt0, on0, on1, lane);
 }
 
 // ---- weight packing: W(n, k) = w[n * s_n + k * s_k] f32 -> fragment order, split into bf16 hi / lo (RNE); K, N padded
@@ -310,7 +428,14 @@ int ac_pw_gemm_bf16x3_ex(const float* x, long ldx, const void* wfrag, const floa
     }
     if (forced == 1 || forced == 2) mw = forced;
   }
-  if (mw == 2) hipLaunchKernelGGL(pw_bf16x3_kernel<2>, dim3((unsigned)((M + 63) / 64), gy), dim3(256), 0, st, p);
+  static int longk = -1;   // AUDIOCAPTION_PW_LONGK=0 / 1 forces the 128-k variant off / on (where K >= 256)
+  if (longk < 0) {
+    const char* e = getenv("AUDIOCAPTION_PW_LONGK");
+    longk = e ? 2 + atoi(e) : 0;
+  }
+  const bool use_long = longk == 3 ? K >= 256 : (longk == 2 ? false : (K >= 512 && (M + 31) / 32 * gy <= 320));
+  if (use_long) hipLaunchKernelGGL(pw_bf16x3_longk_kernel, dim3((unsigned)((M + 31) / 32), gy), dim3(256), 0, st, p);
+  else if (mw == 2) hipLaunchKernelGGL(pw_bf16x3_kernel<2>, dim3((unsigned)((M + 63) / 64), gy), dim3(256), 0, st, p);
   else hipLaunchKernelGGL(pw_bf16x3_kernel<1>, dim3((unsigned)((M + 31) / 32), gy), dim3(256), 0, st, p);
   return ac_check_launch();
 }

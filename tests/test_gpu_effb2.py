@@ -230,11 +230,12 @@ def test_se_gate_and_gated_projection(lib):
 
 
 @pytest.mark.parametrize("M,N,K", [(8192, 1248, 208), (8200, 208, 1248), (4097, 352, 2112), (1344, 768, 256), (300, 88, 528),
-                                   (32256, 120, 720), (70, 1408, 352)])
+                                   (32256, 120, 720), (70, 1408, 352), (1344, 256, 1024), (2000, 120, 720)])
 def test_pw_gemm_bf16x3_vs_float64(lib, M, N, K):
     """ac_pw_gemm_bf16x3 (activation-stationary split-bf16 1x1 convolution over weights pre-split in MFMA fragment order,
     csrc/pw_gemm.hip) against float64 on EfficientNet-B2's matrix-bound shapes: the three tile heights, K and N that are
-    not multiples of 32 (zero-padded fragments), column groups with one and two tiles per wave, row tails; plain, swish,
+    not multiples of 32 (zero-padded fragments), column groups with one and two tiles per wave, row tails, the 128-k
+    variant for long K with few workgroups (K = 528 and 720: partial last chunk); plain, swish,
     and the squeeze-excite form y = res + (x .* gate[clip]) w^T + b.  2^-16 relative operand error: 3e-5 of the
     largest output (the bar of ac_gemm_bf16x3)."""
     g = torch.Generator().manual_seed(M + N)

@@ -17,7 +17,8 @@ shapes = [("s4 expand", 32256, 528, 88, 2), ("s4 project", 32256, 88, 528, 0), (
           ("tf ffn2", 1344, 256, 1024, 0), ("tf cls", 1344, 4368, 256, 0),
           ("tr qkv", 7392, 768, 256, 1), ("tr out", 7392, 256, 256, 1), ("tr ffn1", 7392, 1024, 256, 1),
           ("tr ffn2", 7392, 256, 1024, 1), ("tr kv", 992, 512, 256, 1), ("tr gru0", 992, 1536, 2048, 1),
-          ("tr gru1", 992, 1536, 512, 1), ("tr cls", 672, 4984, 256, 1)]
+          ("tr gru1", 992, 1536, 512, 1), ("tr cls", 672, 4984, 256, 1),
+          ("inf gru0", 1984, 1536, 2048, 1), ("inf gru1", 1984, 1536, 512, 1), ("inf mem", 1984, 256, 2048, 1)]
 
 
 def timeit(fn, reps=20):
