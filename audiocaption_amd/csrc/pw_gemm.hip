@@ -433,7 +433,7 @@ int ac_pw_gemm_bf16x3_ex(const float* x, long ldx, const void* wfrag, const floa
     const char* e = getenv("AUDIOCAPTION_PW_LONGK");
     longk = e ? 2 + atoi(e) : 0;
   }
-  const bool use_long = longk == 3 ? K >= 256 : (longk == 2 ? false : (K >= 512 && (M + 31) / 32 * gy <= 320));
+  const bool use_long = longk == 3 ? K >= 256 : (longk == 2 ? false : ((K >= 512 && (M + 31) / 32 * gy <= 320) || (K >= 256 && (M + 31) / 32 * gy <= 200)));
   if (use_long) hipLaunchKernelGGL(pw_bf16x3_longk_kernel, dim3((unsigned)((M + 31) / 32), gy), dim3(256), 0, st, p);
   else if (mw == 2) hipLaunchKernelGGL(pw_bf16x3_kernel<2>, dim3((unsigned)((M + 63) / 64), gy), dim3(256), 0, st, p);
   else hipLaunchKernelGGL(pw_bf16x3_kernel<1>, dim3((unsigned)((M + 31) / 32), gy), dim3(256), 0, st, p);
