@@ -209,21 +209,27 @@ __global__ __launch_bounds__(256) void se_gate_t_kernel(const float* pool, float
     ((f32x4*)mean)[c4] = ((const f32x4*)(pool + (long)b * C))[c4] * inv_count;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int s = wave; s < S; s += 8) {
-    const int s2 = min(s + 4, S - 1);
-    const f32x4* r0 = (const f32x4*)(w1 + (long)s * C);
-    const f32x4* r1 = (const f32x4*)(w1 + (long)s2 * C);
-    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+  // four squeezed units per wave and pass (s = wave + 4 j): their weight rows are all requested before the first FMA
+  for (int s0 = wave; s0 < S; s0 += 16) {
+    const f32x4* r[4];
+    f32x4 a[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      r[j] = (const f32x4*)(w1 + (long)min(s0 + 4 * j, S - 1) * C);
+      a[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     for (int c4 = lane; c4 < C4; c4 += 64) {
       const f32x4 m = ((const f32x4*)mean)[c4];
-      a0 += r0[c4] * m;
-      a1 += r1[c4] * m;
+      f32x4 wv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wv[j] = r[j][c4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] += wv[j] * m;
     }
-    const float t0 = wave_sum((a0[0] + a0[1]) + (a0[2] + a0[3]));
-    const float t1 = wave_sum((a1[0] + a1[1]) + (a1[2] + a1[3]));
-    if (lane == 0) {
-      sq[s] = swishf(t0 + b1[s]);
-      if (s + 4 < S) sq[s + 4] = swishf(t1 + b1[s + 4]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float t = wave_sum((a[j][0] + a[j][1]) + (a[j][2] + a[j][3]));
+      if (lane == 0 && s0 + 4 * j < S) sq[s0 + 4 * j] = swishf(t + b1[s0 + 4 * j]);
     }
   }
   __syncthreads();
@@ -231,12 +237,12 @@ __global__ __launch_bounds__(256) void se_gate_t_kernel(const float* pool, float
     f32x4 a = ((const f32x4*)b2)[c4];
     const f32x4* col = (const f32x4*)w2t + c4;
     int s = 0;
-    for (; s + 4 <= S; s += 4) {
-      const f32x4 v0 = col[(long)s * C4], v1 = col[(long)(s + 1) * C4], v2 = col[(long)(s + 2) * C4], v3 = col[(long)(s + 3) * C4];
-      a += v0 * sq[s];
-      a += v1 * sq[s + 1];
-      a += v2 * sq[s + 2];
-      a += v3 * sq[s + 3];
+    for (; s + 8 <= S; s += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = col[(long)(s + j) * C4];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a += v[j] * sq[s + j];
     }
     for (; s < S; ++s) a += col[(long)s * C4] * sq[s];
 #pragma unroll

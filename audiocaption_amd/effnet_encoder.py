@@ -257,7 +257,11 @@ class EfficientNetB2(nn.Module):
         T, F = To, Fo
         mid_buf, dw_buf = self._buf("act_b", big, dev), self._buf("act_c", big, dev)
         nxt = self._buf("act_d", big, dev)
-        pool = self._buf("se_pool", B * 2112, dev)
+        # squeeze sums of all 23 blocks in one buffer, cleared by ONE fill per forward (the depthwise kernels accumulate
+        # into their block's slice with atomics)
+        pool_all = self._buf("se_pool", B * sum(blk.mid for blk in net._blocks), dev)
+        pool_all.zero_()
+        pool_off = 0
         gate = self._buf("se_gate", B * 2112, dev)
         sq_buf = self._buf("se_squeezed", B * 128, dev)
         for blk, d in zip(net._blocks, pk["blocks"]):
@@ -266,7 +270,8 @@ class EfficientNetB2(nn.Module):
             wd, sc, sh = d["dw"]
             pb, pa = blk.pad
             To, Fo = (T + pb + pa - blk.k) // blk.stride + 1, (F + pb + pa - blk.k) // blk.stride + 1
-            pool[:B * blk.mid].zero_()
+            pool = pool_all[pool_off:pool_off + B * blk.mid]
+            pool_off += B * blk.mid
             fused = False
             if blk.expand != 1 and FUSE_EXPAND_DW and rows >= FUSE_MIN_ROWS:
                 # expand -> depthwise -> squeeze sums in one kernel: the expanded tensor (6x the block input) stays in LDS
