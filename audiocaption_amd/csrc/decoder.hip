@@ -1070,7 +1070,8 @@ int decoder_step(const ac_trm_weights* w, const float* memkv, const int* mem_len
   const float *jx = nullptr, *jy = nullptr, *jw = nullptr, *jb = nullptr;
   // the reference's decoder shape (d_model 256 = 4 heads of 64) takes the fused per-row sub-layer kernel: 5 launches per
   // layer instead of 8; any other shape the general 8-launch sequence
-  const bool fused = d == ROW_D && w->nhead == ROW_H && t + 1 <= MAX_KEYS && Tm <= MAX_KEYS;
+  static const bool no_rows = getenv("AUDIOCAPTION_DEC_ROW") && !strcmp(getenv("AUDIOCAPTION_DEC_ROW"), "gemm");
+  const bool fused = d == ROW_D && w->nhead == ROW_H && t + 1 <= MAX_KEYS && Tm <= MAX_KEYS && !no_rows;
   for (int l = 0; l < w->nlayers; ++l) {
     const ac_trm_layer& L = w->layer[l];
     // ---- self attention: QKV projection with the layer input produced in its prologue ----

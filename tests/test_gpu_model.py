@@ -332,13 +332,15 @@ def test_forward_async_pair_decode_mixed_shapes(hip_model):
     assert torch.equal(again["seq"], want[0]["seq"])
 
 
-@pytest.mark.parametrize("group", ["1", "2"])
-def test_forward_async_beam_equals_blocking(hip_model, monkeypatch, group):
+@pytest.mark.parametrize("group,conc", [("1", "2"), ("2", "1"), ("1", "1")])
+def test_forward_async_beam_equals_blocking(hip_model, monkeypatch, group, conc):
     """Beam search through forward_async (encoders submitted up front, the host-driven searches run at result() on the
-    decode stream) returns what the blocking call returns - also when consecutive submissions share one search
-    (AUDIOCAPTION_BEAM_GROUP=2: results asked for out of order, a group of two and a single)."""
+    decode stream) returns what the blocking call returns - when two consecutive submissions are searched side by side on
+    two decode streams (AUDIOCAPTION_BEAM_CONCURRENT=2, the default), when they share one search (AUDIOCAPTION_BEAM_GROUP=2)
+    and one by one; results asked for out of order, a group of two and a single."""
     from audiocaption_amd import procedural as P
     monkeypatch.setenv("AUDIOCAPTION_BEAM_GROUP", group)
+    monkeypatch.setenv("AUDIOCAPTION_BEAM_CONCURRENT", conc)
     inputs = []
     for s_, lens in ((11, [48000, 40000, 33000]), (12, [48000, 48000, 21000]), (13, [30000, 48000, 47000])):
         w = torch.from_numpy(P.synthetic_wav(3, 48000, seed=s_, varied=True)).cuda()
