@@ -73,10 +73,12 @@ def test_stem_kernel(lib):
     assert rel("stem", y, ref) < 1e-5
 
 
-@pytest.mark.parametrize("k,stride,pad", [(3, 1, (1, 1)), (3, 2, (0, 1)), (5, 2, (2, 2)), (5, 1, (2, 2)), (3, 2, (1, 1))])
-def test_depthwise_kernel_and_squeeze_sums(lib, k, stride, pad):
+@pytest.mark.parametrize("k,stride,pad,C", [(3, 1, (1, 1), 48), (3, 2, (0, 1), 48), (5, 2, (2, 2), 48), (5, 1, (2, 2), 48),
+                                            (3, 2, (1, 1), 48), (5, 1, (2, 2), 1248), (3, 1, (1, 1), 2112)])
+def test_depthwise_kernel_and_squeeze_sums(lib, k, stride, pad, C):
+    """C = 1248 / 2112: more than 256 channel quads per position (a thread then walks several channel groups)."""
     g = torch.Generator().manual_seed(k * 10 + stride)
-    B, T, Fm, C = 3, 21, 10, 48
+    B, T, Fm = 3, 21, 10
     x = torch.randn(B, T, Fm, C, generator=g)
     w = torch.randn(C, 1, k, k, generator=g) * 0.3          # [C][1][k mel][k time]
     sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
