@@ -205,10 +205,11 @@ class EfficientNetB2(nn.Module):
     @staticmethod
     def _gemm(x, w, bias, y, M, N, Kd, act=0, beta=0.0, a_scale=None, a_rows=0, wfrag=None):
         lib = _lib.load()
-        # two kernels for the same contract (tools/pointwise_bench.py): the full-resolution stages (>= 0.4 M rows against
-        # a few KB of weights) are HBM-bound -> the streaming kernel that reads each activation once; everything later
+        # two kernels for the same contract (tools/pointwise_bench.py, tools/pointwise_vs_pw.py): the full-resolution stages
+        # (>= 0.4 M rows against a few KB of weights) are HBM-bound -> the streaming kernel that reads each activation once
+        # (at 129 k rows the split-bf16 kernel is already ahead: 48 -> 288 expand 79 -> 64 us); everything later
         # -> the LDS-tiled x W^T GEMM, which shares each weight tile between 64 or 128 rows
-        if M >= 400000 or (M >= 100000 and Kd <= 64):
+        if M >= 400000 or (M >= 100000 and Kd <= 32) or wfrag is None and M >= 100000 and Kd <= 64:
             check(lib.ac_pointwise_conv(ptr(x), ptr(w), ptr(bias), ptr(y), M, N, Kd, act, beta, ptr(a_scale), a_rows,
                                         stream()), "ac_pointwise_conv")
         elif wfrag is not None and GEMM_ALGO == "pw":

@@ -13,7 +13,8 @@ S = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 shapes = [("s4 expand", 32256, 528, 88, 2), ("s4 project", 32256, 88, 528, 0), ("s5 expand", 32256, 720, 120, 2),
           ("s5 project", 32256, 120, 720, 0), ("s6 expand", 8192, 1248, 208, 2), ("s6 project", 8192, 208, 1248, 0),
           ("s7 expand", 8192, 2112, 352, 2), ("s7 project", 8192, 352, 2112, 0), ("head", 8192, 1408, 352, 2),
-          ("s3 project", 129024, 48, 288, 0), ("tf qkv", 1344, 768, 256, 0), ("tf ffn1", 1344, 1024, 256, 1),
+          ("s3 project", 129024, 48, 288, 0), ("s3 expand", 129024, 288, 48, 2), ("s2 project", 514048, 24, 144, 0),
+          ("s2 expand", 514048, 144, 24, 2), ("tf qkv", 1344, 768, 256, 0), ("tf ffn1", 1344, 1024, 256, 1),
           ("tf ffn2", 1344, 256, 1024, 0), ("tf cls", 1344, 4368, 256, 0),
           ("tr qkv", 7392, 768, 256, 1), ("tr out", 7392, 256, 256, 1), ("tr ffn1", 7392, 1024, 256, 1),
           ("tr ffn2", 7392, 256, 1024, 1), ("tr kv", 992, 512, 256, 1), ("tr gru0", 992, 1536, 2048, 1),
