@@ -6,7 +6,7 @@
 //
 // Arithmetic replaced: MBConvBlock.forward of efficientnet_pytorch==0.7.1 up to the squeeze (un-vendored; the
 // reference's call sites are hf_wrapper.py:229-241 / cnn_encoder.py:798-805, its restatement of the construction
-// eff_latent_encoder.py:74-186).  PARITY UNPINNED like the rest of the encoder: checked against oracle/effb2_path.py.
+// eff_latent_encoder.py:74-186).  Checked against oracle/effb2_path.py and the independent-witness fixture tests/golden/g11_effb2.npz.
 //
 // Work decomposition.  A workgroup owns one clip, a band of R output time rows over ALL mel columns, and a group of
 // 32-channel chunks of the expanded tensor (the expand and the depthwise convolution are independent per expanded

@@ -7,9 +7,9 @@ keywords, ``forward(input_dict) -> {"fc_emb", "attn_emb", "attn_emb_len"}``, ``f
 The nn modules below only OWN the parameters.  The forward pass is csrc/logmel.hip (HTK mel, top_db clamp),
 csrc/effnet.hip (stem, depthwise + squeeze sums, squeeze-excite gate, ``ac_pointwise_conv`` for the 1x1 convolutions
 (BatchNorm folded into the weight rows; swish, the squeeze-excite gate and the residual in the GEMM's prologue /
-epilogue), channels-last ``[clip][time][mel][C]``.  PARITY UNPINNED: the backbone's arithmetic lives in the un-vendored
-``efficientnet_pytorch==0.7.1``; ``oracle/effb2_path.py`` restates its published algorithm and is what the tests
-compare against.
+epilogue), channels-last ``[clip][time][mel][C]``.  The backbone's arithmetic lives in the un-vendored
+``efficientnet_pytorch==0.7.1``; ``oracle/effb2_path.py`` restates its published algorithm, and both are held to
+``transformers.EfficientNetModel`` / ``transformers.audio_utils`` outputs (tests/golden/g10_logmel.npz, g11_effb2.npz).
 """
 import math
 import os

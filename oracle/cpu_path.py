@@ -11,11 +11,15 @@ Pinning status:
   the reference from /root/reference in the build container, loads the same procedural weights
   and checks every function below against the reference modules; the fixtures it wrote are in
   ``tests/golden/*.npz`` and are re-checked by ``tests/test_oracle_golden.py``.
-* ``logmel`` is **parity unpinned**: its arithmetic lives in torchaudio==0.13.1
-  (requirements.txt:5), which is not vendored in the reference and not installed here.  It
-  follows torchaudio's published MelSpectrogram/AmplitudeToDB semantics (call sites
-  cnn_encoder.py:338-350,418-419) and is cross-checked against an independent float64 numpy
-  DFT and closed-form known answers in ``tests/test_logmel_oracle.py``.
+* ``logmel``: its arithmetic lives in torchaudio==0.13.1 (requirements.txt:5), which is not
+  vendored in the reference and not installed here, so the imported reference cannot pin it.
+  It follows torchaudio's published MelSpectrogram/AmplitudeToDB semantics (call sites
+  cnn_encoder.py:338-350,418-419) and is PINNED BY AN INDEPENDENT WITNESS instead:
+  ``tests/golden/make_witness.py`` runs ``transformers.audio_utils`` (mel_filter_bank +
+  spectrogram, float64) on seeded inputs, writes ``tests/golden/g10_logmel.npz`` and asserts
+  agreement (filterbank 2e-8, log-mel 3.4e-4 dB max / 2e-5 dB 99th percentile);
+  ``tests/test_witness.py`` re-checks this file against that fixture on any machine, next to
+  the float64 numpy DFT and closed-form answers of ``tests/test_logmel_oracle.py``.
 
 All functions take a flat ``state`` dict of torch tensors keyed as the reference's
 ``state_dict()``.
@@ -29,7 +33,7 @@ PAD_IDX, START_IDX, END_IDX = 0, 1, 2  # reference base.py:12-15
 
 
 # ----------------------------------------------------------------------------------------
-# log-mel front-end (torchaudio semantics restated; parity unpinned, see header)
+# log-mel front-end (torchaudio semantics restated; pinned by the transformers.audio_utils witness, see header)
 # ----------------------------------------------------------------------------------------
 def _hz_to_mel_slaney(f):
     f_sp = 200.0 / 3

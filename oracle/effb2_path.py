@@ -3,7 +3,13 @@ A8 / A17: ``EfficientNetB2.forward`` hf_wrapper.py:287-315 == cnn_encoder.py:811
 hf_wrapper.py:229-232, ``get_effb2_model`` :235-241).  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
 ``cpu_baseline`` leg may import it.
 
-**PARITY UNPINNED.**  The backbone's arithmetic lives in the un-vendored third-party package
+**Pinned by independent witnesses, not by the reference** (``tests/golden/make_witness.py`` ->
+``tests/golden/g10_logmel.npz`` / ``g11_effb2.npz``, re-checked by ``tests/test_witness.py``): ``extract_features`` agrees
+with ``transformers.EfficientNetModel`` (B2 coefficients, ``depthwise_padding=[5, 8, 16]``, one input channel) carrying the
+same procedural weights mapped key by key (506 tensors) to 5e-7 of the output's maximum on 64 x 1001, 64 x 3001 and
+260 x 260 inputs; ``logmel_effb2`` agrees with ``transformers.audio_utils`` (htk scale, 0-8000 Hz, n_fft 512, hop 160,
+clamp at batch maximum - 120 dB) to 1.5e-3 dB (6e-5 dB 99th percentile).  Why a witness is needed:
+the backbone's arithmetic lives in the un-vendored third-party package
 ``efficientnet_pytorch==0.7.1`` (requirements.txt:8: ``EfficientNet.extract_features``, ``MBConvBlock.forward``,
 ``Conv2dStaticSamePadding``, ``utils.get_model_params / round_filters / round_repeats``) and the mel front-end in
 ``torchaudio==0.13.1`` (``MelSpectrogram`` defaults: HTK mel scale, no filter normalisation; ``AmplitudeToDB(top_db=120)``);

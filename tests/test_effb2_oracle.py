@@ -1,4 +1,5 @@
-"""CPU tests of the EffB2 oracle (PARITY UNPINNED: efficientnet_pytorch / torchaudio are not vendored): the structure
+"""CPU tests of the EffB2 oracle (efficientnet_pytorch / torchaudio are not vendored; numeric pinning by independent
+witnesses is in tests/test_witness.py): the structure
 facts the reference itself pins (eff_latent_encoder.py:74-186,263-290) and closed-form
 properties of the restated algorithms."""
 import math

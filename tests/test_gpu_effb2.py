@@ -1,6 +1,7 @@
 """GPU tests of the EfficientNet-B2 encoder path through the C ABI against
-oracle/effb2_path.py.  PARITY UNPINNED: the oracle restates the published efficientnet_pytorch / torchaudio algorithms
-(not vendored by the reference); what IS checked here is that the HIP path computes exactly that restatement."""
+oracle/effb2_path.py and against the independent-witness fixtures tests/golden/g10_logmel.npz / g11_effb2.npz
+(transformers.audio_utils / transformers.EfficientNetModel, tests/golden/make_witness.py): the oracle restates the
+published efficientnet_pytorch / torchaudio algorithms, which the reference does not vendor."""
 import ctypes
 import os
 import subprocess
@@ -286,6 +287,40 @@ def test_backbone_from_logmel_vs_oracle(effb2_model, state_effb2):
     got = effb2_model.encoder.features(x, 2, lms.shape[2])
     assert got.shape == want.shape
     assert rel("EffB2 attn_emb", got, want) < 2e-4
+
+
+def test_logmel_htk_top_db_vs_independent_witness(effb2_model, golden_dir):
+    """Rows A1 / A2 (EffB2 front-end, hf_wrapper.py:270-279,292-293) against ``g10_logmel.npz``: the float64
+    ``transformers.audio_utils`` log-mel (htk scale, no norm, 0-8000 Hz, n_fft 512, hop 160) clamped at the maximum of the
+    WHOLE batch - 120 dB; clip 2 is nearly silent and sits on that floor."""
+    import numpy as np
+    sys.path.insert(0, golden_dir)
+    import make_witness as W
+    g = np.load(os.path.join(golden_dir, "g10_logmel.npz"))
+    _, wav16 = W.logmel_inputs()
+    got = effb2_model.encoder.logmel(torch.from_numpy(wav16).cuda()).view(3, -1, 64).transpose(1, 2).cpu().double().numpy()
+    want = g["effb2_db"].astype(np.float64)
+    d = np.abs(got - want)
+    print(f"[log-mel (HTK, top_db 120) vs witness] max|diff| {d.max():.3e} dB, p99 {np.percentile(d, 99):.3e} dB")
+    assert d.max() < 8e-3 and np.percentile(d, 99) < 3e-4
+    assert float(got.min()) == pytest.approx(float(want.max()) - 120.0, abs=1e-3)
+
+
+@pytest.mark.parametrize("name", ["lms10", "lms30", "sq260"])
+def test_backbone_vs_independent_witness(effb2_model, golden_dir, name):
+    """Row A8 against ``g11_effb2.npz``: ``transformers.EfficientNetModel`` (B2: width 1.1, depth 1.2, the 260-px static
+    padding chain, one input channel) carrying the SAME procedural weights mapped by name, mean over mel
+    (hf_wrapper.py:229-232) - for a 10 s and a 30 s log-mel and a square 260 x 260 input."""
+    import numpy as np
+    sys.path.insert(0, golden_dir)
+    import make_witness as W
+    want = torch.from_numpy(np.load(os.path.join(golden_dir, "g11_effb2.npz"))[name])
+    lms = torch.from_numpy(W.effb2_inputs()[name])            # (B, F, T)
+    B, Fm, T = lms.shape
+    x = lms.transpose(1, 2).contiguous().cuda()               # [B][T][F]
+    got = effb2_model.encoder.features(x, B, T, Fm)
+    assert got.shape == want.shape
+    assert rel(f"EffB2 attn_emb vs transformers.EfficientNetModel ({name})", got, want) < 2e-4
 
 
 @pytest.mark.parametrize("seconds", [10, 4])

@@ -136,6 +136,28 @@ def test_logmel_matches_oracle(K, L, B):
     assert float(rows[:, T:].abs().max()) == 0.0
 
 
+def test_logmel_vs_independent_witness(K, golden_dir):
+    """Row A1 / A2 against vectors this repository did not compute: ``tests/golden/g10_logmel.npz`` holds the float64
+    ``transformers.audio_utils`` log-mel (slaney scale + slaney norm, 50-14000 Hz, n_fft 1024, hop 320, 10 log10, no
+    top_db: torchaudio's MelSpectrogram + AmplitudeToDB as called at cnn_encoder.py:338-350,418-419) of seeded inputs
+    (tests/golden/make_witness.py).  Bars in dB: 3e-3 on the maximum (an f32 transform against an f64 one; the largest
+    differences sit ~60 dB below the clip's peak), 3e-4 on the 99th percentile."""
+    import os
+    import sys
+    import numpy as np
+    from audiocaption_amd.mel import MelTables
+    sys.path.insert(0, golden_dir)
+    import make_witness as W
+    g = np.load(os.path.join(golden_dir, "g10_logmel.npz"))
+    wav32, _ = W.logmel_inputs()
+    tables = MelTables(32000, 1024, 320, 50.0, 14000.0, 64, "slaney", "slaney", "cuda:0")
+    assert float((tables.melfb.cpu() - torch.from_numpy(g["fb_slaney"])).abs().max()) < 1e-6
+    got = K.logmel(torch.from_numpy(wav32).cuda(), tables, channels_last=False).cpu().double().numpy()
+    d = np.abs(got - g["cnn14_db"].astype(np.float64))
+    print(f"[log-mel vs transformers.audio_utils witness] max|diff| {d.max():.3e} dB, p99 {np.percentile(d, 99):.3e} dB")
+    assert d.max() < 3e-3 and np.percentile(d, 99) < 3e-4
+
+
 def test_logmel_known_answers(K):
     """zeros -> -100 dB everywhere (clamp at 1e-10); a bin-centred sinusoid peaks in the right mel band."""
     from audiocaption_amd.mel import MelTables

@@ -1,4 +1,4 @@
-"""CPU: the (parity-unpinned) log-mel oracle cross-checked independently - float64 numpy DFT of the
+"""CPU: the log-mel oracle cross-checked independently (see also tests/test_witness.py) - float64 numpy DFT of the
 reflect-padded, Hann-windowed frames, closed-form answers, and agreement of the product-side filterbank
 (audiocaption_amd/mel.py) with the oracle's."""
 import math
