@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libaudiocaption_hip.so")
 STAMP = LIB + ".stamp"
-SOURCES = ["logmel.hip", "conv3x3.hip", "conv3x3_winograd.hip", "gemm.hip", "gru.hip", "decoder.hip", "train.hip", "effnet.hip", "effnet_fused.hip", "pw_gemm.hip", "ingest.hip"]
+SOURCES = ["logmel.hip", "conv3x3.hip", "conv3x3_winograd.hip", "conv3x3_wino1d.hip", "gemm.hip", "gru.hip", "decoder.hip", "train.hip", "effnet.hip", "effnet_fused.hip", "pw_gemm.hip", "ingest.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
          "-Wno-unused-function", "-Wno-unused-result"]
 

@@ -1,0 +1,353 @@
+// Cnn14 conv stack, f32-grade tier with FEWER matrix instructions: 3x3 convolution + eval BatchNorm + ReLU (+ 2x2
+// average pooling / mean over the 2 mel columns) as a 1-D Winograd F(2,3) along the TIME axis on split-bf16 operands.
+//
+// Same contract, layouts and epilogue modes as csrc/conv3x3.hip (reference ConvBlock.forward, cnn_encoder.py:59-75;
+// pooling / mean glue of Cnn14Encoder.forward, cnn_encoder.py:431-444).  f32 activations [B*Hp][W][C] in and out.
+//
+// Arithmetic.  For an output row pair (2j, 2j+1) of one mel column w the four input rows d0..d3 = rows 2j-1 .. 2j+2 give
+//     V0 = d0 - d2    V1 = d1 + d2    V2 = d2 - d1    V3 = d1 - d3                       (input transform, +-1 only, f32)
+//     U0 = g0         U1 = (g0 + g1 + g2) / 2         U2 = (g0 - g1 + g2) / 2    U3 = g2  (rows ky of the filter, f64 offline)
+//     M_p[pair, w, cout] = sum_kx sum_cin V_p[pair, w + kx - 1, cin] U_p,kx[cout, cin]    (4 positions x 3 mel taps)
+//     y(2j) = M0 + M1 + M2        y(2j+1) = M1 - M2 - M3                                  (output transform, epilogue)
+// i.e. 12 products per (cin, cout) and row pair instead of 18: 1.5x fewer multiplications than the direct form.  Every
+// product runs on split-bf16 operands like the "bf16x3" tier (x = hi + lo, hi*hi + hi*lo + lo*hi on
+// v_mfma_f32_32x32x16_bf16, f32 accumulation: 2^-16 relative operand error), so a f32 product costs 3 / 1.5 = TWO bf16
+// MFMA products - what the fp16-activation tier pays - while the activations stay f32 in HBM and the result stays
+// f32-grade (greedy logits within 3e-5 of the fp32 CPU reference: tests/wino_split_emulation.py, tests/test_gpu_model.py).
+// The 2-D form F(2x2,3x3) (1.33 products) was priced and dropped: its 16 accumulator sets per output tile cap a CU at
+// 64 x 64 (tile, channel) outputs in flight, and at that size the transformed operands (4 KB of fresh fragments per
+// three MFMAs) exceed what LDS and the L1 can deliver to the matrix cores.
+//
+// Work decomposition.  A 512-thread workgroup (two waves per SIMD) owns 128 row pairs (256 output pixels: 32 pairs x 4
+// columns, or 64 pairs x 2 columns for the 2-column layers) x 128 output channels.  Wave (g, n) owns two MFMA tiles (32
+// consecutive pairs of one column each) x 32 channels x 4 positions = 128 accumulator registers.  The K loop runs in
+// 16-channel steps over a DOUBLE-BUFFERED set of V planes in LDS: while the matrix cores consume step s, the raw rows of
+// step s + 1 (requested into registers at the start of step s) are transformed, split and stored into the other
+// buffer, piecewise between the MFMA groups; one workgroup barrier per step.  The 12 (kx, p) weight fragments of a step
+// come straight from L2 in MFMA fragment order (pre-transformed, pre-split), requested two groups ahead.  Column tiles
+// know which mel taps fall on the zero padding beside the image and skip them (a third of the work at W = 2).
+#include "ac_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int KS = 16;          // input channels per K step (one MFMA k-step); the packed weights come in chunks of 32
+constexpr int BROW = KS;        // bf16 elements per (pair, column) item in LDS: 32 bytes = 2 bank slots
+
+struct W1Params {
+  const float* in;
+  const void* wpk;    // [Cin/32][3 kx][4 p][2 k-steps][Cout/32][2 (hi, lo)][64 lanes][8] bf16
+  const float* scale;
+  const float* shift;
+  float* out;
+  int rows_total, Hp, H, W, Cin, Cout;
+  int mt_cols, MT, NT;
+  int Hp_out, H_out, W_out;
+  int map_mode;
+};
+
+enum { MODE_FULL = 0, MODE_POOL = 1, MODE_MEANW = 2 };
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+// x (4 floats) -> packed hi (2 dwords) and lo (2 dwords) bf16 quadruples: hi = RNE(x), lo = RNE(x - hi)
+__device__ __forceinline__ void split_bf16x4(const f32x4 x, u32x2& hi, u32x2& lo) {
+  hi.x = cvt_pk_bf16(x[0], x[1]);
+  hi.y = cvt_pk_bf16(x[2], x[3]);
+  const float h0 = __builtin_bit_cast(float, hi.x << 16), h1 = __builtin_bit_cast(float, hi.x & 0xffff0000u);
+  const float h2 = __builtin_bit_cast(float, hi.y << 16), h3 = __builtin_bit_cast(float, hi.y & 0xffff0000u);
+  lo.x = cvt_pk_bf16(x[0] - h0, x[1] - h1);
+  lo.y = cvt_pk_bf16(x[2] - h2, x[3] - h3);
+}
+
+// x mod d / x div d for 0 <= x < 2^23 with one reciprocal per wave (an integer division by a run-time value is ~25
+// instructions; the epilogue needs the row inside the clip for every stored row)
+struct FastDiv {
+  int d;
+  float inv;
+  __device__ __forceinline__ explicit FastDiv(int d_) : d(d_), inv(1.0f / (float)d_) {}
+  __device__ __forceinline__ int div(int x, int& rem) const {
+    int q = (int)((float)x * inv);
+    int r = x - q * d;
+    if (r < 0) { r += d; --q; }
+    if (r >= d) { r -= d; ++q; }
+    rem = r;
+    return q;
+  }
+  __device__ __forceinline__ int mod(int x) const { int r; div(x, r); return r; }
+};
+
+// block -> (m_tile, n_tile); block b runs on XCD b % 8 (speed only).  map_mode 1: one XCD streams one weight column
+// slab (weight-heavy layers, NT % 8 == 0); 2: blocks sharing a halo patch share an L2; 3: NT in {1, 2, 4}
+__device__ __forceinline__ bool block_map(const W1Params& p, int& m_tile, int& n_tile) {
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, seq = bid >> 3;
+  if (p.map_mode == 1) {
+    n_tile = xcd + 8 * (seq / p.MT);
+    m_tile = seq % p.MT;
+  } else if (p.map_mode == 2) {
+    n_tile = seq % p.NT;
+    m_tile = (seq / p.NT) * 8 + xcd;
+    if (m_tile >= p.MT) return false;
+  } else if (p.map_mode == 3) {
+    const int per = 8 / p.NT;
+    n_tile = xcd % p.NT;
+    m_tile = seq * per + xcd / p.NT;
+    if (m_tile >= p.MT) return false;
+  } else {
+    n_tile = bid % p.NT;
+    m_tile = bid / p.NT;
+  }
+  return true;
+}
+
+// LDS pitch (bf16 elements) of one pair row of `pws` staged columns: an odd number of 16-byte slots, so the 16 lanes of
+// every ds_read_b128 group (consecutive pairs of one column) land in 16 different bank slots
+__host__ __device__ constexpr int w1_pitch(int pws) { return pws * BROW + 8; }
+
+// TC: columns of the block (4, or 2 for the 2-column layers).  FULLW: the block spans the whole image width (W == TC):
+// its two outer halo columns are never read (every tap that would is skipped), so they are not staged.
+template <int MODE, int TC, bool FULLW>
+__global__ __launch_bounds__(512, 2) void conv3x3_w1_kernel(W1Params p) {
+  constexpr int PR = 128 / TC;              // pair rows per block
+  constexpr int MW = 2;                     // MFMA tiles per wave
+  constexpr int COFF = FULLW ? 1 : 0;
+  constexpr int PWS = TC + 2 - 2 * COFF;    // staged columns: image columns col0 - 1 + COFF ..
+  constexpr int PITCH = w1_pitch(PWS);
+  constexpr int PLANE = PR * PITCH;         // one (position, hi | lo) plane
+  constexpr int VBUF = 8 * PLANE;           // [4 p][2 (hi, lo)][PR][PITCH]
+  // staging item = NP vertically adjacent pairs x one staged column x one channel quad: 2 NP + 2 input rows
+  constexpr int NP = FULLW ? 1 : 2;
+  constexpr int NROW = 2 * NP + 2;
+  constexpr int NITEM = (PR / NP) * PWS * (KS / 4);
+  static_assert(NITEM <= 512, "one staging item per thread");
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm_raw[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wn = wave & 3, wg = wave >> 2;
+  const int half = lane >> 5;
+
+  int m_tile, n_tile;
+  if (!block_map(p, m_tile, n_tile)) return;
+  const int pair0 = (m_tile / p.mt_cols) * PR;
+  const int col0 = (m_tile % p.mt_cols) * TC;
+  const bool at_left = col0 == 0, at_right = col0 + TC == p.W;
+  __bf16* sV = (__bf16*)dsm_raw;            // two buffers of VBUF elements
+
+  // this wave's tiles: TC = 4: columns 2 wg, 2 wg + 1 of the 32 pairs; TC = 2: columns 0, 1 of pair group wg
+  const int mrow = TC == 4 ? 0 : wg * 32;
+  const int mcol0 = TC == 4 ? 2 * wg : 0;
+  int pbase[MW];
+#pragma unroll
+  for (int m = 0; m < MW; ++m) pbase[m] = (mrow + (lane & 31)) * PITCH + (mcol0 + m - COFF) * BROW + half * 8;
+
+  f32x16 acc[4][MW];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int m = 0; m < MW; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q][m][r] = 0.f;
+
+  const int row0 = 2 * pair0;
+  const int rc0 = row0 % p.Hp;
+  const bool all_pad = (rc0 >= p.H && rc0 + 2 * PR <= p.Hp) || row0 >= p.rows_total;
+  const int nstep = p.Cin / KS;
+  if (!all_pad) {
+    // weight fragment of (32-channel chunk c, group gi = kx * 4 + p, k-step ks, plane) for this wave's 32 channels
+    const int NT32 = p.Cout >> 5;
+    const bf16x8* wf = (const bf16x8*)p.wpk + (size_t)(n_tile * 4 + wn) * 2 * 64 + lane;
+    const size_t ks_stride = (size_t)NT32 * 2 * 64;
+    auto w_load = [&](int s, int gi, bf16x8 (&w)[2]) {
+      const size_t base = ((size_t)((s >> 1) * 12 + gi) * 2 + (s & 1)) * ks_stride;
+      w[0] = wf[base];
+      w[1] = wf[base + 64];
+    };
+
+    // Staging descriptor of this thread's item, once per workgroup
+    int goff = 0;            // element offset of the item's first input row (2 pair - 1; negative for the very first row)
+    unsigned lofs = 0;       // LDS element offset of its first pair inside a plane
+    unsigned okrows = 0;     // bit r: input row r of the item exists
+    const bool has_item = tid < NITEM;
+    if (has_item) {
+      const int q = tid & 3, pc = (tid >> 2) % PWS, pr = NP * ((tid >> 2) / PWS);
+      const int gr0 = 2 * (pair0 + pr) - 1, gc = col0 - 1 + COFF + pc;
+      if (gc >= 0 && gc < p.W)
+#pragma unroll
+        for (int r = 0; r < NROW; ++r)
+          if (gr0 + r >= 0 && gr0 + r < p.rows_total) okrows |= 1u << r;
+      goff = (gr0 * p.W + gc) * p.Cin + q * 4;
+      lofs = (unsigned)(pr * PITCH + pc * BROW + q * 4);
+    }
+    const int row_stride = p.W * p.Cin;
+    f32x4 pre[NROW];
+    auto patch_request = [&](int s) {
+#pragma unroll
+      for (int r = 0; r < NROW; ++r) {
+        pre[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (okrows & (1u << r)) pre[r] = *(const f32x4*)(p.in + (ptrdiff_t)goff + (ptrdiff_t)r * row_stride + s * KS);
+      }
+    };
+    // one of the 4 NP (pair, position) pieces of the item: transform, split, two 8-byte LDS stores
+    auto commit_piece = [&](__bf16* buf, int piece) {
+      if (!has_item) return;
+      const int e = piece >> 2, q = piece & 3;
+      const f32x4 d0 = pre[2 * e], d1 = pre[2 * e + 1], d2 = pre[2 * e + 2], d3 = pre[2 * e + 3];
+      const f32x4 v = q == 0 ? d0 - d2 : (q == 1 ? d1 + d2 : (q == 2 ? d2 - d1 : d1 - d3));
+      u32x2 hi, lo;
+      split_bf16x4(v, hi, lo);
+      __bf16* dst = buf + lofs + e * PITCH + (2 * q) * PLANE;
+      *(u32x2*)dst = hi;
+      *(u32x2*)(dst + PLANE) = lo;
+    };
+
+    // prologue: step 0 into buffer 0
+    bf16x8 wr[3][2];   // ring of weight fragments: group gi lives in wr[gi % 3]
+    w_load(0, 0, wr[0]);
+    w_load(0, 1, wr[1]);
+    patch_request(0);
+#pragma unroll
+    for (int piece = 0; piece < 4 * NP; ++piece) commit_piece(sV, piece);
+    __syncthreads();
+
+#pragma unroll 1
+    for (int s = 0; s < nstep; ++s) {
+      const __bf16* cur = sV + (s & 1) * VBUF;
+      __bf16* nxt = sV + ((s + 1) & 1) * VBUF;
+      const bool more = s + 1 < nstep;
+      if (more) patch_request(s + 1);
+#pragma unroll
+      for (int gi = 0; gi < 12; ++gi) {
+        const int kx = gi >> 2, q = gi & 3;
+        // weights two groups ahead (the ring position of a group is static: 12 % 3 == 0)
+        if (gi + 2 < 12) w_load(s, gi + 2, wr[(gi + 2) % 3]);
+        else if (more) w_load(s + 1, gi + 2 - 12, wr[(gi + 2) % 3]);
+        const __bf16* vh = cur + (2 * q) * PLANE + kx * BROW;
+        const __bf16* vl = vh + PLANE;
+#pragma unroll
+        for (int m = 0; m < MW; ++m) {
+          // the tap of this column reads the zero padding beside the image: nothing to add
+          const int mc = mcol0 + m;   // block column of the tile (TC = 2: mcol0 = 0)
+          if ((kx == 0 && at_left && mc == 0) || (kx == 2 && at_right && mc == TC - 1)) continue;
+          const bf16x8 ah = *(const bf16x8*)(vh + pbase[m]);
+          const bf16x8 al = *(const bf16x8*)(vl + pbase[m]);
+          acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wr[gi % 3][0], acc[q][m], 0, 0, 0);
+          acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wr[gi % 3][1], acc[q][m], 0, 0, 0);
+          acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wr[gi % 3][0], acc[q][m], 0, 0, 0);
+        }
+        // the next step's planes, a piece per group (the raw rows were requested at the top of the step)
+        if (more) {
+          constexpr int FIRST = 12 - 4 * NP;
+          if (gi >= FIRST) commit_piece(nxt, gi - FIRST);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep every group's reads and pieces inside the group
+      }
+      lds_barrier();     // step s + 1 is complete in `nxt`; every wave is done reading `cur` (weight requests stay in flight)
+    }
+  }
+
+  // ---- epilogue: output transform, BN, ReLU, pooling / mean, zero rows.  Lane l owns channel l % 32 and the pairs
+  // 8 (r / 4) + 4 (l / 32) + r % 4 of each tile (MFMA output layout): both rows of a pair, the two columns of a pooling
+  // window / of the last layer's mean (the wave's two tiles) all sit in this lane's registers ----
+  const int ch = n_tile * 128 + wn * 32 + (lane & 31);
+  const float sc = p.scale[ch], sh = p.shift[ch];
+  const FastDiv by_hp(p.Hp), by_hp_out(MODE == MODE_POOL ? p.Hp_out : 1);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int prow = pair0 + mrow + 8 * (r >> 2) + 4 * half + (r & 3);   // global pair index
+    float y0[MW], y1[MW];
+#pragma unroll
+    for (int m = 0; m < MW; ++m) {
+      const float m0 = acc[0][m][r], m1 = acc[1][m][r], m2 = acc[2][m][r], m3 = acc[3][m][r];
+      y0[m] = fmaxf(fmaf((m0 + m1) + m2, sc, sh), 0.f);
+      y1[m] = fmaxf(fmaf((m1 - m2) - m3, sc, sh), 0.f);
+    }
+    const int gr = 2 * prow;
+    if (gr >= p.rows_total) continue;
+    if (MODE == MODE_FULL) {
+      const int h = by_hp.mod(gr);   // Hp is even: both rows of a pair belong to one clip
+#pragma unroll
+      for (int m = 0; m < MW; ++m) {
+        float* o = p.out + ((size_t)gr * p.W + col0 + mcol0 + m) * p.Cout + ch;
+        o[0] = h < p.H ? y0[m] : 0.f;
+        o[(size_t)p.W * p.Cout] = h + 1 < p.H ? y1[m] : 0.f;
+      }
+    } else if (MODE == MODE_POOL) {   // a row pair IS a pooled row; the wave's two columns are one pooled column
+      const bool valid = by_hp_out.mod(prow) < p.H_out;
+      const float o = 0.25f * ((y0[0] + y1[0]) + (y0[1] + y1[1]));
+      p.out[((size_t)prow * p.W_out + ((col0 + mcol0) >> 1)) * p.Cout + ch] = valid ? o : 0.f;
+    } else {   // MEANW: TC == 2
+      int h;
+      const int b = by_hp.div(gr, h);
+      if (h < p.H) p.out[((size_t)b * p.H + h) * p.Cout + ch] = 0.5f * (y0[0] + y0[1]);
+      if (h + 1 < p.H) p.out[((size_t)b * p.H + h + 1) * p.Cout + ch] = 0.5f * (y1[0] + y1[1]);
+    }
+  }
+}
+
+template <int MODE, int TC, bool FULLW>
+int launch_w1(W1Params p, hipStream_t s) {
+  constexpr int PR = 128 / TC;
+  const int pairs = p.rows_total / 2;
+  p.MT = ((pairs + PR - 1) / PR) * p.mt_cols;
+  unsigned grid;
+  if (p.map_mode == 2) grid = (unsigned)(((p.MT + 7) / 8) * 8 * p.NT);
+  else if (p.map_mode == 3) grid = (unsigned)(((p.MT + 8 / p.NT - 1) / (8 / p.NT)) * 8);
+  else grid = (unsigned)(p.MT * p.NT);
+  constexpr int PWS = FULLW ? TC : TC + 2;
+  constexpr size_t lds = (size_t)2 * 8 * PR * w1_pitch(PWS) * 2;   // 2 buffers x 4 positions x (hi, lo) planes of bf16
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)conv3x3_w1_kernel<MODE, TC, FULLW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      return AC_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3x3_w1_kernel<MODE, TC, FULLW>), dim3(grid), dim3(512), lds, s, p);
+  return ac_check_launch();
+}
+
+}  // namespace
+
+// C ABI: see include/audiocaption_hip.h
+extern "C" int ac_conv3x3_bn_relu_wino1d(const float* in, const void* wfrag, const float* scale, const float* shift,
+                                         float* out, int B, int Hp, int H, int W, int Cin, int Cout, int mode,
+                                         int map_mode, void* stream) {
+  if (!in || !wfrag || !scale || !shift || !out) return AC_ERR_ARG;
+  if (B <= 0 || Hp <= H || (Hp & 1) || W < 2 || (W != 2 && (W & 3)) || Cin % 32 || Cout % 128) return AC_ERR_ARG;
+  if (mode < 0 || mode > 2) return AC_ERR_ARG;
+  if (mode == MODE_MEANW && W != 2) return AC_ERR_ARG;
+  if ((unsigned long long)(B * (unsigned long long)Hp + 2) * W * Cin >= (1ull << 31)) return AC_ERR_ARG;   // 32-bit offsets
+  W1Params p;
+  p.in = in; p.wpk = wfrag; p.scale = scale; p.shift = shift; p.out = out;
+  p.rows_total = B * Hp; p.Hp = Hp; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+  p.mt_cols = W == 2 ? 1 : W / 4;
+  p.MT = 0;
+  p.NT = Cout / 128;
+  p.Hp_out = Hp / 2; p.H_out = H / 2; p.W_out = W / 2;
+  if (map_mode < 0) map_mode = (p.NT % 8 == 0) ? 1 : ((p.NT == 1 || p.NT == 2 || p.NT == 4) ? 3 : 2);
+  if (map_mode == 1 && p.NT % 8 != 0) return AC_ERR_ARG;
+  if (map_mode == 3 && !(p.NT == 1 || p.NT == 2 || p.NT == 4 || p.NT == 8)) return AC_ERR_ARG;
+  p.map_mode = map_mode;
+  hipStream_t s = (hipStream_t)stream;
+  if (W == 2) {
+    if (mode == MODE_FULL) return launch_w1<MODE_FULL, 2, true>(p, s);
+    if (mode == MODE_MEANW) return launch_w1<MODE_MEANW, 2, true>(p, s);
+    return AC_ERR_ARG;   // W = 2 is never pooled
+  }
+  if (W == 4) {
+    if (mode == MODE_FULL) return launch_w1<MODE_FULL, 4, true>(p, s);
+    if (mode == MODE_POOL) return launch_w1<MODE_POOL, 4, true>(p, s);
+    return AC_ERR_ARG;
+  }
+  if (mode == MODE_FULL) return launch_w1<MODE_FULL, 4, false>(p, s);
+  if (mode == MODE_POOL) return launch_w1<MODE_POOL, 4, false>(p, s);
+  return AC_ERR_ARG;
+}

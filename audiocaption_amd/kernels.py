@@ -148,6 +148,22 @@ def conv3x3_bn_relu_bf16x3_gw(x, wfrag, scale, shift, out, B, Hp, H, W, Cin, Cou
     return out
 
 
+def conv3x3_bn_relu_wino1d(x, wfrag, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode=-1):
+    """F(2,3) Winograd along time on split-bf16 operands (csrc/conv3x3_wino1d.hip); ``wfrag`` from
+    ``pack_conv_weight_wino1d_frag``.  Layers the kernel does not cover (Cout % 128 != 0: conv2 of block 1) must be
+    routed to ``conv3x3_bn_relu_bf16x3_gw`` by the caller."""
+    lib = _lib.load()
+    hook = CONV_LAUNCH_HOOK
+    if hook is not None:
+        info = {"B": B, "H": H, "Hp": Hp, "W": W, "Cin": Cin, "Cout": Cout, "mode": mode, "algo": "wino1d"}
+        hook("pre", info)
+    check(lib.ac_conv3x3_bn_relu_wino1d(ptr(x), ptr(wfrag), ptr(scale), ptr(shift), ptr(out), B, Hp, H, W, Cin,
+                                        Cout, mode, map_mode, stream()), "ac_conv3x3_bn_relu_wino1d")
+    if hook is not None:
+        hook("post", info)
+    return out
+
+
 def conv3x3_bn_relu_f16x2_gw(x, wfrag, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode=-1, overflow=None):
     """``out``: fp16 for modes 0 / 1 (an f32 ``out`` with mode 1 selects the f32 pooled output that feeds a split-bf16
     block), f32 for mode 2.  ``overflow``: a uint32 / int32 device word OR-ed with 1 when a value stored as fp16
@@ -200,6 +216,25 @@ def pack_conv_weight_bf16x3_frag(w):
         # (cout, cin, 3, 3) -> (cin, tap, cout) -> [c][ks][h][e][tap][nt][r] -> [c][tap][ks][nt][h][r][e]
         t = t.permute(1, 2, 3, 0).reshape(cin // 32, 2, 2, 8, taps, cout // 32, 32)
         return t.permute(0, 4, 1, 5, 2, 6, 3).reshape(cin // 32, taps, 2, cout // 32, 64, 8)
+
+    return torch.stack([lay(hi), lay(lo)], dim=4).contiguous()
+
+
+def pack_conv_weight_wino1d_frag(w):
+    """OIHW f32 -> U = G g (F(2,3) filter transform over the time taps ky, evaluated in float64), split into bf16
+    hi + lo, in MFMA fragment order [Cin/32][12 = 3 kx x 4 positions][2 ks][Cout/32][2 (hi, lo)][64 lanes][8]
+    (csrc/conv3x3_wino1d.hip).  Pure elementwise / small-matrix torch ops: no library GEMM."""
+    cout, cin = w.shape[0], w.shape[1]
+    g = w.double()                                                   # (o, c, ky, kx)
+    u = torch.stack([g[:, :, 0], 0.5 * (g[:, :, 0] + g[:, :, 1] + g[:, :, 2]),
+                     0.5 * (g[:, :, 0] - g[:, :, 1] + g[:, :, 2]), g[:, :, 2]], dim=3)   # (o, c, kx, position)
+    u = u.reshape(cout, cin, 12, 1)                                  # "tap" = kx * 4 + position
+    hi = u.to(torch.bfloat16)
+    lo = (u - hi.double()).to(torch.bfloat16)
+
+    def lay(t):
+        t = t.permute(1, 2, 3, 0).reshape(cin // 32, 2, 2, 8, 12, cout // 32, 32)
+        return t.permute(0, 4, 1, 5, 2, 6, 3).reshape(cin // 32, 12, 2, cout // 32, 64, 8)
 
     return torch.stack([lay(hi), lay(lo)], dim=4).contiguous()
 

@@ -72,6 +72,18 @@ int ac_conv3x3_bn_relu_bf16x3(const float* in, const void* wpk, const float* sca
 int ac_conv3x3_bn_relu_bf16x3_gw(const float* in, const void* wfrag, const float* scale, const float* shift,
                                  float* out, int B, int Hp, int H, int W, int Cin, int Cout, int mode,
                                  int map_mode, void* stream);
+/* The same operation (ConvBlock.forward, cnn_encoder.py:59-75) with 1.5x fewer multiplications: 1-D Winograd F(2,3)
+ * along the time axis (row pairs) on split-bf16 operands - the input transform V = B^T d (+-1 coefficients) in f32,
+ * then hi + lo; the filter transform U = G g evaluated offline in f64, then hi + lo; three bf16 MFMA products per
+ * transformed product, f32 accumulation, output transform + BN + ReLU (+ pool / mean) in the epilogue.  Two bf16 MFMA
+ * products per f32 product of the direct form (ac_conv3x3_bn_relu_bf16x3_gw: three) at the same f32-grade accuracy.
+ * in / out f32 with the layouts of ac_conv3x3_bn_relu.  wfrag = U split and packed in MFMA fragment order
+ * [Cin/32][3 kx][4 positions][2 k-steps][Cout/32][2 (hi, lo)][64 lanes][8] bf16, lane = (cout % 32) + 32 * ((cin % 16) / 8),
+ * element = cin % 8.  Requires Hp even, W = 2 or a multiple of 4, Cin % 32 == 0, Cout % 128 == 0 (AC_ERR_ARG otherwise;
+ * mode 1 needs W >= 4, mode 2 needs W == 2). */
+int ac_conv3x3_bn_relu_wino1d(const float* in, const void* wfrag, const float* scale, const float* shift,
+                              float* out, int B, int Hp, int H, int W, int Cin, int Cout, int mode,
+                              int map_mode, void* stream);
 
 /* "f16x2" tier of the same kernel.  Activations live in HBM as fp16 (in: [B*Hp][W][Cin] fp16; out: fp16 for modes 0
  * and 1, f32 for mode 2 = the attn_emb the rest of the path consumes), weights as fp16 hi + lo (2^-22) in the same

@@ -189,13 +189,15 @@ def _to_rows(x_nchw, Hp):
     (2, 11, 16, 128, 256, 0), (2, 9, 8, 256, 512, 1), (3, 7, 4, 512, 1024, 0), (3, 6, 4, 1024, 1024, 1),
     (5, 3, 2, 1024, 2048, 0), (5, 3, 2, 2048, 2048, 2), (1, 31, 2, 64, 128, 2), (2, 30, 16, 32, 64, 1)])
 @pytest.mark.parametrize("map_mode", [-1, 0])
-@pytest.mark.parametrize("algo", ["direct", "winograd", "bf16x3", "bf16x3_gw", "f16x2"])
+@pytest.mark.parametrize("algo", ["direct", "winograd", "bf16x3", "bf16x3_gw", "f16x2", "wino1d"])
 def test_conv3x3_bn_relu(K, B, H, W, Cin, Cout, mode, map_mode, algo):
     """conv3x3+BN+ReLU(+pool / +mean over W) vs F.conv2d on the CPU.  Tolerance 1e-4 * sqrt(K/576) abs on
     O(1) activations (fp32 accumulation-order differences only)."""
     import torch.nn.functional as F
     if map_mode == 0 and Cin > 512:
         pytest.skip("linear mapping only exercised on the small shapes")
+    if algo == "wino1d" and (Cout % 128 or (mode == 2 and W != 2)):
+        pytest.skip("the F(2,3) kernel covers 128-channel column tiles (conv2 of block 1 stays on bf16x3_gw)")
     g = torch.Generator().manual_seed(B * 1000 + H * 10 + W + Cin)
     x = torch.randn(B, Cin, H, W, generator=g)
     if algo == "f16x2":
@@ -226,6 +228,9 @@ def test_conv3x3_bn_relu(K, B, H, W, Cin, Cout, mode, map_mode, algo):
     elif algo == "bf16x3":
         K.conv3x3_bn_relu_bf16x3(_to_rows(x, Hp).cuda(), K.pack_conv_weight_bf16x3(w.cuda()), sc.cuda(),
                                  sh.cuda(), out, B, Hp, H, W, Cin, Cout, mode, map_mode)
+    elif algo == "wino1d":
+        K.conv3x3_bn_relu_wino1d(_to_rows(x, Hp).cuda(), K.pack_conv_weight_wino1d_frag(w.cuda()), sc.cuda(),
+                                 sh.cuda(), out, B, Hp, H, W, Cin, Cout, mode, map_mode)
     elif algo == "f16x2":
         wfrag, inv = K.pack_conv_weight_f16x2_frag(w.cuda())
         out16 = out if mode == 2 else torch.full(out.shape, 7.0, dtype=torch.float16, device="cuda")
@@ -238,7 +243,7 @@ def test_conv3x3_bn_relu(K, B, H, W, Cin, Cout, mode, map_mode, algo):
         K.conv3x3_bn_relu_bf16x3_gw(_to_rows(x, Hp).cuda(), K.pack_conv_weight_bf16x3_frag(w.cuda()), sc.cuda(),
                                     sh.cuda(), out, B, Hp, H, W, Cin, Cout, mode, map_mode)
     tol = 1e-4 * max(1.0, math.sqrt(9 * Cin / 576))
-    if algo.startswith("bf16x3"):
+    if algo.startswith("bf16x3") or algo == "wino1d":
         tol *= 10  # split-bf16 tier: 2^-16 relative operand error (f32: 2^-24) on O(1..10) outputs
     if algo == "f16x2" and mode != 2:
         tol += 4e-3  # one fp16 ulp of an O(1..8) output (the reference value may round the other way)

@@ -57,6 +57,11 @@ def main():
             elif algo == "bf16x3":
                 wp = K.pack_conv_weight_bf16x3(w)
                 fn = lambda: K.conv3x3_bn_relu_bf16x3(x, wp, sc, sh, out, B, Hp, H, W, Cin, Cout, mode)
+            elif algo == "wino1d":
+                if Cout % 128:
+                    continue
+                wp = K.pack_conv_weight_wino1d_frag(w)
+                fn = lambda: K.conv3x3_bn_relu_wino1d(x, wp, sc, sh, out, B, Hp, H, W, Cin, Cout, mode, args.map_mode)
             elif algo == "f16x2":
                 wp, inv = K.pack_conv_weight_f16x2_frag(w)
                 sc2 = (sc * inv).contiguous()
