@@ -26,6 +26,8 @@
 // buffer, piecewise between the MFMA groups; one workgroup barrier per step.  The 12 (kx, p) weight fragments of a step
 // come straight from L2 in MFMA fragment order (pre-transformed, pre-split), requested two groups ahead.  Column tiles
 // know which mel taps fall on the zero padding beside the image and skip them (a third of the work at W = 2).
+#include <type_traits>
+
 #include "ac_common.h"
 
 namespace {
@@ -84,7 +86,8 @@ struct FastDiv {
 };
 
 // block -> (m_tile, n_tile); block b runs on XCD b % 8 (speed only).  map_mode 1: one XCD streams one weight column
-// slab (weight-heavy layers, NT % 8 == 0); 2: blocks sharing a halo patch share an L2; 3: NT in {1, 2, 4}
+// slab (weight-heavy layers, NT % 8 == 0); 2: the channel tiles of a pixel tile share an L2; 3: NT in {1, 2, 4}: every
+// XCD owns one weight slab; 4: row blocks (below)
 __device__ __forceinline__ bool block_map(const W1Params& p, int& m_tile, int& n_tile) {
   const int bid = blockIdx.x;
   const int xcd = bid & 7, seq = bid >> 3;
@@ -99,6 +102,14 @@ __device__ __forceinline__ bool block_map(const W1Params& p, int& m_tile, int& n
     const int per = 8 / p.NT;
     n_tile = xcd % p.NT;
     m_tile = seq * per + xcd / p.NT;
+    if (m_tile >= p.MT) return false;
+  } else if (p.map_mode == 4) {
+    // every column block and channel tile of one ROW block back to back on one XCD: the row block's input rows (with
+    // the column halos its blocks share) reach that L2 once
+    const int G = p.mt_cols * p.NT;
+    const int within = seq % G;
+    n_tile = within % p.NT;
+    m_tile = ((seq / G) * 8 + xcd) * p.mt_cols + within / p.NT;
     if (m_tile >= p.MT) return false;
   } else {
     n_tile = bid % p.NT;
@@ -130,7 +141,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w1_kernel(W1Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm_raw[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform for the compiler: scalar branches below
   const int wn = wave & 3, wg = wave >> 2;
   const int half = lane >> 5;
 
@@ -161,39 +172,42 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w1_kernel(W1Params p) {
   const bool all_pad = (rc0 >= p.H && rc0 + 2 * PR <= p.Hp) || row0 >= p.rows_total;
   const int nstep = p.Cin / KS;
   if (!all_pad) {
-    // weight fragment of (32-channel chunk c, group gi = kx * 4 + p, k-step ks, plane) for this wave's 32 channels
+    // Buffer descriptors (wave-uniform): out-of-range offsets read as zero, so the rows above / below the batch and the
+    // threads without a staging item need no branches.
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.in, 0, (int)((unsigned)p.rows_total * (unsigned)p.W * (unsigned)p.Cin * 4u), 0x00020000);
     const int NT32 = p.Cout >> 5;
-    const bf16x8* wf = (const bf16x8*)p.wpk + (size_t)(n_tile * 4 + wn) * 2 * 64 + lane;
-    const size_t ks_stride = (size_t)NT32 * 2 * 64;
+    const unsigned ks_bytes = (unsigned)NT32 * 2048u;   // one k-step of a (chunk, group): NT32 x (hi, lo) x 1 KiB
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.wpk, 0, (int)((unsigned)(p.Cin / 32) * 24u * ks_bytes), 0x00020000);
+    // weight fragment of (K step s = 2 chunk + k-step, group gi = kx * 4 + p, plane) for this wave's 32 channels
+    const unsigned wvoff = (unsigned)((n_tile * 4 + wn) * 2048 + lane * 16);
     auto w_load = [&](int s, int gi, bf16x8 (&w)[2]) {
-      const size_t base = ((size_t)((s >> 1) * 12 + gi) * 2 + (s & 1)) * ks_stride;
-      w[0] = wf[base];
-      w[1] = wf[base + 64];
+      const unsigned soff = (unsigned)(((s >> 1) * 12 + gi) * 2 + (s & 1)) * ks_bytes;
+      w[0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff, soff, 0));
+      w[1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff + 1024u, soff, 0));
     };
 
-    // Staging descriptor of this thread's item, once per workgroup
-    int goff = 0;            // element offset of the item's first input row (2 pair - 1; negative for the very first row)
-    unsigned lofs = 0;       // LDS element offset of its first pair inside a plane
-    unsigned okrows = 0;     // bit r: input row r of the item exists
+    // Staging descriptor of this thread's item, once per workgroup: byte offset of its first input row (row 2 pair - 1:
+    // "negative" for the very first row of the batch -> out of range -> zeros; the rows below it wrap back into range)
+    // and its LDS offset.  Threads without an item / columns outside the image: an offset that stays out of range.
+    unsigned vbase;
+    unsigned lofs = 0;       // LDS element offset of the item's first pair inside a plane
     const bool has_item = tid < NITEM;
-    if (has_item) {
+    {
       const int q = tid & 3, pc = (tid >> 2) % PWS, pr = NP * ((tid >> 2) / PWS);
       const int gr0 = 2 * (pair0 + pr) - 1, gc = col0 - 1 + COFF + pc;
-      if (gc >= 0 && gc < p.W)
-#pragma unroll
-        for (int r = 0; r < NROW; ++r)
-          if (gr0 + r >= 0 && gr0 + r < p.rows_total) okrows |= 1u << r;
-      goff = (gr0 * p.W + gc) * p.Cin + q * 4;
+      const bool ok = has_item && gc >= 0 && gc < p.W;
+      vbase = ok ? (unsigned)((gr0 * p.W + gc) * p.Cin + q * 4) * 4u : 0x80000000u;
       lofs = (unsigned)(pr * PITCH + pc * BROW + q * 4);
     }
-    const int row_stride = p.W * p.Cin;
+    const unsigned row_bytes = (unsigned)(p.W * p.Cin) * 4u;
     f32x4 pre[NROW];
     auto patch_request = [&](int s) {
+      const unsigned v0 = vbase + (unsigned)(s * KS * 4);
 #pragma unroll
-      for (int r = 0; r < NROW; ++r) {
-        pre[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (okrows & (1u << r)) pre[r] = *(const f32x4*)(p.in + (ptrdiff_t)goff + (ptrdiff_t)r * row_stride + s * KS);
-      }
+      for (int r = 0; r < NROW; ++r)
+        pre[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, v0 + (unsigned)r * row_bytes, 0, 0));
     };
     // one of the 4 NP (pair, position) pieces of the item: transform, split, two 8-byte LDS stores
     auto commit_piece = [&](__bf16* buf, int piece) {
@@ -217,39 +231,64 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w1_kernel(W1Params p) {
     for (int piece = 0; piece < 4 * NP; ++piece) commit_piece(sV, piece);
     __syncthreads();
 
-#pragma unroll 1
-    for (int s = 0; s < nstep; ++s) {
-      const __bf16* cur = sV + (s & 1) * VBUF;
-      __bf16* nxt = sV + ((s + 1) & 1) * VBUF;
-      const bool more = s + 1 < nstep;
-      if (more) patch_request(s + 1);
-#pragma unroll
-      for (int gi = 0; gi < 12; ++gi) {
+    // SL / SR (compile time): this wave's tile 0 is the first / its tile 1 the last column of the IMAGE, whose kx = 0 /
+    // kx = 2 products read the zero padding beside it: nothing to add.  (Kept out of run-time branches: an MFMA under a
+    // branch makes the compiler copy its accumulator.)
+    auto k_loop = [&](auto SL_, auto SR_) {
+      constexpr bool SL = decltype(SL_)::value, SR = decltype(SR_)::value;
+      auto a_load = [&](const __bf16* buf, int gi, bf16x8 (&a)[MW][2]) {
         const int kx = gi >> 2, q = gi & 3;
-        // weights two groups ahead (the ring position of a group is static: 12 % 3 == 0)
-        if (gi + 2 < 12) w_load(s, gi + 2, wr[(gi + 2) % 3]);
-        else if (more) w_load(s + 1, gi + 2 - 12, wr[(gi + 2) % 3]);
-        const __bf16* vh = cur + (2 * q) * PLANE + kx * BROW;
-        const __bf16* vl = vh + PLANE;
+        const __bf16* vh = buf + (2 * q) * PLANE + kx * BROW;
 #pragma unroll
         for (int m = 0; m < MW; ++m) {
-          // the tap of this column reads the zero padding beside the image: nothing to add
-          const int mc = mcol0 + m;   // block column of the tile (TC = 2: mcol0 = 0)
-          if ((kx == 0 && at_left && mc == 0) || (kx == 2 && at_right && mc == TC - 1)) continue;
-          const bf16x8 ah = *(const bf16x8*)(vh + pbase[m]);
-          const bf16x8 al = *(const bf16x8*)(vl + pbase[m]);
-          acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wr[gi % 3][0], acc[q][m], 0, 0, 0);
-          acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wr[gi % 3][1], acc[q][m], 0, 0, 0);
-          acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wr[gi % 3][0], acc[q][m], 0, 0, 0);
+          if ((kx == 0 && m == 0 && SL) || (kx == 2 && m == 1 && SR)) continue;
+          a[m][0] = *(const bf16x8*)(vh + pbase[m]);
+          a[m][1] = *(const bf16x8*)(vh + PLANE + pbase[m]);
         }
-        // the next step's planes, a piece per group (the raw rows were requested at the top of the step)
-        if (more) {
-          constexpr int FIRST = 12 - 4 * NP;
-          if (gi >= FIRST) commit_piece(nxt, gi - FIRST);
+      };
+      bf16x8 af[2][MW][2];   // A fragments (tile, hi | lo) of the current and the next group
+#pragma unroll 1
+      for (int s = 0; s < nstep; ++s) {
+        const __bf16* cur = sV + (s & 1) * VBUF;
+        __bf16* nxt = sV + ((s + 1) & 1) * VBUF;
+        const bool more = s + 1 < nstep;
+        if (more) patch_request(s + 1);
+        a_load(cur, 0, af[0]);
+#pragma unroll
+        for (int gi = 0; gi < 12; ++gi) {
+          const int kx = gi >> 2, q = gi & 3;
+          // the next group's fragments are requested before this group's MFMAs; weights two groups ahead (the ring
+          // position of a group is static: 12 % 3 == 0)
+          if (gi + 1 < 12) a_load(cur, gi + 1, af[(gi + 1) & 1]);
+          if (gi + 2 < 12) w_load(s, gi + 2, wr[(gi + 2) % 3]);
+          else if (more) w_load(s + 1, gi + 2 - 12, wr[(gi + 2) % 3]);
+#pragma unroll
+          for (int m = 0; m < MW; ++m) {
+            if ((kx == 0 && m == 0 && SL) || (kx == 2 && m == 1 && SR)) continue;
+            const bf16x8 ah = af[gi & 1][m][0], al = af[gi & 1][m][1];
+            acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wr[gi % 3][0], acc[q][m], 0, 0, 0);
+            acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wr[gi % 3][1], acc[q][m], 0, 0, 0);
+            acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wr[gi % 3][0], acc[q][m], 0, 0, 0);
+          }
+          // the next step's planes, a piece per group (the raw rows were requested at the top of the step)
+          if (more) {
+            constexpr int FIRST = 12 - 4 * NP;
+            if (gi >= FIRST) commit_piece(nxt, gi - FIRST);
+          }
+          __builtin_amdgcn_sched_barrier(0);   // keep every group's requests and pieces inside the group
         }
-        __builtin_amdgcn_sched_barrier(0);   // keep every group's reads and pieces inside the group
+        lds_barrier();   // step s + 1 is complete in `nxt`; every wave is done reading `cur` (weight requests stay in flight)
       }
-      lds_barrier();     // step s + 1 is complete in `nxt`; every wave is done reading `cur` (weight requests stay in flight)
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    if (TC == 2) {
+      k_loop(T_{}, T_{});                       // both columns of the image in every wave
+    } else {
+      const bool sl = at_left && wg == 0, sr = at_right && wg == 1;   // wave-uniform
+      if (sl) k_loop(T_{}, F_{});
+      else if (sr) k_loop(F_{}, T_{});
+      else k_loop(F_{}, F_{});
     }
   }
 
@@ -300,6 +339,7 @@ int launch_w1(W1Params p, hipStream_t s) {
   unsigned grid;
   if (p.map_mode == 2) grid = (unsigned)(((p.MT + 7) / 8) * 8 * p.NT);
   else if (p.map_mode == 3) grid = (unsigned)(((p.MT + 8 / p.NT - 1) / (8 / p.NT)) * 8);
+  else if (p.map_mode == 4) grid = (unsigned)(((p.MT / p.mt_cols + 7) / 8) * 8 * p.mt_cols * p.NT);
   else grid = (unsigned)(p.MT * p.NT);
   constexpr int PWS = FULLW ? TC : TC + 2;
   constexpr size_t lds = (size_t)2 * 8 * PR * w1_pitch(PWS) * 2;   // 2 buffers x 4 positions x (hi, lo) planes of bf16
