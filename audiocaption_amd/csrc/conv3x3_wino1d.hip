@@ -18,14 +18,18 @@
 // 64 x 64 (tile, channel) outputs in flight, and at that size the transformed operands (4 KB of fresh fragments per
 // three MFMAs) exceed what LDS and the L1 can deliver to the matrix cores.
 //
-// Work decomposition.  A 512-thread workgroup (two waves per SIMD) owns 128 row pairs (256 output pixels: 32 pairs x 4
-// columns, or 64 pairs x 2 columns for the 2-column layers) x 128 output channels.  Wave (g, n) owns two MFMA tiles (32
-// consecutive pairs of one column each) x 32 channels x 4 positions = 128 accumulator registers.  The K loop runs in
-// 16-channel steps over a DOUBLE-BUFFERED set of V planes in LDS: while the matrix cores consume step s, the raw rows of
-// step s + 1 (requested into registers at the start of step s) are transformed, split and stored into the other
-// buffer, piecewise between the MFMA groups; one workgroup barrier per step.  The 12 (kx, p) weight fragments of a step
-// come straight from L2 in MFMA fragment order (pre-transformed, pre-split), requested two groups ahead.  Column tiles
-// know which mel taps fall on the zero padding beside the image and skip them (a third of the work at W = 2).
+// Work decomposition.  Every wave owns 32 output channels x two MFMA tiles of 32 output-row pairs x 4 positions = 128
+// accumulator registers; two waves per SIMD.  The K loop runs in 16-channel steps over a DOUBLE-BUFFERED set of V planes
+// in LDS: while the matrix cores consume step s, the raw rows of step s + 1 (requested into registers at the start of
+// step s) are transformed, split and stored into the other buffer, piecewise between the MFMA groups; one workgroup
+// barrier per step.  The 12 (kx, p) weight fragments of a step come straight from L2 in MFMA fragment order
+// (pre-transformed, pre-split), requested two groups ahead; the A fragments of a group one group ahead.
+//   * W = 2 / W = 4 (blocks 5-6: long K, few pixels): 512-thread workgroups of 256 pixels (64 pairs x 2 columns, 32 pairs
+//     x 4 columns) x 128 channels; a tile is 32 pairs of ONE column, so the kx taps that read the zero padding beside the
+//     image are skipped (a third / a sixth of the work) and the outer halo columns are not staged.
+//   * W >= 8 (blocks 2-4: short K, many pixels): 256-thread workgroups of 128 pixels (16 pairs x 4 columns) x 128
+//     channels, TWO per CU, so that one's prologue / epilogue (a third of a workgroup's life at K = 64...256) runs under
+//     the other's MFMAs; a tile is 16 pairs x 2 columns.
 #include <type_traits>
 
 #include "ac_common.h"
@@ -118,26 +122,38 @@ __device__ __forceinline__ bool block_map(const W1Params& p, int& m_tile, int& n
   return true;
 }
 
-// LDS pitch (bf16 elements) of one pair row of `pws` staged columns: an odd number of 16-byte slots, so the 16 lanes of
-// every ds_read_b128 group (consecutive pairs of one column) land in 16 different bank slots
-__host__ __device__ constexpr int w1_pitch(int pws) { return pws * BROW + 8; }
-
 // TC: columns of the block (4, or 2 for the 2-column layers).  FULLW: the block spans the whole image width (W == TC):
-// its two outer halo columns are never read (every tap that would is skipped), so they are not staged.
-template <int MODE, int TC, bool FULLW>
-__global__ __launch_bounds__(512, 2) void conv3x3_w1_kernel(W1Params p) {
-  constexpr int PR = 128 / TC;              // pair rows per block
-  constexpr int MW = 2;                     // MFMA tiles per wave
-  constexpr int COFF = FULLW ? 1 : 0;
-  constexpr int PWS = TC + 2 - 2 * COFF;    // staged columns: image columns col0 - 1 + COFF ..
-  constexpr int PITCH = w1_pitch(PWS);
-  constexpr int PLANE = PR * PITCH;         // one (position, hi | lo) plane
-  constexpr int VBUF = 8 * PLANE;           // [4 p][2 (hi, lo)][PR][PITCH]
+// its two outer halo columns are never read (every tap that would is skipped), so they are not staged.  WIDE: the
+// 256-thread / 128-pixel form for W >= 8 (TC = 4, not FULLW).
+//
+// V planes in LDS, one per (position, hi | lo), items of 16 channels = 32 bytes = two 16-byte bank slots.
+//   !WIDE: [pair][staged column], pair pitch an odd number of slots;  WIDE: [staged column][pair], column pitch an odd
+//   number of slots - either way the 16 lanes of every ds_read_b128 group (16 consecutive pairs of one column, or 8
+//   pairs of one column + 8 of the next) land in 16 different slots.
+template <int TC, bool FULLW, bool WIDE>
+struct W1Geom {
+  static_assert(!WIDE || (TC == 4 && !FULLW), "the wide form is 4 columns with halo");
+  static constexpr int THREADS = WIDE ? 256 : 512;
+  static constexpr int PR = WIDE ? 16 : 128 / TC;          // pair rows per block
+  static constexpr int COFF = FULLW ? 1 : 0;
+  static constexpr int PWS = TC + 2 - 2 * COFF;            // staged columns: image columns col0 - 1 + COFF ..
+  static constexpr int PAIR_PITCH = WIDE ? BROW : PWS * BROW + 8;
+  static constexpr int COL_PITCH = WIDE ? PR * BROW + 8 : BROW;
+  static constexpr int PLANE = WIDE ? PWS * COL_PITCH : PR * PAIR_PITCH;   // one (position, hi | lo) plane
+  static constexpr int VBUF = 8 * PLANE;
   // staging item = NP vertically adjacent pairs x one staged column x one channel quad: 2 NP + 2 input rows
-  constexpr int NP = FULLW ? 1 : 2;
-  constexpr int NROW = 2 * NP + 2;
-  constexpr int NITEM = (PR / NP) * PWS * (KS / 4);
-  static_assert(NITEM <= 512, "one staging item per thread");
+  static constexpr int NP = FULLW ? 1 : 2;
+  static constexpr int NROW = 2 * NP + 2;
+  static constexpr int NITEM = (PR / NP) * PWS * (KS / 4);
+  static_assert(NITEM <= THREADS, "one staging item per thread");
+};
+
+template <int MODE, int TC, bool FULLW, bool WIDE>
+__global__ __launch_bounds__((W1Geom<TC, FULLW, WIDE>::THREADS), 2) void conv3x3_w1_kernel(W1Params p) {
+  using G = W1Geom<TC, FULLW, WIDE>;
+  constexpr int PR = G::PR, MW = 2, COFF = G::COFF, PWS = G::PWS, PLANE = G::PLANE, VBUF = G::VBUF;
+  constexpr int PAIR_PITCH = G::PAIR_PITCH, COL_PITCH = G::COL_PITCH;
+  constexpr int NP = G::NP, NROW = G::NROW, NITEM = G::NITEM;
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm_raw[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -152,12 +168,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w1_kernel(W1Params p) {
   const bool at_left = col0 == 0, at_right = col0 + TC == p.W;
   __bf16* sV = (__bf16*)dsm_raw;            // two buffers of VBUF elements
 
-  // this wave's tiles: TC = 4: columns 2 wg, 2 wg + 1 of the 32 pairs; TC = 2: columns 0, 1 of pair group wg
-  const int mrow = TC == 4 ? 0 : wg * 32;
-  const int mcol0 = TC == 4 ? 2 * wg : 0;
+  // this wave's two tiles.  !WIDE: 32 pairs of one column each - TC = 4: columns 2 wg, 2 wg + 1; TC = 2: columns 0, 1 of
+  // pair group wg.  WIDE (wg = 0): tile m = 16 pairs x columns 2 m, 2 m + 1; MFMA row i = pair i & 15 of column i >> 4
+  const int mrow = (WIDE || TC == 4) ? 0 : wg * 32;
+  const int mcol0 = (!WIDE && TC == 4) ? 2 * wg : 0;
   int pbase[MW];
+  {
+    const int i = lane & 31;
+    const int pr = WIDE ? (i & 15) : mrow + i, dc = WIDE ? (i >> 4) : 0;
 #pragma unroll
-  for (int m = 0; m < MW; ++m) pbase[m] = (mrow + (lane & 31)) * PITCH + (mcol0 + m - COFF) * BROW + half * 8;
+    for (int m = 0; m < MW; ++m)
+      pbase[m] = pr * PAIR_PITCH + (mcol0 + (WIDE ? 2 * m : m) + dc - COFF) * COL_PITCH + half * 8;
+  }
 
   f32x16 acc[4][MW];
 #pragma unroll
@@ -199,7 +221,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w1_kernel(W1Params p) {
       const int gr0 = 2 * (pair0 + pr) - 1, gc = col0 - 1 + COFF + pc;
       const bool ok = has_item && gc >= 0 && gc < p.W;
       vbase = ok ? (unsigned)((gr0 * p.W + gc) * p.Cin + q * 4) * 4u : 0x80000000u;
-      lofs = (unsigned)(pr * PITCH + pc * BROW + q * 4);
+      lofs = (unsigned)(pr * PAIR_PITCH + pc * COL_PITCH + q * 4);
     }
     const unsigned row_bytes = (unsigned)(p.W * p.Cin) * 4u;
     f32x4 pre[NROW];
@@ -217,7 +239,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w1_kernel(W1Params p) {
       const f32x4 v = q == 0 ? d0 - d2 : (q == 1 ? d1 + d2 : (q == 2 ? d2 - d1 : d1 - d3));
       u32x2 hi, lo;
       split_bf16x4(v, hi, lo);
-      __bf16* dst = buf + lofs + e * PITCH + (2 * q) * PLANE;
+      __bf16* dst = buf + lofs + e * PAIR_PITCH + (2 * q) * PLANE;
       *(u32x2*)dst = hi;
       *(u32x2*)(dst + PLANE) = lo;
     };
@@ -238,7 +260,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w1_kernel(W1Params p) {
       constexpr bool SL = decltype(SL_)::value, SR = decltype(SR_)::value;
       auto a_load = [&](const __bf16* buf, int gi, bf16x8 (&a)[MW][2]) {
         const int kx = gi >> 2, q = gi & 3;
-        const __bf16* vh = buf + (2 * q) * PLANE + kx * BROW;
+        const __bf16* vh = buf + (2 * q) * PLANE + kx * COL_PITCH;
 #pragma unroll
         for (int m = 0; m < MW; ++m) {
           if ((kx == 0 && m == 0 && SL) || (kx == 2 && m == 1 && SR)) continue;
@@ -282,7 +304,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w1_kernel(W1Params p) {
     };
     using T_ = std::true_type;
     using F_ = std::false_type;
-    if (TC == 2) {
+    if (WIDE) {
+      k_loop(F_{}, F_{});                       // two-column tiles: the halo columns beside the image are staged as zeros
+    } else if (TC == 2) {
       k_loop(T_{}, T_{});                       // both columns of the image in every wave
     } else {
       const bool sl = at_left && wg == 0, sr = at_right && wg == 1;   // wave-uniform
@@ -292,36 +316,43 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w1_kernel(W1Params p) {
     }
   }
 
-  // ---- epilogue: output transform, BN, ReLU, pooling / mean, zero rows.  Lane l owns channel l % 32 and the pairs
-  // 8 (r / 4) + 4 (l / 32) + r % 4 of each tile (MFMA output layout): both rows of a pair, the two columns of a pooling
-  // window / of the last layer's mean (the wave's two tiles) all sit in this lane's registers ----
+  // ---- epilogue: output transform, BN, ReLU, pooling / mean, zero rows.  Lane l owns channel l % 32 and the MFMA rows
+  // i = 8 (r / 4) + 4 (l / 32) + r % 4 of each tile: both rows of a pair, and the two columns of a pooling window / of the
+  // last layer's mean - the wave's two tiles (!WIDE), registers r and r + 8 of one tile (WIDE) - sit in this lane ----
   const int ch = n_tile * 128 + wn * 32 + (lane & 31);
   const float sc = p.scale[ch], sh = p.shift[ch];
   const FastDiv by_hp(p.Hp), by_hp_out(MODE == MODE_POOL ? p.Hp_out : 1);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int prow = pair0 + mrow + 8 * (r >> 2) + 4 * half + (r & 3);   // global pair index
-    float y0[MW], y1[MW];
+  for (int r = 0; r < (WIDE ? 8 : 16); ++r) {
+    const int i = 8 * (r >> 2) + 4 * half + (r & 3);                      // WIDE: r < 8 -> i < 16 = the pair
+    const int prow = pair0 + mrow + i;                                    // global pair index
+    // y[row of the pair][column slot]: !WIDE: slot = tile; WIDE: slot = 2 tile + (column inside the tile)
+    constexpr int NS = WIDE ? 4 : 2;
+    float y0[NS], y1[NS];
 #pragma unroll
-    for (int m = 0; m < MW; ++m) {
-      const float m0 = acc[0][m][r], m1 = acc[1][m][r], m2 = acc[2][m][r], m3 = acc[3][m][r];
-      y0[m] = fmaxf(fmaf((m0 + m1) + m2, sc, sh), 0.f);
-      y1[m] = fmaxf(fmaf((m1 - m2) - m3, sc, sh), 0.f);
+    for (int sl = 0; sl < NS; ++sl) {
+      const int m = WIDE ? sl >> 1 : sl, rr = WIDE ? r + 8 * (sl & 1) : r;
+      const float m0 = acc[0][m][rr], m1 = acc[1][m][rr], m2 = acc[2][m][rr], m3 = acc[3][m][rr];
+      y0[sl] = fmaxf(fmaf((m0 + m1) + m2, sc, sh), 0.f);
+      y1[sl] = fmaxf(fmaf((m1 - m2) - m3, sc, sh), 0.f);
     }
     const int gr = 2 * prow;
     if (gr >= p.rows_total) continue;
     if (MODE == MODE_FULL) {
       const int h = by_hp.mod(gr);   // Hp is even: both rows of a pair belong to one clip
 #pragma unroll
-      for (int m = 0; m < MW; ++m) {
-        float* o = p.out + ((size_t)gr * p.W + col0 + mcol0 + m) * p.Cout + ch;
-        o[0] = h < p.H ? y0[m] : 0.f;
-        o[(size_t)p.W * p.Cout] = h + 1 < p.H ? y1[m] : 0.f;
+      for (int sl = 0; sl < NS; ++sl) {
+        float* o = p.out + ((size_t)gr * p.W + col0 + mcol0 + sl) * p.Cout + ch;
+        o[0] = h < p.H ? y0[sl] : 0.f;
+        o[(size_t)p.W * p.Cout] = h + 1 < p.H ? y1[sl] : 0.f;
       }
-    } else if (MODE == MODE_POOL) {   // a row pair IS a pooled row; the wave's two columns are one pooled column
+    } else if (MODE == MODE_POOL) {   // a row pair IS a pooled row; column slots (0, 1) and (2, 3) are pooled columns
       const bool valid = by_hp_out.mod(prow) < p.H_out;
-      const float o = 0.25f * ((y0[0] + y1[0]) + (y0[1] + y1[1]));
-      p.out[((size_t)prow * p.W_out + ((col0 + mcol0) >> 1)) * p.Cout + ch] = valid ? o : 0.f;
+#pragma unroll
+      for (int oc = 0; oc < NS / 2; ++oc) {
+        const float o = 0.25f * ((y0[2 * oc] + y1[2 * oc]) + (y0[2 * oc + 1] + y1[2 * oc + 1]));
+        p.out[((size_t)prow * p.W_out + ((col0 + mcol0) >> 1) + oc) * p.Cout + ch] = valid ? o : 0.f;
+      }
     } else {   // MEANW: TC == 2
       int h;
       const int b = by_hp.div(gr, h);
@@ -331,26 +362,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w1_kernel(W1Params p) {
   }
 }
 
-template <int MODE, int TC, bool FULLW>
+template <int MODE, int TC, bool FULLW, bool WIDE>
 int launch_w1(W1Params p, hipStream_t s) {
-  constexpr int PR = 128 / TC;
+  using G = W1Geom<TC, FULLW, WIDE>;
   const int pairs = p.rows_total / 2;
-  p.MT = ((pairs + PR - 1) / PR) * p.mt_cols;
+  p.MT = ((pairs + G::PR - 1) / G::PR) * p.mt_cols;
   unsigned grid;
   if (p.map_mode == 2) grid = (unsigned)(((p.MT + 7) / 8) * 8 * p.NT);
   else if (p.map_mode == 3) grid = (unsigned)(((p.MT + 8 / p.NT - 1) / (8 / p.NT)) * 8);
   else if (p.map_mode == 4) grid = (unsigned)(((p.MT / p.mt_cols + 7) / 8) * 8 * p.mt_cols * p.NT);
   else grid = (unsigned)(p.MT * p.NT);
-  constexpr int PWS = FULLW ? TC : TC + 2;
-  constexpr size_t lds = (size_t)2 * 8 * PR * w1_pitch(PWS) * 2;   // 2 buffers x 4 positions x (hi, lo) planes of bf16
+  constexpr size_t lds = (size_t)2 * G::VBUF * 2;   // two buffers of 4 positions x (hi, lo) planes, bf16
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv3x3_w1_kernel<MODE, TC, FULLW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)conv3x3_w1_kernel<MODE, TC, FULLW, WIDE>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return AC_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3x3_w1_kernel<MODE, TC, FULLW>), dim3(grid), dim3(512), lds, s, p);
+  hipLaunchKernelGGL((conv3x3_w1_kernel<MODE, TC, FULLW, WIDE>), dim3(grid), dim3(G::THREADS), lds, s, p);
   return ac_check_launch();
 }
 
@@ -378,16 +408,16 @@ extern "C" int ac_conv3x3_bn_relu_wino1d(const float* in, const void* wfrag, con
   p.map_mode = map_mode;
   hipStream_t s = (hipStream_t)stream;
   if (W == 2) {
-    if (mode == MODE_FULL) return launch_w1<MODE_FULL, 2, true>(p, s);
-    if (mode == MODE_MEANW) return launch_w1<MODE_MEANW, 2, true>(p, s);
+    if (mode == MODE_FULL) return launch_w1<MODE_FULL, 2, true, false>(p, s);
+    if (mode == MODE_MEANW) return launch_w1<MODE_MEANW, 2, true, false>(p, s);
     return AC_ERR_ARG;   // W = 2 is never pooled
   }
   if (W == 4) {
-    if (mode == MODE_FULL) return launch_w1<MODE_FULL, 4, true>(p, s);
-    if (mode == MODE_POOL) return launch_w1<MODE_POOL, 4, true>(p, s);
+    if (mode == MODE_FULL) return launch_w1<MODE_FULL, 4, true, false>(p, s);
+    if (mode == MODE_POOL) return launch_w1<MODE_POOL, 4, true, false>(p, s);
     return AC_ERR_ARG;
   }
-  if (mode == MODE_FULL) return launch_w1<MODE_FULL, 4, false>(p, s);
-  if (mode == MODE_POOL) return launch_w1<MODE_POOL, 4, false>(p, s);
+  if (mode == MODE_FULL) return launch_w1<MODE_FULL, 4, false, true>(p, s);
+  if (mode == MODE_POOL) return launch_w1<MODE_POOL, 4, false, true>(p, s);
   return AC_ERR_ARG;
 }
