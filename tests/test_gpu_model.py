@@ -36,16 +36,18 @@ def _cnn_from_logmel(cnn, lms):
     return attn, blocks
 
 
-# Absolute tolerances per conv tier on O(1) activations / logits.  "bf16x3" (split bf16, 2^-16 operand error) is held
-# to the f32 bars the exact-f32 kernels are held to; "f16x2" (fp16 activations, the default) to BASELINE.json's
-# half-precision bar: identical token ids, logits within 1e-3 (measured: 4e-4).
-TIER_TOL = {"bf16x3": {"block": 1e-4, "attn_golden": 2e-4, "attn_e2e": 5e-4, "logit_e2e": 1e-3, "block_sum_rtol": 2e-5},
+# Absolute tolerances per conv tier on O(1) activations / logits.  The f32-grade tiers - "wino1d" (the default: F(2,3)
+# Winograd on split-bf16 operands), "bf16x3" (direct, split bf16; 2^-16 operand error) and the exact-f32 "winograd" - are
+# held to SURVEY 8(d)'s fp32 gate end to end: identical token ids, logits within 1e-4; the opt-in "f16x2" tier (fp16
+# activations) to BASELINE.json's half-precision bar: identical token ids, logits within 1e-3 (measured: 4e-4).
+_F32_GRADE = {"block": 1e-4, "attn_golden": 2e-4, "attn_e2e": 5e-4, "logit_e2e": 1e-4, "block_sum_rtol": 2e-5}
+TIER_TOL = {"wino1d": _F32_GRADE, "bf16x3": _F32_GRADE, "winograd": _F32_GRADE,
             "f16x2": {"block": 1.5e-3, "attn_golden": 1e-3, "attn_e2e": 1e-3, "logit_e2e": 1e-3, "block_sum_rtol": 1e-4}}
 
 
-@pytest.fixture(params=["f16x2", "bf16x3"])
+@pytest.fixture(params=["wino1d", "bf16x3", "winograd", "f16x2"])
 def conv_tier(request, hip_model):
-    """Run the test once per production conv tier of the Cnn14 (the default and the f32-grade one)."""
+    """Run the test once per conv tier of the Cnn14: the default, the other two f32-grade ones and the fp16 one."""
     cnn = hip_model.encoder.cnn
     saved = cnn.conv_algo
     cnn.conv_algo = request.param
@@ -54,7 +56,7 @@ def conv_tier(request, hip_model):
 
 
 def test_default_conv_tier(hip_model):
-    assert hip_model.encoder.cnn.conv_algo == os.environ.get("AUDIOCAPTION_CONV_ALGO", "f16x2")
+    assert hip_model.encoder.cnn.conv_algo == os.environ.get("AUDIOCAPTION_CONV_ALGO", "wino1d")
 
 
 def test_g1_cnn14_vs_reference_golden(hip_model, golden_dir, conv_tier):
@@ -117,7 +119,7 @@ def test_f16x2_tier_odd_geometries(hip_model, monkeypatch, B, T):
     assert _maxdiff(f"attn_emb f16x2 vs f32 B={B} T={T}", got, want) < 1e-3 * max(1.0, float(want.abs().max()))
 
 
-@pytest.mark.parametrize("algo", ["direct", "winograd", "bf16x3", "bf16x3_lds", "f16x2"])
+@pytest.mark.parametrize("algo", ["direct", "winograd", "bf16x3", "bf16x3_lds", "wino1d", "f16x2"])
 def test_g1_cnn14_every_conv_algorithm(hip_model, golden_dir, algo):
     """Every conv kernel family against the reference's attn_emb (bar 2e-4 abs; f32 kernels land at ~5e-6,
     the split-bf16 ones at ~2e-5; the fp16-activation tier "f16x2" has its own bar, 1e-3 = BASELINE.json's
@@ -238,6 +240,36 @@ def test_wav_to_tokens_vs_oracle(hip_model, state4981, conv_tier):
     assert _maxdiff("e2e logit", out["logit"][:, :st], want["logit"][:, :st]) < tol["logit_e2e"]
 
 
+@pytest.mark.parametrize("algo", ["wino1d", "bf16x3", "winograd", "direct"])
+def test_fp32_gate_from_the_oracles_logmel(hip_model, state4981, algo):
+    """SURVEY 8(d)'s fp32 gate end to end on the reference-pinned part of the path: the ORACLE's log-mel through the HIP
+    conv stack -> bi-GRU -> greedy decoding against the oracle from the same log-mel - logits within 1e-4, ids identical
+    (the mel front-end, third-party arithmetic, is held to its own witness in tests/test_gpu_kernels.py)."""
+    from audiocaption_amd import procedural as P
+    from oracle import cpu_path as O
+    wav_len = [320000, 280000, 160000, 300000]
+    wav = P.synthetic_wav(4, 320000, varied=True)
+    for i, n in enumerate(wav_len):
+        wav[i, n:] = 0.0
+    lms = O.logmel(torch.from_numpy(wav), 32000)
+    flen = O.cnn14_feat_len(wav_len)
+    enc_o = O.gru_forward(state4981, O.cnn14_from_logmel(state4981, lms), flen)
+    want = O.greedy_decode(state4981, enc_o["attn_emb"], enc_o["attn_emb_len"], 20)
+    cnn = hip_model.encoder.cnn
+    saved = cnn.conv_algo
+    try:
+        cnn.conv_algo = algo
+        attn, _ = _cnn_from_logmel(cnn, lms.cuda())
+    finally:
+        cnn.conv_algo = saved
+    enc = hip_model.encoder.rnn({"attn": attn, "attn_len": flen})
+    assert _maxdiff(f"attn_emb after the GRU [{algo}]", enc["attn_emb"], enc_o["attn_emb"]) < 1e-4
+    out = hip_model.decoder.greedy(enc["attn_emb"], flen, 20, hip_model.start_idx, hip_model.end_idx, hip_model.pad_idx)
+    st = want["steps"]
+    assert _maxdiff(f"logits from the oracle's log-mel [{algo}]", out["logit"][:, :st], want["logit"][:, :st]) < 1e-4
+    assert torch.equal(out["seq"][:, :st].cpu(), want["seq"][:, :st])
+
+
 def test_cnn14_standalone_fc_emb(hip_model, state4981, conv_tier):
     from audiocaption_amd import procedural as P
     tol = TIER_TOL[conv_tier]["attn_e2e"] * 2   # Cnn14's own 2048-d output (O(2.4)), before the GRU
@@ -298,12 +330,45 @@ def test_forward_async_equals_blocking_forward(hip_model):
     got = [p.result() for p in pend]
     for w, g in zip(want, got):
         assert torch.equal(w["seq"], g["seq"])
-        assert torch.equal(w["logit"], g["logit"]) and torch.equal(w["attn_emb"], g["attn_emb"])
+        assert torch.equal(w["attn_emb"], g["attn_emb"])
+        assert torch.equal(w["logit"], g["logit"])
         assert torch.equal(w["sampled_logprob"], g["sampled_logprob"])
     # the one-workgroup recurrence kernel (gru_algo="single"): another summation order, the same tokens
     for i, g in zip(inputs, got):
         w = hip_model(dict(i, gru_algo="single"))
         assert torch.equal(w["seq"], g["seq"]) and float((w["logit"] - g["logit"]).abs().max()) < 2e-5
+
+
+def test_decode_is_bit_stable_beside_matrix_heavy_kernels(hip_model, state4981):
+    """The greedy decode chain must give the same bits whatever else runs on the GPU: here beside the F(2,3) conv kernel
+    (W = 16: 256-thread workgroups that keep the matrix cores busy at two waves per SIMD) launched back to back on a
+    second stream - the situation of ``forward_async``, where the next batch's encoder runs under this batch's decode.
+    (The per-row decode kernels failed this in ~1 of 3 decodes - csrc/decoder.hip, AUDIOCAPTION_DEC_ROW - which is why
+    the general launch sequence is the default.)"""
+    from audiocaption_amd import kernels as K, procedural as P
+    wav = torch.from_numpy(P.synthetic_wav(3, 48000, seed=1, varied=True)).cuda()
+    enc = hip_model.encoder({"wav": wav, "wav_len": [48000, 40000, 33000], "specaug": False})
+    dec = hip_model.decoder
+    args = (enc["attn_emb"], enc["attn_emb_len"], 8, hip_model.start_idx, hip_model.end_idx, hip_model.pad_idx)
+    for _ in range(3):
+        want = dec.greedy(*args)
+    B, H, Hp, W, Cin, Cout = 16, 250, 256, 16, 128, 256
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(B * Hp, W, Cin, device="cuda", generator=g)
+    wpk = K.pack_conv_weight_wino1d_frag(torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) * 0.03)
+    sc, sh = torch.ones(Cout, device="cuda"), torch.zeros(Cout, device="cuda")
+    out = torch.empty(B * Hp, W, Cout, device="cuda")
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    differing = 0
+    for _ in range(25):
+        with torch.cuda.stream(side):
+            for _ in range(6):
+                K.conv3x3_bn_relu_wino1d(x, wpk, sc, sh, out, B, Hp, H, W, Cin, Cout, 0)
+        got = dec.greedy(*args)
+        torch.cuda.synchronize()
+        differing += int(not (torch.equal(got["logit"], want["logit"]) and torch.equal(got["embed"], want["embed"])))
+    assert differing == 0
 
 
 def test_forward_async_pair_decode_mixed_shapes(hip_model):
@@ -431,7 +496,7 @@ def test_fp16_tier_with_panns_like_statistics(state4981, seed, gains):
     var = st["encoder.cnn.conv_block3.bn1.running_var"]
     assert float(var.max() / var.min()) > 1e3
     model = _model_with_state(st)
-    assert model.encoder.cnn.conv_algo == "f16x2"
+    model.encoder.cnn.conv_algo = "f16x2"
     L = 160000
     wav_len = [L, 120000]                                  # 15 and 11 output frames: the fp16 tier runs
     wav = P.synthetic_wav(2, L, seed=20 + seed, varied=True)
@@ -459,6 +524,7 @@ def test_fp16_range_overflow_is_detected_and_rerouted(state4981):
     from oracle import cpu_path as O
     st = _panns_like_state(state4981, 5, {3: 65536.0})       # block 2's output: O(10) x 2^16
     model = _model_with_state(st)
+    model.encoder.cnn.conv_algo = "f16x2"                     # the opt-in fp16-activation tier
     L = 160000
     wav_len = [L, 120000]
     wav = P.synthetic_wav(2, L, seed=31, varied=True)
@@ -510,14 +576,27 @@ def test_mixed_tier_hands_block6_f32_activations(hip_model, golden_dir):
 
 
 @pytest.mark.parametrize("seconds", [1.0, 2.0, 3.0, 4.0, 6.0, 10.0])
-def test_default_tier_logit_error_by_clip_length(hip_model, state4981, seconds):
-    """Worst logit error of the DEFAULT path (fp16 tier with block 6 on split-bf16; batches with a clip under
-    ``f16x2_min_frames`` frames on the split-bf16 tier) against the CPU oracle over 5 seeds per clip length: <= 5e-4
-    (half of BASELINE.json's 1e-3 bar for half-precision operands), token ids identical."""
+@pytest.mark.parametrize("tier,bar", [("wino1d", 1e-4), ("f16x2", 5e-4)])
+def test_tier_logit_error_by_clip_length(hip_model, state4981, seconds, tier, bar):
+    """Worst logit error against the CPU oracle over 5 seeds per clip length, token ids identical: the DEFAULT tier
+    ("wino1d") inside the fp32 gate (1e-4) at every length; the opt-in fp16 tier (block 6 on split-bf16; batches with a
+    clip under ``f16x2_min_frames`` frames re-routed to split-bf16) <= 5e-4, half of BASELINE.json's half-precision bar."""
     from audiocaption_amd import procedural as P
     from oracle import cpu_path as O
     cnn = hip_model.encoder.cnn
-    assert cnn.conv_algo == "f16x2" and cnn.f16x2_block6 == "bf16x3"
+    assert cnn.f16x2_block6 == "bf16x3"
+    saved = cnn.conv_algo
+    cnn.conv_algo = tier
+    try:
+        worst = _worst_logit_error(hip_model, state4981, seconds)
+    finally:
+        cnn.conv_algo = saved
+    assert worst <= bar
+
+
+def _worst_logit_error(hip_model, state4981, seconds):
+    from audiocaption_amd import procedural as P
+    from oracle import cpu_path as O
     L = int(32000 * seconds)
     lens = [L, int(L * 0.8)]
     worst = 0.0
@@ -533,5 +612,6 @@ def test_default_tier_logit_error_by_clip_length(hip_model, state4981, seconds):
         top2 = want["logit"][:, :stp].topk(2, -1).values
         if float((top2[..., 0] - top2[..., 1]).min()) > 1e-3:
             assert torch.equal(out["seq"][:, :stp], want["seq"][:, :stp])
-    print(f"{seconds} s clips ({want['attn_emb_len'].tolist()} frames): worst |logit diff| over 5 seeds {worst:.2e}")
-    assert worst <= 5e-4
+    print(f"{seconds} s clips ({want['attn_emb_len'].tolist()} frames), tier {hip_model.encoder.cnn.conv_algo}: "
+          f"worst |logit diff| over 5 seeds {worst:.2e}")
+    return worst
