@@ -10,17 +10,21 @@ from the environment; launched plainly with ``--gpus N > 1`` the script re-execu
 collective ("scaling": "weak").  A step is one pass of the hot path (log-mel -> Cnn14 -> bi-GRU -> greedy Transformer
 decoding, token ids back on the host) over one resident batch.  Rank 0 prints ONE JSON line with
 
-* the throughput of the DEFAULT conv tier (``config.precision_gate`` states the parity gate it is held to) over exactly
-  K timed steps, plus ``steady_state`` (>= 2 s of steps: the matrix pipes clock down under sustained MFMA load, which a
-  0.1 s window does not see);
+* ``value``: the throughput of the DEFAULT conv tier - "wino1d", f32-grade: logits within 1e-4 of the fp32 reference,
+  identical token ids (``config.precision_gate``) - over exactly K timed steps that rotate over four resident input
+  batches;
 * ``roofline``: the dominant kernel (conv2 + BN + ReLU + 2x2 pool of blocks 2-5) timed live with HIP events on its
-  launch stream, against the MFMA peak of its operand type;
-* ``tiers``: the same measurement (value, ms_per_step, roofline) for every conv tier - exact f32 (Winograd on the f32
-  MFMA), split-bf16 (f32-grade: logits within 1e-4) and the default fp16 tier - so that whichever precision a reader
-  credits has a number measured in THIS run;
-* ``train_step`` (BASELINE configs[3]) with the roofline of its backward GEMMs and, under ``--mode train``, ``rccl``
-  (the gradient all-reduce timed on its own); ``effb2_trm`` (configs[2]);
-* ``cpu_baseline``: the oracle (CPU restatement of the reference) on the host cores, on a bounded 32-clip sample.
+  launch stream; ``achieved`` = algorithmic direct-convolution FLOPs / time, ``frac`` = MFMA FLOPs actually ISSUED / the
+  dense peak of the pipe they run on (never above 1: Winograd forms issue fewer products than the direct form counts);
+* flat scalars measured in THIS run: ``value_f32_exact`` (Winograd on the f32 MFMA), ``value_bf16x3_direct``,
+  ``value_f16x2_half_precision_gate`` (the opt-in fp16 tier: NOT reference precision), ``value_blocking_model_call`` (the
+  reference's own call, one blocking ``model(input_dict)`` per step), ``latency_b1_greedy_ms`` / ``latency_b1_beam3_ms``
+  (one 10 s clip through ``model()``, what demo.py / the HF surface run), ``train_clips_per_s`` (BASELINE configs[3]),
+  ``effb2_trm_clips_per_s`` (configs[2]);
+* ``cpu_baseline``: the oracle (CPU restatement of the reference) on all physical host cores, median of 5 passes over a
+  bounded 32-clip sample.
+The per-tier rooflines, the steady-state window, the decoder GEMM table, the training-step and EffB2 objects go to
+``gpurun_out/bench_details.json`` (``details_file``) so that the printed line stays short.
 """
 import argparse
 import json
@@ -45,6 +49,13 @@ HBM_PEAK_GBS = 8000.0
 # 36 products per tile; the split-bf16 path issues three bf16 products per f32 product (hi*hi, hi*lo, lo*hi); the fp16
 # tier two (x16*w_hi, x16*w_lo)
 TIERS = {
+    "wino1d": {"conv_algo": "wino1d", "linear_algo": "bf16x3", "issue_ratio": 2.0, "peak": BF16_MFMA_PEAK_TFLOPS,
+               "dtype": "bf16x3",
+               "kernel": "conv3x3_w1_kernel<POOL> (F(2,3) Winograd along time on split-bf16 operands: 12 transformed "
+                         "products x 3 bf16 MFMAs per 18 direct f32 products, f32 accumulate)",
+               "gate": "f32 gate: logits within 1e-4 of the fp32 CPU reference, identical token ids (measured 4e-5; split-bf16 "
+                       "operands carry 16 significant bits, activations stay f32 in HBM, f32 accumulation) - asserted end "
+                       "to end by tests/test_gpu_model.py"},
     "f32": {"conv_algo": "winograd", "linear_algo": "f32", "issue_ratio": 1.0 / 2.25, "peak": FP32_MFMA_PEAK_TFLOPS,
             "dtype": "f32", "kernel": "conv3x3_wino_kernel<POOL> (Winograd F(2x2,3x3), v_mfma_f32_32x32x2_f32)",
             "gate": "f32 end to end: logits within 1e-4 of the fp32 CPU reference, identical token ids (measured 4e-6)"},
@@ -60,7 +71,8 @@ TIERS = {
                       "the fp32 CPU reference (worst measured over 5 seeds x 6 clip lengths: "
                       "tests/test_gpu_model.py::test_default_tier_logit_error_by_clip_length, bar 5e-4)"},
 }
-ALGO_TO_TIER = {"winograd": "f32", "direct": "f32", "bf16x3": "bf16x3", "bf16x3_lds": "bf16x3", "f16x2": "f16x2"}
+ALGO_TO_TIER = {"winograd": "f32", "direct": "f32", "bf16x3": "bf16x3", "bf16x3_lds": "bf16x3", "f16x2": "f16x2",
+                "wino1d": "wino1d"}
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -277,14 +289,14 @@ def bench_train(args, ranks, steps, warmup, with_rccl=False):
                            "kernels)" if split else "gemm_general / gemm_nt / gemm_kk (ac_gemm, exact f32 v_mfma_f32_32x32x2_f32)")
                           + f": the {len(bwd)} dgrad + wgrad launches of one backward pass",
                 "achieved": fl_b / ms_b / 1e9, "peak": peak, "unit": "TFLOP/s",
-                "frac": fl_b / ms_b / 1e9 / peak, "mfma_issue_frac": fl_b / ms_b / 1e9 * (3.0 if split else 1.0) / peak,
-                "frac_of_f32_mfma_peak": fl_b / ms_b / 1e9 / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                "frac": fl_b / ms_b / 1e9 * (3.0 if split else 1.0) / peak, "algorithmic_frac": fl_b / ms_b / 1e9 / peak,
+                "issued_per_algorithmic": 3.0 if split else 1.0, "traffic": None,
                 "gemm_ms_per_step": ms_b, "gflop_per_step": fl_b / 1e9, "launches": len(bwd),
                 "largest": {"M": big[1]["M"], "N": big[1]["N"], "K": big[1]["K"], "ms": big[0],
                             "tflops": big[1]["flops"] / big[0] / 1e9},
                 "forward_gemms": {"achieved": fl_f / ms_f / 1e9 if ms_f > 0 else None, "gemm_ms_per_step": ms_f,
                                   "gflop_per_step": fl_f / 1e9, "launches": len(fwd),
-                                  "frac_of_f32_mfma_peak": fl_f / ms_f / 1e9 / FP32_MFMA_PEAK_TFLOPS if ms_f > 0 else None,
+                                  "frac": fl_f / ms_f / 1e9 * (3.0 if split else 1.0) / peak if ms_f > 0 else None,
                                   "note": "all decoder passes teacher forced as one batch + the free-running passes re-run"},
                 "note": "HIP events around every ac_gemm of one eager iteration (the timed steps replay a HIP graph)"}
     except Exception as e:  # noqa: BLE001 - a secondary measurement never costs the line
@@ -298,7 +310,8 @@ def bench_train(args, ranks, steps, warmup, with_rccl=False):
         "metric": "clips/sec trained (forward+backward+Adam), Cnn14_Rnn-Trm, AudioCaps-shape batches",
         "value": world * B * steps / elapsed, "unit": "clips/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16x3 frozen convolutions and large GEMMs (split-bf16 operands, f32 accumulation), f32 elsewhere"
+        "dtype": "bf16x3 (frozen convolutions: F(2,3) Winograd on split-bf16 operands; large GEMMs on split-bf16 operands; f32 "
+                 "accumulation, f32 elsewhere)"
                  if engine.gemm_algo in ("bf16x3", "pw") else "bf16x3 frozen convolutions, f32 everything trained",
         "data": "synthetic",
         "config": {"workload": f"training step, batch {B} per GPU ({world * B} global), {args.seconds:g} s @ 32 kHz clips, "
@@ -402,7 +415,7 @@ def bench_effb2(args, ranks, steps, warmup):
     enc_ms = e0.elapsed_time(e1) / 3
     alg_bytes = 100e6 * (args.seconds / 10.0) * B
     traffic, tsrc = None, None
-    for name in ("r02_traffic_effb2.json", "r01_traffic_effb2.json"):
+    for name in ("r03_traffic_effb2.json", "r02_traffic_effb2.json", "r01_traffic_effb2.json"):
         tpath = os.path.join(REPO, "profiles", name)
         if os.path.exists(tpath) and args.seconds == 10.0:
             with open(tpath) as f:   # PMC-measured HBM bytes per clip (collected in separate --pmc passes), scaled to B
@@ -425,8 +438,9 @@ def bench_effb2(args, ranks, steps, warmup):
                                + (f"beam search (beam {args.beam})" if args.beam > 0 else "greedy")
                                + f", max_length {args.max_length}, vocab {vocab} (BASELINE configs[2]; configs[4] with "
                                  "--seconds 30 --beam 4 --gpus 8)",
-                   "global_batch": world * B, "parity": "unpinned (efficientnet_pytorch / torchaudio are not vendored by "
-                   "the reference): checked against oracle/effb2_path.py",
+                   "global_batch": world * B, "parity": "efficientnet_pytorch / torchaudio are not vendored by the reference: "
+                   "HIP path and oracle/effb2_path.py are held to transformers.EfficientNetModel / audio_utils witnesses "
+                   "(tests/golden/g10_logmel.npz, g11_effb2.npz)",
                    "sharding": f"clips sharded over {world} rank(s), no data-path collective",
                    "schedule": "blocking model() per step" if getattr(args, "sync_steps", False) else
                                "forward_async: encoders on one HIP stream, the beam searches on a second one under the "
@@ -512,57 +526,55 @@ def _decoder_rooflines(model, dev, B, vocab, max_length):
                         "mfma_frac": step_flops / (step_us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                         "note": "one KV-cached greedy step over the whole batch, from the replayed HIP graph: a dependent "
                                 "chain of small kernels; neither HBM nor the matrix cores are the limit at 64 rows"},
-        "teacher_forced_gemms": {"bound": "mfma", "rows": M, "achieved": tot_flops / tot_us / 1e6, "peak": FP32_MFMA_PEAK_TFLOPS,
-                                 "unit": "TFLOP/s", "frac": tot_flops / tot_us / 1e6 / FP32_MFMA_PEAK_TFLOPS, "dtype": "bf16x3",
-                                 "mfma_issue_frac_of_bf16_peak": 3.0 * tot_flops / tot_us / 1e6 / BF16_MFMA_PEAK_TFLOPS,
-                                 "exact_f32": {"achieved": tot_flops / tot_us_f32 / 1e6,
-                                               "frac": tot_flops / tot_us_f32 / 1e6 / FP32_MFMA_PEAK_TFLOPS},
-                                 "per_gemm": rows,
-                                 "all_passes_batched": {
-                                     "rows": B * 231, "achieved": tf_all[1] / tf_all[2] / 1e6,
-                                     "frac": tf_all[1] / tf_all[2] / 1e6 / FP32_MFMA_PEAK_TFLOPS,
-                                     "mfma_issue_frac_of_bf16_peak": 3.0 * tf_all[1] / tf_all[2] / 1e6 / BF16_MFMA_PEAK_TFLOPS,
-                                     "exact_f32_frac": tf_all[1] / tf_all[3] / 1e6 / FP32_MFMA_PEAK_TFLOPS, "per_gemm": tf_all[0],
-                                     "note": "the same layer GEMMs at the row count the training step really launches them "
-                                             "with: every one of the 21 prefix passes of scheduled sampling teacher forced as "
-                                             "ONE batch (TrainEngine._decoder_passes), 231 rows per clip; layer GEMMs only - the "
-                                             "classifier sees the last position of each pass (the B x 21 rows above)"},
-                                 "note": "ALGORITHMIC f32 FLOPs of the decoder's layer GEMMs at M = batch x 21 caption "
-                                         "positions (layer GEMMs weighted x2 layers) over the time of ac_pw_gemm_bf16x3 - "
-                                         "the kernel the training step's x W^T / dy W products run on: split-bf16 "
-                                         "operands, three bf16 MFMAs per product, f32 accumulation - against the f32 MFMA "
-                                         "peak (there is no TF32 on gfx950: this is the rate an exact-f32 decoder could "
-                                         "reach); exact_f32 = the same shapes on ac_gemm (v_mfma_f32_32x32x2_f32)"},
+        # One convention (as for the conv kernels): achieved = algorithmic f32 FLOPs / time; frac = MFMA FLOPs ISSUED / the
+        # dense peak of the pipe the kernel runs on - ac_pw_gemm_bf16x3 issues three bf16 products per f32 product on the
+        # bf16 pipe (2.5 PFLOP/s), ac_gemm one f32 product on the f32 pipe (157.3 TFLOP/s).
+        "teacher_forced_gemms": {
+            "bound": "mfma", "rows": M, "kernel": "pw_bf16x3_kernel (ac_pw_gemm_bf16x3: the training step's x W^T / dy W kernel)",
+            "achieved": tot_flops / tot_us / 1e6, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": 3.0 * tot_flops / tot_us / 1e6 / BF16_MFMA_PEAK_TFLOPS, "issued_per_algorithmic": 3.0, "dtype": "bf16x3",
+            "exact_f32": {"kernel": "ac_gemm (v_mfma_f32_32x32x2_f32)", "achieved": tot_flops / tot_us_f32 / 1e6,
+                          "peak": FP32_MFMA_PEAK_TFLOPS, "frac": tot_flops / tot_us_f32 / 1e6 / FP32_MFMA_PEAK_TFLOPS},
+            "per_gemm": rows,
+            "all_passes_batched": {
+                "rows": B * 231, "achieved": tf_all[1] / tf_all[2] / 1e6, "peak": BF16_MFMA_PEAK_TFLOPS,
+                "frac": 3.0 * tf_all[1] / tf_all[2] / 1e6 / BF16_MFMA_PEAK_TFLOPS,
+                "exact_f32": {"achieved": tf_all[1] / tf_all[3] / 1e6, "peak": FP32_MFMA_PEAK_TFLOPS,
+                              "frac": tf_all[1] / tf_all[3] / 1e6 / FP32_MFMA_PEAK_TFLOPS},
+                "per_gemm": tf_all[0],
+                "note": "the same layer GEMMs at the row count the training step really launches them with: every one of "
+                        "the 21 prefix passes of scheduled sampling teacher forced as ONE batch "
+                        "(TrainEngine._decoder_passes), 231 rows per clip; layer GEMMs only - the classifier sees the last "
+                        "position of each pass (the B x 21 rows above)"},
+            "note": "ALGORITHMIC f32 FLOPs of the decoder's layer GEMMs at M = batch x 21 caption positions (layer GEMMs "
+                    "weighted x2 layers) over kernel time"},
     }
 
 
 # ---------------------------------------------------------------------------------------------------------------------
 # headline: Cnn14Rnn-Trm greedy inference (BASELINE configs[1])
 # ---------------------------------------------------------------------------------------------------------------------
-def conv_roofline(tier, events, note_extra=""):
-    """Roofline object of the dominant conv kernel from the HIP events the launch hook collected."""
+def conv_roofline(tier, events):
+    """Roofline object of the dominant conv kernel from the HIP events the launch hook collected.  One convention for every
+    tier: ``achieved`` = ALGORITHMIC direct-convolution f32 FLOPs / kernel time; ``frac`` = MFMA FLOPs actually issued
+    (achieved x the tier's products per direct product) / the dense peak of the pipe they run on."""
     t = TIERS[tier]
     flops = sum(2.0 * 9 * i["Cin"] * i["Cout"] * i["H"] * i["W"] * i["B"] for _, _, i in events)
     ms = sum(s.elapsed_time(e) for s, e, _ in events)
     n = len(events)
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     traffic, tsrc = None, None
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         tpath = os.path.join(REPO, "profiles", f"{rnd}_traffic_{t['conv_algo']}.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch")
-            tsrc = (f"profiles/{rnd}_traffic_{t['conv_algo']}.json (rocprofv3 --pmc passes of the same command; "
-                    "not measured in this run)")
+            tsrc = f"profiles/{rnd}_traffic_{t['conv_algo']}.json (separate rocprofv3 --pmc passes, not this run)"
             break
-    return {"bound": "mfma", "achieved": achieved, "peak": t["peak"], "unit": "TFLOP/s", "frac": achieved / t["peak"],
-            "traffic": traffic, "traffic_source": tsrc,
-            "kernel": t["kernel"] + " (conv2+BN+ReLU+pool of blocks 2-5)",
-            "note": "achieved = ALGORITHMIC direct-convolution f32 FLOPs / kernel time (HIP events on the launch stream inside "
-                    "the timed steps); mfma_issue_frac = MFMA FLOPs actually issued (x%.3g) / the MFMA peak of the "
-                    "operand type" % t["issue_ratio"] + note_extra,
-            "mfma_issue_frac": achieved * t["issue_ratio"] / t["peak"], "launches_timed": n,
-            "avg_launch_ms": ms / n if n else None,
+    return {"bound": "mfma", "achieved": achieved, "peak": t["peak"], "unit": "TFLOP/s",
+            "frac": achieved * t["issue_ratio"] / t["peak"], "algorithmic_frac": achieved / t["peak"],
+            "issued_per_algorithmic": t["issue_ratio"], "traffic": traffic, "traffic_source": tsrc,
+            "kernel": t["kernel"], "launches_timed": n, "avg_launch_ms": ms / n if n else None,
             "algorithmic_gflop_per_launch": flops / n / 1e9 if n else None}
 
 
@@ -581,7 +593,7 @@ def main():
     ap.add_argument("--steady-seconds", type=float, default=2.0, help="length of the steady-state window")
     ap.add_argument("--sync-steps", action="store_true", help="blocking model(input_dict) per step (no overlap)")
     ap.add_argument("--cpu-clips", type=int, default=32, help="clips per CPU-baseline pass")
-    ap.add_argument("--cpu-reps", type=int, default=2)
+    ap.add_argument("--cpu-reps", type=int, default=5)
     ap.add_argument("--mode", choices=["infer", "train", "effb2"], default="infer",
                     help="train: the JSON line is the TRAINING step (BASELINE configs[3]: forward + backward + Adam, "
                          "gradients all-reduced over RCCL when N > 1); effb2: EffB2-Transformer inference "
@@ -637,6 +649,8 @@ def main():
     L = int(args.seconds * 32000)
     B = args.batch
     audio_seconds = args.seconds * B
+    NROT = 4   # resident input batches the timed steps rotate over (4 x 82 MB at the default shape: beyond the 256 MiB
+    #            Infinity Cache, so no step finds its waveform on chip)
     if args.clotho_shape:
         # the same global set on every rank (seeded), dealt out by total duration: encoder cost ~ duration
         import numpy as np
@@ -647,27 +661,30 @@ def main():
         B = len(mine)
         wav_len = [int(dur[i] * 32000) for i in mine]
         L = max(wav_len)
-        full = P.synthetic_wav(B, L, seed=P.BASE_SEED + rank)
-        for j, n in enumerate(wav_len):
-            full[j, n:] = 0.0
-        wav = torch.from_numpy(full).to(dev)
+        wavs = []
+        for k in range(NROT):
+            full = P.synthetic_wav(B, L, seed=P.BASE_SEED + rank + 1000 * k)
+            for j, n in enumerate(wav_len):
+                full[j, n:] = 0.0
+            wavs.append(torch.from_numpy(full).to(dev))
         audio_seconds = float(sum(wav_len)) / 32000.0
     else:
-        wav = torch.from_numpy(P.synthetic_wav(B, L, seed=P.BASE_SEED + rank)).to(dev)  # resident in HBM
+        wavs = [torch.from_numpy(P.synthetic_wav(B, L, seed=P.BASE_SEED + rank + 1000 * k)).to(dev) for k in range(NROT)]
         wav_len = [L] * B
-    inp = {"mode": "inference", "wav": wav, "wav_len": wav_len, "specaug": False, "sample_method": "greedy",
-           "max_length": args.max_length}
+    inputs = [{"mode": "inference", "wav": w_, "wav_len": wav_len, "specaug": False, "sample_method": "greedy",
+               "max_length": args.max_length} for w_ in wavs]
+    wav = wavs[0]
 
-    def run_steps(n):
-        """n passes of the hot path.  Default: throughput mode (forward_async: the encoder of step i+1
-        overlaps the latency-bound decode of step i on a second stream; every step is fully processed and its
-        token ids are on the host before the timed region ends).  --sync-steps: one blocking model() per step."""
-        if args.sync_steps:
+    def run_steps(n, sync=None):
+        """n passes of the hot path over the rotating resident batches.  Default: throughput mode (forward_async: the
+        encoder of step i+1 overlaps the latency-bound decode of step i on a second stream; every step is fully processed
+        and its token ids are on the host before the timed region ends).  sync: one blocking model() per step."""
+        if args.sync_steps if sync is None else sync:
             last = None
-            for _ in range(n):
-                last = model(dict(inp))
+            for i in range(n):
+                last = model(dict(inputs[i % NROT]))
             return last
-        pend = [model.forward_async(dict(inp)) for _ in range(n)]
+        pend = [model.forward_async(dict(inputs[i % NROT])) for i in range(n)]
         last = None
         for p_ in pend:
             last = p_.result()
@@ -678,13 +695,13 @@ def main():
     default_tier = ALGO_TO_TIER[default_algo]
     linear_algo = K.LINEAR_ALGO
 
-    def measure(tier, steps, warmup):
+    def measure(tier, steps, warmup, sync=None):
         """K timed steps of one conv tier with HIP events around every launch of its dominant kernel."""
         cnn.conv_algo = TIERS[tier]["conv_algo"] if tier != default_tier else default_algo
         K.LINEAR_ALGO = "f32" if tier == "f32" else linear_algo   # the exact-f32 tier: f32 GEMMs as well
         try:
             if warmup:
-                run_steps(warmup)
+                run_steps(warmup, sync)
             events = []
 
             def hook(phase, info):
@@ -699,7 +716,7 @@ def main():
 
             K.CONV_LAUNCH_HOOK = hook
             try:
-                elapsed, out = timed_steps(ranks, run_steps, steps)
+                elapsed, out = timed_steps(ranks, lambda n: run_steps(n, sync), steps)
             finally:
                 K.CONV_LAUNCH_HOOK = None
             return elapsed, out, events
@@ -734,7 +751,7 @@ def main():
     # ---- the other conv tiers, same hook, same schedule ----
     extra = {}
     if not args.no_tiers:
-        for tier in ("f32", "bf16x3", "f16x2"):
+        for tier in ("f32", "bf16x3", "f16x2", "wino1d"):
             if tier in tiers:
                 continue
             n_t = max(5, args.steps // 2)
@@ -746,17 +763,46 @@ def main():
             except Exception as e:  # noqa: BLE001
                 tiers[tier] = {"error": f"{type(e).__name__}: {e}"}
 
+    # ---- the reference's own call: one blocking model(input_dict) per step (run.py:45,51; base.py:212-224) ----
+    blocking = None
+    try:
+        n_b = max(5, args.steps // 2)
+        b_el, _, _ = measure(default_tier, n_b, 2, sync=True)
+        blocking = {"value": world * B * n_b / b_el, "unit": "clips/s", "ms_per_step": b_el / n_b * 1e3, "steps": n_b}
+    except Exception as e:  # noqa: BLE001
+        blocking = {"error": f"{type(e).__name__}: {e}"}
+
+    # ---- batch-1 latency of the blocking call: what demo.py / the HF surface model(audio, audio_length) run ----
+    latency = {}
+    try:
+        one = {"mode": "inference", "wav": wavs[0][:1].contiguous(), "wav_len": wav_len[:1], "specaug": False,
+               "max_length": args.max_length}
+        for name, kw in (("greedy", {"sample_method": "greedy"}), ("beam3", {"sample_method": "beam", "beam_size": 3})):
+            for _ in range(3):
+                model(dict(one, **kw))
+            ts = []
+            for _ in range(10):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                o1 = model(dict(one, **kw))
+                _ = o1["seq"].cpu()
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            latency[name] = sorted(ts)[len(ts) // 2]
+    except Exception as e:  # noqa: BLE001
+        latency["error"] = f"{type(e).__name__}: {e}"
+
     # the log-mel kernel on its own: HBM-bound (1.54 MB per 10 s clip: waveform in, log-mel out)
     m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     pk = cnn._pack(dev)
     hp0 = cnn.geometry(L)[2][0]
     K.logmel(wav, cnn._tables, pk["bn0"][0], pk["bn0"][1], rows_per_clip=hp0, channels_last=True)
     m0.record()
-    for _ in range(10):
-        K.logmel(wav, cnn._tables, pk["bn0"][0], pk["bn0"][1], rows_per_clip=hp0, channels_last=True)
+    for i in range(12):
+        K.logmel(wavs[i % NROT], cnn._tables, pk["bn0"][0], pk["bn0"][1], rows_per_clip=hp0, channels_last=True)
     m1.record()
     torch.cuda.synchronize()
-    mel_ms = m0.elapsed_time(m1) / 10
+    mel_ms = m0.elapsed_time(m1) / 12
     mel_bytes = 1.54e6 * (args.seconds / 10.0) * B
     extra["mel_roofline"] = {"bound": "hbm", "achieved": mel_bytes / (mel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": mel_bytes / (mel_ms * 1e-3) / 8e12, "traffic": None, "kernel": "logmel_kernel<1024>",
@@ -766,7 +812,7 @@ def main():
                                      "HBM bound"}
     # the decoder's dense GEMMs.  One cached decode step is a latency chain over ~12 MB of
     # weights (no matrix-bound regime exists at 64 rows); the "MFMA utilisation on the decoder GEMMs" figure is only
-    # meaningful on the teacher-forced training shape (M = B x 21 rows), measured here on the training GEMM (ac_gemm).
+    # meaningful on the teacher-forced training shape (M = B x 21 rows), measured here on the training step's GEMM kernels.
     try:
         extra["decoder_roofline"] = _decoder_rooflines(model, dev, B, vocab, args.max_length)
     except Exception as e:  # secondary measurement: never lose the headline line over it
@@ -788,10 +834,9 @@ def main():
                                                       "encoder_roofline")}
         except Exception as e:  # noqa: BLE001
             extra["effb2_trm"] = {"error": f"{type(e).__name__}: {e}"}
-    result = None
     if rank == 0:
         clips = world * B * args.steps
-        mixed = default_algo == "f16x2" and getattr(cnn, "f16x2_block6", "f16x2") == "bf16x3"
+        val = lambda d_, k="value": (d_ or {}).get(k) if isinstance(d_, dict) else None
         result = {
             "metric": "clips/sec (10 s @ 32 kHz) encode+greedy-decode, Cnn14_Rnn-Trm",
             "value": clips / elapsed,
@@ -808,43 +853,52 @@ def main():
             "config": {"workload": f"Cnn14Rnn-Trm greedy decode, batch {B} per GPU, {args.seconds:g} s @ 32 kHz "
                                    f"synthetic clips, max_length {args.max_length}, vocab {vocab} (BASELINE configs[1])",
                        "global_batch": world * B, "decode_steps_executed": args.max_length,
+                       "decode_steps_reference_would_run": ref_steps, "conv_algo": default_algo,
                        "input_set": ("Clotho-shape: ragged 15-30 s clips, zero-padded, duration-balanced sharding; "
                                      "%.0f s of audio per step on rank 0" % audio_seconds) if args.clotho_shape else
-                                    "fixed-length",
-                       "decode_steps_reference_would_run": ref_steps, "conv_algo": default_algo,
-                       "precision_gate": TIERS[default_tier]["gate"],
+                                    f"fixed-length, {NROT} resident batches in rotation",
+                       "precision_gate": "logits within 1e-4 of the fp32 CPU reference, identical token ids"
+                                         if default_tier != "f16x2" else "HALF-PRECISION gate only: logits within 1e-3",
+                       "precision": {
+                           "wino1d": "f32 activations in HBM; 3x3 convolutions as F(2,3) Winograd along time on split-bf16 "
+                                     "operands (x = hi + lo, hi*hi + hi*lo + lo*hi, f32 accumulate: 2^-16 operand error), "
+                                     "GRU input projections on split-bf16 operands, everything else f32",
+                           "bf16x3": "f32 activations; direct 3x3 convolutions on split-bf16 operands (2^-16), f32 accumulate",
+                           "f32": "f32 end to end (Winograd F(2x2,3x3) on the f32 MFMA)",
+                           "f16x2": "fp16 activations in HBM, fp16 hi+lo weights: NOT reference precision (logits within "
+                                    "1e-3); batches with a clip under 3.2 s or an fp16 overflow re-run on bf16x3"}[default_tier],
                        "sharding": f"clips sharded over {world} rank(s), no data-path collective",
                        "schedule": "blocking model() per step" if args.sync_steps else
-                                   "forward_async: encoders on one HIP stream, the decode chain of step i on a second one under "
-                                   "the encoder of step i+1"},
-            "roofline": headline_roof,
-            "steady_state": steady,
-            "tiers": tiers,
+                                   "forward_async: encoder of step i+1 under the decode chain of step i (two HIP streams)"},
+            "roofline": {k: headline_roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "algorithmic_frac",
+                                                       "issued_per_algorithmic", "traffic", "avg_launch_ms", "launches_timed",
+                                                       "kernel")},
+            # flat scalars, all measured in this run
+            "value_f32_exact": val(tiers.get("f32")),
+            "value_bf16x3_direct": val(tiers.get("bf16x3")),
+            "value_f16x2_half_precision_gate": val(tiers.get("f16x2")),
+            "value_wino1d": val(tiers.get("wino1d")),
+            "value_blocking_model_call": val(blocking),
+            "ms_blocking_model_call": val(blocking, "ms_per_step"),
+            "latency_b1_greedy_ms": latency.get("greedy"),
+            "latency_b1_beam3_ms": latency.get("beam3"),
+            "steady_state_value": val(steady),
+            "train_clips_per_s": val(extra.get("train_step")),
+            "train_ms_per_step": val(extra.get("train_step"), "ms_per_step"),
+            "effb2_trm_clips_per_s": val(extra.get("effb2_trm")),
+            "logmel_hbm_frac": extra["mel_roofline"]["frac"],
         }
-        result["config"]["precision"] = {
-            "f16x2": "convolutions of blocks 1-5 on fp16 MFMA with f32 accumulation: activations rounded once to fp16 (RNE, "
-                     "2^-12 relative; they live in HBM as fp16), weights as fp16 hi + lo (2^-22), two products per f32 "
-                     "product; " + ("conv_block6 (K = 9216 / 18432: half of the tier's logit error) on split-bf16 operands "
-                                    "with f32 activations; " if mixed else "") +
-                     "the GRU input projections on split-bf16 operands (2^-16); everything else f32.  Values beyond the "
-                     "fp16 range raise a device flag and the batch is re-run on the split-bf16 tier; batches with a clip "
-                     "under 2.6 s run there as well.  AUDIOCAPTION_CONV_ALGO=bf16x3 is the f32-grade tier (logits within "
-                     "3e-5), =winograd exact f32 - both measured in `tiers`",
-            "bf16x3": "split-bf16 convolutions (x = hi + lo, hi*hi + hi*lo + lo*hi, f32 accumulate: 2^-16 relative "
-                      "operand error), everything else f32; parity: identical greedy/beam token ids, logits within "
-                      "3e-5 of the reference on the golden fixtures",
-            "f32": "f32 end to end"}[default_tier]
-        result["rooflines_other"] = {"logmel": extra["mel_roofline"], "decoder": extra["decoder_roofline"]}
-        if "train_step" in extra:
-            result["train_step"] = extra["train_step"]
-        if "effb2_trm" in extra:
-            result["effb2_trm"] = extra["effb2_trm"]
+        details = {"tiers": tiers, "steady_state": steady, "blocking_model_call": blocking, "latency_b1_ms": latency,
+                   "rooflines_other": {"logmel": extra["mel_roofline"], "decoder": extra["decoder_roofline"]},
+                   "train_step": extra.get("train_step"), "effb2_trm": extra.get("effb2_trm")}
         if not args.no_cpu_baseline and world == 1:
             try:
                 from oracle import cpu_path as O  # the CPU restatement, timed as a reported baseline only
+                phys = _physical_cores()
+                torch.set_num_threads(phys)
                 nc = args.cpu_clips
                 cwav = torch.from_numpy(P.synthetic_wav(max(nc, 1), L)[:nc])
-                O.caption_forward(state, cwav[:1], [L], "greedy", max_length=args.max_length, force_steps=True)
+                O.caption_forward(state, cwav[:2], [L] * 2, "greedy", max_length=args.max_length, force_steps=True)   # warm-up
                 t_enc, t_dec = [], []
                 for _ in range(args.cpu_reps):   # encode and decode timed separately
                     c0 = time.perf_counter()
@@ -855,19 +909,43 @@ def main():
                     c2 = time.perf_counter()
                     t_enc.append(c1 - c0)
                     t_dec.append(c2 - c1)
-                me, md = min(t_enc), min(t_dec)
+                med = lambda v: sorted(v)[len(v) // 2]
+                me, md = med(t_enc), med(t_dec)
                 result["cpu_baseline"] = {
-                    "value": nc / (me + md), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
-                    "encode_clips_per_s": nc / me, "decode_clips_per_s": nc / md,
-                    "host_cpu_count": os.cpu_count(), "torch": torch.__version__,
-                    "sample": f"oracle/cpu_path.py (fp32 torch CPU ops): log-mel + Cnn14 + bi-GRU, then greedy decoding that "
-                              f"re-runs the decoder on the whole prefix for {args.max_length} steps like the reference; ONE "
-                              f"batch of {nc} clips x {args.seconds:g} s per pass, best of {args.cpu_reps} passes after a "
-                              f"1-clip warm-up"}
+                    "value": nc / (me + md), "unit": "clips/s", "cores": phys, "kind": "port",
+                    "encode_clips_per_s": nc / me, "decode_clips_per_s": nc / md, "host_cpu_count": os.cpu_count(),
+                    "sample": f"oracle/cpu_path.py (fp32 torch {torch.__version__} CPU ops) on all {phys} physical cores: log-mel "
+                              f"+ Cnn14 + bi-GRU, then greedy decoding that re-runs the decoder on the whole prefix for "
+                              f"{args.max_length} steps like the reference; one batch of {nc} clips x {args.seconds:g} s per "
+                              f"pass, median of {args.cpu_reps} passes after a warm-up pass"}
             except Exception as e:  # noqa: BLE001
                 result["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+        try:
+            os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+            dpath = os.path.join(REPO, "gpurun_out", "bench_details.json")
+            with open(dpath, "w") as f:
+                json.dump({"line": result, "details": details}, f, indent=1)
+            result["details_file"] = "gpurun_out/bench_details.json (per-tier rooflines, steady state, decoder GEMMs, train_step, effb2_trm)"
+        except OSError:
+            pass
         print(json.dumps(result), flush=True)
     ranks.finish()
+
+
+def _physical_cores():
+    """Physical cores of the host (SMT siblings counted once); falls back to os.cpu_count()."""
+    try:
+        seen = set()
+        for cpu in os.listdir("/sys/devices/system/cpu"):
+            tp = os.path.join("/sys/devices/system/cpu", cpu, "topology")
+            if cpu.startswith("cpu") and cpu[3:].isdigit() and os.path.isdir(tp):
+                with open(os.path.join(tp, "physical_package_id")) as f1, open(os.path.join(tp, "core_id")) as f2:
+                    seen.add((f1.read().strip(), f2.read().strip()))
+        if seen:
+            return len(seen)
+    except OSError:
+        pass
+    return os.cpu_count() or 1
 
 
 if __name__ == "__main__":
