@@ -712,12 +712,13 @@ def test_replayed_graph_after_a_buffer_regrow_equals_the_eager_step(train_model)
     small, big = batch(96000, 6, 2), batch(256000, 8, 4)
     eager = float(eng.step(small, opt, use_graph=False)["loss"])
     cnn = model.encoder.cnn
-    pack_id = id(cnn._packed["bf16x3"][1])
+    tier = cnn.effective_algo(None, True)                               # the conv tier of the train-mode forward
+    pack_id = id(cnn._packed[tier][1])
     ptr_small = cnn._bufs[("full", torch.float32)].data_ptr()
     vals = [float(eng.step(small, opt)["loss"]) for _ in range(3)]     # eager (first of the shape), capture, replay
     st_small = eng._states[next(k for k in eng._states if k[1] == 2)]
     assert "fwd0" in st_small["graphs"] and "tail" in st_small["graphs"]
-    assert id(cnn._packed["bf16x3"][1]) == pack_id                      # optimiser steps do not repack the frozen Cnn14
+    assert id(cnn._packed[tier][1]) == pack_id                      # optimiser steps do not repack the frozen Cnn14
     big_eager = float(eng.step(big, opt, use_graph=False)["loss"])      # larger shape: shared buffers re-allocated
     assert cnn._bufs[("full", torch.float32)].data_ptr() != ptr_small or cnn._bufs[("full", torch.float32)].numel() > 0
     filler = torch.full((int(1e8),), 3.0, device="cuda")                # recycle the freed blocks
