@@ -145,6 +145,27 @@ def decoder_state(prefix="", vocab_size=4368, d_model=256, attn_emb_dim=512, nla
     return out
 
 
+# A second, HIGH-ENTROPY decoder draw for the decode fixtures g4b / g5b (tests/golden/make_golden.py): larger token
+# embeddings and positional encodings make the next token depend on the whole prefix (few repeated tokens, clips and beams
+# that differ), a larger <end> logit makes beams finish early while others continue (the -1000 path of base.py:317), and
+# closely ranked candidates make the parent beam change at most steps (prev_beam != identity: the KV-cache re-gather).
+DIVERSE = {"greedy": {"seed": 325, "emb_scale": 3.0, "pe_scale": 4.0, "end_beta": 3.0},
+           "beam": {"seed": 255, "emb_scale": 2.0, "pe_scale": 2.0, "end_beta": 3.0}}
+
+
+def decoder_state_diverse(kind, prefix="decoder.", vocab_size=4981):
+    """``decoder_state`` re-drawn with the DIVERSE[kind] seed and scales (kind: "greedy" | "beam")."""
+    c = DIVERSE[kind]
+    d = decoder_state(prefix, vocab_size, seed=c["seed"])
+    d[prefix + "word_embedding.weight"] = d[prefix + "word_embedding.weight"] * np.float32(c["emb_scale"])
+    d[prefix + "pos_encoder.pe"] = d[prefix + "pos_encoder.pe"] * np.float32(c["pe_scale"])
+    b3 = d[f"{prefix}model.layers.1.norm3.bias"]
+    cw = d[prefix + "classifier.weight"].copy()
+    cw[2] = ((c["end_beta"] / float(np.dot(b3, b3))) * b3).astype(np.float32)
+    d[prefix + "classifier.weight"] = cw
+    return d
+
+
 def cnn14rnn_trm_state(vocab_size=4368, seed=BASE_SEED):
     """Full state dict of the Cnn14Rnn-Trm captioner."""
     out = {}

@@ -287,9 +287,10 @@ def greedy_decode(state, attn_emb, attn_emb_len, max_length=20, prefix="decoder.
 # beam search (base.py:254-361, transformer_model.py:59-86)
 # ----------------------------------------------------------------------------------------
 def beam_search(state, attn_emb, attn_emb_len, beam_size=3, max_length=20, temp=1.0, prefix="decoder.",
-                start_idx=START_IDX, end_idx=END_IDX, pad_idx=PAD_IDX, n_best=False, n_best_size=None):
+                start_idx=START_IDX, end_idx=END_IDX, pad_idx=PAD_IDX, n_best=False, n_best_size=None, trace=None):
     """base.py:254-361.  n_best: "seq" is (B, n_best_size, max_length), the finished beams of a clip by descending
-    length-normalised score (base.py:258-263,354-358)."""
+    length-normalised score (base.py:258-263,354-358).  trace (a list, fixtures only): receives one record per (clip,
+    step) - the parent beam of every kept candidate and which of them ended."""
     B = attn_emb.shape[0]
     n_best_size = beam_size if n_best_size is None else n_best_size
     nbest_seq = torch.full((B, n_best_size, max_length), end_idx, dtype=torch.long)
@@ -319,6 +320,10 @@ def beam_search(state, attn_emb, attn_emb_len, beam_size=3, max_length=20, temp=
             is_end = next_word == end_idx
             if t == max_length - 1:
                 is_end = torch.ones_like(is_end)
+            if trace is not None:
+                cand = (lp[0] if t == 0 else lp.view(-1)).topk(beam_size + 1).values
+                trace.append({"clip": i, "t": t, "prev_beam": prev_beam.tolist(), "ended": is_end.tolist(),
+                              "margin": float((cand[:-1] - cand[1:]).min())})   # smallest gap among the kept and to the first cut
             for b in range(beam_size):
                 if is_end[b]:
                     done.append({"seq": seq[b].clone(), "score": topk_logprob[b].item() / (t + 1)})

@@ -191,6 +191,72 @@ def main():
         g5[f"score_beam{k}"] = o_b["score"].numpy()
     np.savez_compressed(os.path.join(out_dir, "g5_beam.npz"), **g5)
 
+    # ---- G4b / G5b: the same searches on HIGH-ENTROPY decoder draws (audiocaption_amd/procedural.py DIVERSE) ----------
+    # g4 / g5 above repeat one token and hardly ever change the parent beam, so a wrong KV-cache re-gather could pass
+    # them.  These draws are checked HERE to exercise what they are for, on the reference's own outputs.
+    def max_repeat(seqs):
+        worst = 0
+        for row in seqs.tolist():
+            toks = [t for t in row if t != 2]
+            if toks:
+                worst = max(worst, int(np.bincount(toks).max()))
+        return worst
+
+    sb = dict(state)
+    sb.update(P.to_torch(P.decoder_state_diverse("greedy", vocab_size=V)))
+    model.load_state_dict(sb, strict=True)
+    ref_gb = model(dict(inp, sample_method="greedy", max_length=20))
+    o_gb = O.greedy_decode(sb, o_enc["attn_emb"], o_enc["attn_emb_len"], 20)
+    assert torch.equal(o_gb["seq"], ref_gb["seq"])
+    stb = o_gb["steps"]
+    cmp("G4b greedy logit", o_gb["logit"][:, :stb], ref_gb["logit"][:, :stb])
+    ends = [int((row == 2).nonzero()[0]) if (row == 2).any() else 20 for row in ref_gb["seq"]]
+    top2b = ref_gb["logit"][:, :stb].topk(2, dim=-1).values
+    gapb = top2b[..., 0] - top2b[..., 1]
+    print(f"  G4b greedy: steps {stb}, first <end> per clip {ends}, most repeated token x{max_repeat(ref_gb['seq'])}, "
+          f"min top1-top2 gap {float(gapb.min()):.2e}\n", ref_gb["seq"].numpy())
+    assert len(set(ends)) >= 3 and max_repeat(ref_gb["seq"]) <= 4 and float(gapb.min()) > 5e-4 and stb >= 15
+    np.savez_compressed(
+        os.path.join(out_dir, "g4b_greedy.npz"), steps=np.array(stb), seq=ref_gb["seq"].numpy(), top2_gap=gapb.numpy(),
+        sampled_logprob=ref_gb["sampled_logprob"][:, :stb].numpy(),
+        logit_top_val=ref_gb["logit"][:, :stb].topk(8, dim=-1).values.numpy(),
+        logit_top_idx=ref_gb["logit"][:, :stb].topk(8, dim=-1).indices.numpy())
+
+    sb = dict(state)
+    sb.update(P.to_torch(P.decoder_state_diverse("beam", vocab_size=V)))
+    model.load_state_dict(sb, strict=True)
+    g5b = {}
+    for k in (3, 4):
+        ref_b = model(dict(inp, sample_method="beam", beam_size=k, max_length=20))
+        trace = []
+        o_b = O.beam_search(sb, o_enc["attn_emb"], o_enc["attn_emb_len"], k, 20, trace=trace)
+        assert torch.equal(o_b["seq"], ref_b["seq"]), (o_b["seq"], ref_b["seq"])
+        ident = list(range(k))
+        per_clip = [[r for r in trace if r["clip"] == i] for i in range(4)]
+        reorder = [sum(1 for r in rs if r["t"] > 0 and r["prev_beam"] != ident) for rs in per_clip]
+        first_end = [min((r["t"] for r in rs if any(r["ended"])), default=99) for rs in per_clip]
+        last_t = [max(r["t"] for r in rs) for rs in per_clip]
+        early_and_on = sum(1 for i in range(4) if first_end[i] < 5 and last_t[i] > first_end[i])
+        margin = min(r["margin"] for r in trace)
+        distinct = len(set(map(tuple, ref_b["seq"].tolist())))
+        print(f"  G5b beam {k}: distinct results {distinct}/4, steps with a changed parent per clip {reorder}, first finished "
+              f"beam at t = {first_end} of {last_t}, most repeated token x{max_repeat(ref_b['seq'])}, min candidate margin "
+              f"{margin:.2e}\n", ref_b["seq"].numpy())
+        # >= 3 distinct captions, the parent beam changes on >= 5 steps of every clip, a beam finishes before t = 5 while
+        # the search goes on (the -1000 path, base.py:317), margins far above the f32 noise of the logits (4e-6)
+        assert distinct >= 3 and min(reorder) >= 5 and early_and_on >= 1 and margin > 1e-4
+        if k == 3:
+            assert max_repeat(ref_b["seq"]) <= 3
+        g5b[f"seq_beam{k}"] = ref_b["seq"].numpy()
+        g5b[f"score_beam{k}"] = o_b["score"].numpy()
+        g5b[f"reorder_steps_beam{k}"] = np.array(reorder)
+        nb = model(dict(inp, sample_method="beam", beam_size=k, max_length=20, n_best=True, n_best_size=k))
+        o_nb = O.beam_search(sb, o_enc["attn_emb"], o_enc["attn_emb_len"], k, 20, n_best=True, n_best_size=k)
+        assert torch.equal(o_nb["seq"], nb["seq"])
+        g5b[f"nbest_beam{k}"] = nb["seq"].numpy()
+    np.savez_compressed(os.path.join(out_dir, "g5b_beam.npz"), **g5b)
+    model.load_state_dict(state, strict=True)
+
     # ---- G7: LabelSmoothingLoss known answers (loss.py:51-74) ---------------------------------
     sys.modules["wandb"].run = None
     from captioning.losses.loss import LabelSmoothingLoss

@@ -187,6 +187,56 @@ def test_g5_beam_tokens_identical_to_reference(hip_model, golden_dir):
         np.testing.assert_array_equal(out["seq"].numpy(), g[f"seq_beam{k}"])
 
 
+@pytest.fixture(scope="module")
+def diverse_models(state4981):
+    """The product model with the two HIGH-ENTROPY decoder draws of the g4b / g5b fixtures (procedural.DIVERSE)."""
+    import audiocaption_amd as A
+    from audiocaption_amd import procedural as P
+    models = {}
+    for kind in ("greedy", "beam"):
+        st = dict(state4981)
+        st.update(P.to_torch(P.decoder_state_diverse(kind, vocab_size=4981)))
+        m = A.init_model_from_config(A.cnn14rnn_trm_config(4981), print_fn=lambda s: None)
+        m.load_state_dict(st, strict=True)
+        models[kind] = m.eval().to("cuda:0")
+    return models
+
+
+def test_g4b_greedy_high_entropy_fixture(diverse_models, golden_dir):
+    """Reference greedy ids on a draw whose clips stop at steps 3 / 10 / 19 / 10 and repeat no token more than 4 times
+    (g4 repeats one token fourteen times): ids identical, top-8 logits within 1e-4."""
+    g4, gb = _load(golden_dir, "g4_greedy.npz"), _load(golden_dir, "g4b_greedy.npz")
+    enc = {"attn_emb": torch.from_numpy(g4["attn_emb"]).cuda(), "attn_emb_len": torch.from_numpy(g4["attn_emb_len"]),
+           "fc_emb": torch.from_numpy(g4["fc_emb"]).cuda()}
+    out = diverse_models["greedy"].forward_decoder({"mode": "inference", "sample_method": "greedy", "max_length": 20}, enc)
+    np.testing.assert_array_equal(out["seq"].numpy(), gb["seq"])
+    steps = int(gb["steps"])
+    got_top = out["logit"][:, :steps].cpu().gather(-1, torch.from_numpy(gb["logit_top_idx"]))
+    # rows that have already emitted <end> keep decoding in the reference too; compare where the reference wrote logits
+    assert _maxdiff("g4b greedy logit top8", got_top, gb["logit_top_val"]) < 1e-4
+    assert _maxdiff("g4b greedy logprob", out["sampled_logprob"][:, :steps], gb["sampled_logprob"]) < 1e-4
+
+
+def test_g5b_beam_high_entropy_fixture(diverse_models, golden_dir):
+    """Reference beam-3 / beam-4 ids and n-best lists on a draw where the parent beam changes on 7-16 steps of every clip
+    (a wrong source row in the KV-cache re-gather cannot pass), four distinct captions, and beams that finish at t = 0...6
+    while the search runs on to t = 7...17 (the -1000 path, base.py:317); eager, captured and replayed."""
+    g4, g = _load(golden_dir, "g4_greedy.npz"), _load(golden_dir, "g5b_beam.npz")
+    model = diverse_models["beam"]
+    enc = {"attn_emb": torch.from_numpy(g4["attn_emb"]).cuda(), "attn_emb_len": torch.from_numpy(g4["attn_emb_len"]),
+           "fc_emb": torch.from_numpy(g4["fc_emb"]).cuda()}
+    for k in (3, 4):
+        req = {"mode": "inference", "sample_method": "beam", "beam_size": k, "max_length": 20}
+        for _ in range(3):                                       # eager, capture, replay
+            out = model.forward_decoder(dict(req), enc)
+            np.testing.assert_array_equal(out["seq"].numpy(), g[f"seq_beam{k}"])
+        outn = model.forward_decoder(dict(req, n_best=True, n_best_size=k), enc)
+        np.testing.assert_array_equal(outn["seq"].numpy(), g[f"nbest_beam{k}"])
+        # clips searched alone give the same captions (rows of other clips never leak into a clip's beams)
+        one = model.forward_decoder(dict(req), {kk: v[2:3] for kk, v in enc.items()})
+        np.testing.assert_array_equal(one["seq"].numpy(), g[f"seq_beam{k}"][2:3])
+
+
 def test_beam_search_graph_replay_and_n_best(hip_model, state4981, golden_dir):
     """The beam search runs as four captured launch sequences (steps 0-7, 8-11, 12-15, 16-19) from the second use of a
     shape on: the first (eager), second (capture) and third (replay) call return the reference fixture's ids, also after a

@@ -73,6 +73,35 @@ def test_g5_beam_tokens_identical(golden_dir, state4981):
         np.testing.assert_array_equal(out["seq"].numpy(), g[f"seq_beam{k}"])
 
 
+def _diverse_state(state4981, kind):
+    from audiocaption_amd import procedural as P
+    st = dict(state4981)
+    st.update(P.to_torch(P.decoder_state_diverse(kind, vocab_size=4981)))
+    return st
+
+
+def test_g4b_g5b_high_entropy_decode_fixtures(golden_dir, state4981):
+    """The second decoder draw (procedural.DIVERSE): the reference's greedy / beam-3 / beam-4 / n-best ids on searches
+    whose parent beam changes at >= 5 steps per clip and whose beams finish at different steps (make_golden.py asserts
+    those properties on the reference's outputs when it writes the files)."""
+    g4 = _load(golden_dir, "g4_greedy.npz")
+    attn, lens = torch.from_numpy(g4["attn_emb"]), torch.from_numpy(g4["attn_emb_len"])
+    gb = _load(golden_dir, "g4b_greedy.npz")
+    out = O.greedy_decode(_diverse_state(state4981, "greedy"), attn, lens, 20)
+    np.testing.assert_array_equal(out["seq"].numpy(), gb["seq"])
+    assert gb["top2_gap"].min() > 5e-4 and len({int((r == 2).argmax()) for r in gb["seq"]}) >= 3
+    steps = int(gb["steps"])
+    idx = torch.from_numpy(gb["logit_top_idx"])
+    np.testing.assert_allclose(out["logit"][:, :steps].gather(-1, idx).numpy(), gb["logit_top_val"], rtol=0, atol=5e-5)
+    g5 = _load(golden_dir, "g5b_beam.npz")
+    st = _diverse_state(state4981, "beam")
+    for k in (3, 4):
+        assert g5[f"reorder_steps_beam{k}"].min() >= 5 and len(set(map(tuple, g5[f"seq_beam{k}"].tolist()))) >= 3
+        np.testing.assert_array_equal(O.beam_search(st, attn, lens, k, 20)["seq"].numpy(), g5[f"seq_beam{k}"])
+        np.testing.assert_array_equal(O.beam_search(st, attn, lens, k, 20, n_best=True, n_best_size=k)["seq"].numpy(),
+                                      g5[f"nbest_beam{k}"])
+
+
 def test_g7_label_smoothing_known_answer(golden_dir, state4981):
     g3 = _load(golden_dir, "g3_decoder.npz")
     g = _load(golden_dir, "g7_loss.npz")
