@@ -17,7 +17,16 @@ STAMP = LIB + ".stamp"
 SOURCES = ["logmel.hip", "conv3x3.hip", "conv3x3_winograd.hip", "conv3x3_wino1d.hip", "gemm.hip", "gru.hip", "decoder.hip", "train.hip", "effnet.hip", "effnet_fused.hip", "pw_gemm.hip", "ingest.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
          "-Wno-unused-function", "-Wno-unused-result"]
-
+# Every source is built WITHOUT the packed-f32 VALU instructions (v_pk_fma_f32, v_pk_add_f32 ...).  With them the per-row
+# decode kernels' matrix-vector products (csrc/decoder.hip row_gemv256: v_pk_fma_f32 on freshly loaded weight rows) came
+# out wrong - single 64-byte chunks, ~1 decode in 3 - whenever ANOTHER kernel kept the matrix cores of the same SIMDs
+# busy: the next batch's conv kernels in forward_async, or a synthetic MFMA loop that touches no memory
+# (tools/corunner_probe.py).  The same source compiled to scalar v_fma_f32 is bit-stable under every co-runner tried
+# (tests/test_gpu_model.py::test_decode_is_bit_stable_beside_matrix_heavy_kernels).  Plain register-to-register packed
+# arithmetic beside MFMAs is fine (tools/pk_f32_probe.hip); what exactly fails was not isolated, so no kernel of this
+# library - all of them can run beside MFMA-heavy kernels of another stream - uses the packed forms.
+NO_PACKED_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+EXTRA_FLAGS = {}
 
 def _hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
@@ -34,6 +43,7 @@ def _digest():
                 h.update(name.encode())
                 h.update(f.read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr((NO_PACKED_F32, sorted(EXTRA_FLAGS.items()))).encode())
     return h.hexdigest()
 
 
@@ -69,7 +79,7 @@ def _compile(digest, verbose):
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     for src in SOURCES:
         obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
-        cmd = [hipcc, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj] + FLAGS
+        cmd = [hipcc, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj] + FLAGS + NO_PACKED_F32 + EXTRA_FLAGS.get(src, [])
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -1070,15 +1070,11 @@ int decoder_step(const ac_trm_weights* w, const float* memkv, const int* mem_len
   const float *jx = nullptr, *jy = nullptr, *jw = nullptr, *jb = nullptr;
   // the reference's decoder shape (d_model 256 = 4 heads of 64) takes the fused per-row sub-layer kernel: 5 launches per
   // layer instead of 8; any other shape the general 8-launch sequence
-  // The per-row kernels (dec_row_kernel / dec_row2_kernel: 10 launches per step instead of 18) are OPT-IN
-  // (AUDIOCAPTION_DEC_ROW=fused | split): their results were found to depend on what else runs on the GPU - beside a kernel
-  // that keeps the matrix cores busy at one or two waves per SIMD (the F(2,3) conv kernels of the next batch in
-  // forward_async; a synthetic MFMA loop that touches no memory does it too) single 64-byte chunks of their
-  // matrix-vector products come out wrong in ~1 of 3 decodes (tools/corunner_probe.py; logits off by up to 0.1, token ids
-  // unchanged), while this general sequence (attn_step_kernel + dec_gemm_kernel) is bit-stable under every co-runner
-  // tried (tests/test_gpu_model.py::test_decode_is_bit_stable_beside_matrix_heavy_kernels).  Root cause not found.
-  static const bool no_rows = !(getenv("AUDIOCAPTION_DEC_ROW") && (!strcmp(getenv("AUDIOCAPTION_DEC_ROW"), "fused") ||
-                                                                 !strcmp(getenv("AUDIOCAPTION_DEC_ROW"), "split")));
+  // AUDIOCAPTION_DEC_ROW=gemm: the general 18-launch sequence (attn_step_kernel + dec_gemm_kernel) instead of the per-row
+  // kernels.  (The row kernels once gave co-runner-dependent results: built with packed-f32 VALU instructions their
+  // matrix-vector products broke beside MFMA-heavy kernels of another stream - see audiocaption_amd/build.py; every mode is
+  // now held to tests/test_gpu_model.py::test_decode_is_bit_stable_beside_matrix_heavy_kernels.)
+  static const bool no_rows = getenv("AUDIOCAPTION_DEC_ROW") && !strcmp(getenv("AUDIOCAPTION_DEC_ROW"), "gemm");
   const bool fused = d == ROW_D && w->nhead == ROW_H && t + 1 <= MAX_KEYS && Tm <= MAX_KEYS && !no_rows;
   for (int l = 0; l < w->nlayers; ++l) {
     const ac_trm_layer& L = w->layer[l];

@@ -393,8 +393,8 @@ def test_decode_is_bit_stable_beside_matrix_heavy_kernels(hip_model, state4981):
     """The greedy decode chain must give the same bits whatever else runs on the GPU: here beside the F(2,3) conv kernel
     (W = 16: 256-thread workgroups that keep the matrix cores busy at two waves per SIMD) launched back to back on a
     second stream - the situation of ``forward_async``, where the next batch's encoder runs under this batch's decode.
-    (The per-row decode kernels failed this in ~1 of 3 decodes - csrc/decoder.hip, AUDIOCAPTION_DEC_ROW - which is why
-    the general launch sequence is the default.)"""
+    Built WITH packed-f32 VALU instructions the per-row decode kernels failed this in ~1 of 3 decodes (logits off by up to
+    0.1: audiocaption_amd/build.py NO_PACKED_F32, tools/corunner_probe.py)."""
     from audiocaption_amd import kernels as K, procedural as P
     wav = torch.from_numpy(P.synthetic_wav(3, 48000, seed=1, varied=True)).cuda()
     enc = hip_model.encoder({"wav": wav, "wav_len": [48000, 40000, 33000], "specaug": False})
