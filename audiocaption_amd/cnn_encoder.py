@@ -39,12 +39,22 @@ def cnn14_feat_len(wav_len, hop, ratio=32):
     return torch.div(n, ratio, rounding_mode="floor").long()
 
 
-def _conv_wino1d(x, w, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode=-1):
+def _conv_wino1d(x, w, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode=-1, need=None):
     """The "wino1d" tier's launcher: the F(2,3) kernel covers 128-channel column tiles; conv2 of block 1 (Cout = 64)
     runs on the direct split-bf16 kernel (``_pack`` packs its weights for that kernel)."""
     if Cout % 128:
         return K.conv3x3_bn_relu_bf16x3_gw(x, w, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode)
-    return K.conv3x3_bn_relu_wino1d(x, w, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode)
+    return K.conv3x3_bn_relu_wino1d(x, w, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode, need=need)
+
+
+def rows_needed(block, conv):
+    """(mul, add): output rows of conv ``conv`` (1 | 2) of conv block ``block`` (1..6) that can reach an output frame below a
+    clip's own ``attn_emb_len`` = mul * attn_emb_len + add.  Block 6 is not pooled: its second conv needs exactly the
+    frames, its first one row more; every 3x3 conv upstream adds a row, every pooling doubles (cnn_encoder.py:431-441)."""
+    if block == 6:
+        return (1, 0) if conv == 2 else (1, 1)
+    mul, add = 1 << (6 - block), (1 << (8 - block)) - 4
+    return (mul, add) if conv == 2 else (mul, add + 1)
 
 
 def conv_kernel(algo):
@@ -191,7 +201,8 @@ class Cnn14Encoder(nn.Module):
         Hp = [hp6 << (5 - k) for k in range(6)]
         return T, H, Hp
 
-    def encode(self, wav, dropout=None, specaug=None, train=False, min_frames=None, algo=None, overflow=None):
+    def encode(self, wav, dropout=None, specaug=None, train=False, min_frames=None, algo=None, overflow=None,
+               clip_frames=None):
         """wav (B, L) on the ROCm device -> attn_emb (B, T // 32, 2048).
 
         ``dropout = (p, op_code, seed_dev_ptr)``: the train-mode forward of the frozen network, F.dropout(p) after
@@ -205,7 +216,11 @@ class Cnn14Encoder(nn.Module):
         over: 3e-4 at 10 s, 6e-4 at 3 s, up to 1.7e-3 at 1 s - DESIGN.md section 4), so a batch that contains a clip of
         fewer than ``f16x2_min_frames`` (8, = 2.6 s) frames runs on the split-bf16 tier (3e-5 at any length).
         ``algo``: conv tier of this call (default ``self.conv_algo``).  ``overflow``: int32 device word the fp16 tier ORs
-        with 1 when an activation left the fp16 range (``forward`` returns it as ``f16_overflow``)."""
+        with 1 when an activation left the fp16 range (``forward`` returns it as ``f16_overflow``).
+        ``clip_frames``: int32 device tensor (B,) of every clip's own ``attn_emb_len`` - ragged batches: the "wino1d" tier
+        skips the conv rows that lie beyond what a clip's own length can bring to one of its output frames (the reference
+        convolves the zero padding, collate_func.py:29-32); frames below ``attn_emb_len`` are bit-identical, frames at or
+        beyond it - which no temporal encoder reads (model_util.py:10-27) - are then NOT the reference's values."""
         if wav.dim() != 2:
             raise ValueError("wav must be (batch, samples)")
         dev = wav.device
@@ -224,7 +239,8 @@ class Cnn14Encoder(nn.Module):
         x0 = K.logmel(wav, self._tables, pk["bn0"][0], pk["bn0"][1], rows_per_clip=Hp[0], channels_last=True)
         if specaug is not None:
             K.specaug_(x0, specaug, pk["bn0"][1], B, Hp[0], T)
-        return self.conv_stack(x0, B, H, Hp, pk, algo, dropout, overflow=overflow)
+        return self.conv_stack(x0, B, H, Hp, pk, algo, dropout, overflow=overflow,
+                               clip_frames=clip_frames if algo == "wino1d" else None)
 
     def effective_algo(self, algo=None, train=False, min_frames=None):
         """The conv tier a call runs on: the fp16-activation tier is left for the train-mode forward and for batches
@@ -236,7 +252,7 @@ class Cnn14Encoder(nn.Module):
             return "bf16x3"
         return algo
 
-    def conv_stack(self, x0, B, H, Hp, pk, algo, dropout=None, blocks=None, overflow=None):
+    def conv_stack(self, x0, B, H, Hp, pk, algo, dropout=None, blocks=None, overflow=None, clip_frames=None):
         """The six conv blocks on a bn0-normalised log-mel x0 [B*Hp[0]][64] -> attn_emb (B, H[5], 2048).
         ``blocks``: a list that receives a float32 (B, C, H, W) copy of every pooled block output (tests)."""
         dev = x0.device
@@ -249,6 +265,10 @@ class Cnn14Encoder(nn.Module):
             import functools
             conv = functools.partial(conv, overflow=overflow)
         fuse1 = algo == "f16x2" and os.environ.get("AUDIOCAPTION_FUSE_BLOCK1", "1") != "0"
+
+        def need(block, j):   # ragged batches: the rows of this layer a clip's own length can bring to an output frame
+            return {"need": (clip_frames,) + rows_needed(block, j)} if clip_frames is not None and algo == "wino1d" else {}
+
         mixed = algo == "f16x2" and pk.get("mixed", False)
         for b in range(6):
             cin, cout = CHANNELS[b], CHANNELS[b + 1]
@@ -265,10 +285,10 @@ class Cnn14Encoder(nn.Module):
             elif b == 0:
                 K.conv3x3_first(x0, w1, s1, t1, full, B, Hp[0], H[0], W, overflow=overflow)
             else:
-                conv(pooled, w1, s1, t1, full, B, Hp[b], H[b], W, cin, cout, 0)
+                conv(pooled, w1, s1, t1, full, B, Hp[b], H[b], W, cin, cout, 0, **need(b + 1, 1))
             if b < 5:
                 if not (b == 0 and fuse1):
-                    conv(full, w2, s2, t2, pool_out, B, Hp[b], H[b], W, cout, cout, 1)
+                    conv(full, w2, s2, t2, pool_out, B, Hp[b], H[b], W, cout, cout, 1, **(need(b + 1, 2) if cout % 128 == 0 else {}))
                 pooled = pool_out
                 W //= 2
                 if dropout is not None:
@@ -279,7 +299,7 @@ class Cnn14Encoder(nn.Module):
             else:
                 attn = torch.empty(B, H[5], cout, device=dev, dtype=torch.float32)
                 if dropout is None:
-                    conv(full, w2, s2, t2, attn, B, Hp[b], H[b], W, cout, cout, 2)
+                    conv(full, w2, s2, t2, attn, B, Hp[b], H[b], W, cout, cout, 2, **need(6, 2))
                 else:  # dropout sits between the last block and the mean over mel bins
                     last = self._buf("last", B * Hp[5] * W * cout, dev)
                     conv(full, w2, s2, t2, last, B, Hp[b], H[b], W, cout, cout, 0)
@@ -300,7 +320,12 @@ class Cnn14Encoder(nn.Module):
         # activations overflowed on the f32-activation tier)
         algo = self.effective_algo(input_dict.get("conv_algo"), False, min_frames)
         flag = torch.zeros(1, device=wav.device, dtype=torch.int32) if algo == "f16x2" else None
-        attn_emb = self.encode(wav, min_frames=min_frames, algo=algo, overflow=flag)
+        # inside a composite encoder (skip_fc: CrnnEncoder / Cnn14TransformerEncoder mask by length) the rows a clip's own
+        # length cannot bring to an output frame are not convolved; stand-alone, attn_emb is the reference's everywhere
+        ragged = skip_fc and algo == "wino1d" and os.environ.get("AUDIOCAPTION_SKIP_DEAD_ROWS", "1") != "0" \
+            and int(feat_length.min()) < int(feat_length.max())
+        frames = K.upload(feat_length, wav.device, torch.int32) if ragged else None
+        attn_emb = self.encode(wav, min_frames=min_frames, algo=algo, overflow=flag, clip_frames=frames)
         out = {"attn_emb": attn_emb, "attn_emb_len": feat_length}
         if flag is not None:
             # non-zero: an activation exceeded the fp16 range (65504) and this result must not be used -

@@ -52,6 +52,10 @@ struct W1Params {
   int mt_cols, MT, NT;
   int Hp_out, H_out, W_out;
   int map_mode;
+  // ragged batches: clip b needs only its first need_mul * clip_frames[b] + need_add output rows of this layer (the rows
+  // beyond can never reach an output frame the temporal encoder reads); null = every row of the geometry
+  const int* clip_frames;
+  int need_mul, need_add;
 };
 
 enum { MODE_FULL = 0, MODE_POOL = 1, MODE_MEANW = 2 };
@@ -191,7 +195,24 @@ __global__ __launch_bounds__((W1Geom<TC, FULLW, WIDE>::THREADS), 2) void conv3x3
 
   const int row0 = 2 * pair0;
   const int rc0 = row0 % p.Hp;
-  const bool all_pad = (rc0 >= p.H && rc0 + 2 * PR <= p.Hp) || row0 >= p.rows_total;
+  (void)rc0;
+  // dead block: every row of it lies in the padding of its clip(s) - beyond the geometry's H valid rows, or (ragged
+  // batches) beyond the rows the clip's own length can bring to an output frame
+  bool live = false;
+  if (row0 < p.rows_total) {
+    const int r_end = row0 + 2 * PR < p.rows_total ? row0 + 2 * PR : p.rows_total;
+    int b = row0 / p.Hp;
+    for (int base = b * p.Hp; base < r_end; base += p.Hp, ++b) {
+      const int lo = (row0 > base ? row0 : base) - base;
+      int lim = p.H;
+      if (p.clip_frames) {
+        const int need = p.need_mul * p.clip_frames[b] + p.need_add;
+        lim = need < lim ? need : lim;
+      }
+      live = live || lo < lim;
+    }
+  }
+  const bool all_pad = !live;
   const int nstep = p.Cin / KS;
   if (!all_pad) {
     // Buffer descriptors (wave-uniform): out-of-range offsets read as zero, so the rows above / below the batch and the
@@ -320,7 +341,7 @@ __global__ __launch_bounds__((W1Geom<TC, FULLW, WIDE>::THREADS), 2) void conv3x3
   // i = 8 (r / 4) + 4 (l / 32) + r % 4 of each tile: both rows of a pair, and the two columns of a pooling window / of the
   // last layer's mean - the wave's two tiles (!WIDE), registers r and r + 8 of one tile (WIDE) - sit in this lane ----
   const int ch = n_tile * 128 + wn * 32 + (lane & 31);
-  const float sc = p.scale[ch], sh = p.shift[ch];
+  const float sc = all_pad ? 0.f : p.scale[ch], sh = all_pad ? 0.f : p.shift[ch];   // dead blocks store zeros
   const FastDiv by_hp(p.Hp), by_hp_out(MODE == MODE_POOL ? p.Hp_out : 1);
 #pragma unroll
   for (int r = 0; r < (WIDE ? 8 : 16); ++r) {
@@ -389,7 +410,8 @@ int launch_w1(W1Params p, hipStream_t s) {
 // C ABI: see include/audiocaption_hip.h
 extern "C" int ac_conv3x3_bn_relu_wino1d(const float* in, const void* wfrag, const float* scale, const float* shift,
                                          float* out, int B, int Hp, int H, int W, int Cin, int Cout, int mode,
-                                         int map_mode, void* stream) {
+                                         int map_mode, const int* clip_frames, int need_mul, int need_add,
+                                         void* stream) {
   if (!in || !wfrag || !scale || !shift || !out) return AC_ERR_ARG;
   if (B <= 0 || Hp <= H || (Hp & 1) || W < 2 || (W != 2 && (W & 3)) || Cin % 32 || Cout % 128) return AC_ERR_ARG;
   if (mode < 0 || mode > 2) return AC_ERR_ARG;
@@ -406,6 +428,7 @@ extern "C" int ac_conv3x3_bn_relu_wino1d(const float* in, const void* wfrag, con
   if (map_mode == 1 && p.NT % 8 != 0) return AC_ERR_ARG;
   if (map_mode == 3 && !(p.NT == 1 || p.NT == 2 || p.NT == 4 || p.NT == 8)) return AC_ERR_ARG;
   p.map_mode = map_mode;
+  p.clip_frames = clip_frames; p.need_mul = need_mul; p.need_add = need_add;
   hipStream_t s = (hipStream_t)stream;
   if (W == 2) {
     if (mode == MODE_FULL) return launch_w1<MODE_FULL, 2, true, false>(p, s);

@@ -80,10 +80,15 @@ int ac_conv3x3_bn_relu_bf16x3_gw(const float* in, const void* wfrag, const float
  * in / out f32 with the layouts of ac_conv3x3_bn_relu.  wfrag = U split and packed in MFMA fragment order
  * [Cin/32][3 kx][4 positions][2 k-steps][Cout/32][2 (hi, lo)][64 lanes][8] bf16, lane = (cout % 32) + 32 * ((cin % 16) / 8),
  * element = cin % 8.  Requires Hp even, W = 2 or a multiple of 4, Cin % 32 == 0, Cout % 128 == 0 (AC_ERR_ARG otherwise;
- * mode 1 needs W >= 4, mode 2 needs W == 2). */
+ * mode 1 needs W >= 4, mode 2 needs W == 2).
+ * Ragged batches (the reference pads every clip to the batch maximum and convolves the padding, collate_func.py:29-32,
+ * cnn_encoder.py:446-450): clip_frames (device int32 [B], may be NULL) = every clip's own attn_emb_len; workgroups whose
+ * output rows all lie at or beyond need_mul * clip_frames[b] + need_add of their clip(s) skip the convolution and store
+ * zeros.  The caller derives (need_mul, need_add) per layer from the receptive field downstream, so that every output
+ * frame below clip_frames[b] - all the temporal encoder reads (model_util.py:10-27) - is bit-identical. */
 int ac_conv3x3_bn_relu_wino1d(const float* in, const void* wfrag, const float* scale, const float* shift,
                               float* out, int B, int Hp, int H, int W, int Cin, int Cout, int mode,
-                              int map_mode, void* stream);
+                              int map_mode, const int* clip_frames, int need_mul, int need_add, void* stream);
 
 /* "f16x2" tier of the same kernel.  Activations live in HBM as fp16 (in: [B*Hp][W][Cin] fp16; out: fp16 for modes 0
  * and 1, f32 for mode 2 = the attn_emb the rest of the path consumes), weights as fp16 hi + lo (2^-22) in the same

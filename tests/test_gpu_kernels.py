@@ -250,6 +250,44 @@ def test_conv3x3_bn_relu(K, B, H, W, Cin, Cout, mode, map_mode, algo):
     assert _report(f"conv[{algo}] {B}x{H}x{W} {Cin}->{Cout} mode{mode}", out.reshape(want_rows.shape), want_rows) < tol
 
 
+@pytest.mark.parametrize("W,Cin,Cout,mode,block,conv", [(16, 128, 256, 0, 3, 1), (8, 512, 512, 1, 4, 2), (4, 512, 1024, 0, 5, 1),
+                                                       (2, 1024, 2048, 0, 6, 1), (2, 2048, 2048, 2, 6, 2)])
+def test_conv3x3_wino1d_dead_row_skipping(K, W, Cin, Cout, mode, block, conv):
+    """Per-clip dead rows: output rows below ``mul * frames[b] + add`` are bit-identical to the full convolution, workgroups
+    wholly beyond it store zeros, and at least one workgroup is skipped on this ragged set."""
+    from audiocaption_amd.cnn_encoder import rows_needed
+    g = torch.Generator().manual_seed(W * 7 + Cin)
+    # clips long enough for whole workgroups (up to 128 rows) to fall between a short clip's need and the next clip
+    frames = torch.tensor([90, 4, 50, 2, 30], dtype=torch.int32) * (2 if block == 6 else 1)
+    B = len(frames)
+    H = 90 << (6 - block) if block < 6 else 218
+    Hp = H + 1 + ((H + 1) % 2)
+    x = torch.zeros(B, Hp, W, Cin)
+    x[:, :H] = torch.randn(B, H, W, Cin, generator=g)
+    x = x.reshape(B * Hp, W, Cin).cuda()
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * math.sqrt(2.0 / (9 * Cin))
+    wp = K.pack_conv_weight_wino1d_frag(w.cuda())
+    sc, sh = (torch.rand(Cout, generator=g) + 0.5).cuda(), (torch.randn(Cout, generator=g) * 0.1).cuda()
+    shape = (B * Hp, W, Cout) if mode == 0 else ((B * Hp // 2, W // 2, Cout) if mode == 1 else (B, H, Cout))
+    full, skip = torch.full(shape, 7.0).cuda(), torch.full(shape, 7.0).cuda()
+    K.conv3x3_bn_relu_wino1d(x, wp, sc, sh, full, B, Hp, H, W, Cin, Cout, mode)
+    mul, add = rows_needed(block, conv)
+    K.conv3x3_bn_relu_wino1d(x, wp, sc, sh, skip, B, Hp, H, W, Cin, Cout, mode, need=(frames.cuda(), mul, add))
+    rows = Hp if mode == 0 else (Hp // 2 if mode == 1 else H)
+    f, s_ = full.reshape(B, rows, -1).cpu(), skip.reshape(B, rows, -1).cpu()
+    zeroed = 0
+    for b in range(B):
+        need = min(int(mul * frames[b] + add), H)
+        n = need if mode != 1 else need // 2
+        assert torch.equal(f[b, :n], s_[b, :n]), (b, n)
+        tail = s_[b, n:]
+        same = (tail == f[b, n:]).all(dim=1)
+        zero = (tail == 0).all(dim=1)
+        assert bool((same | zero).all())          # a row beyond the need is either computed as usual or a skipped block's zeros
+        zeroed += int((zero & ~same).sum())
+    assert zeroed > 0
+
+
 def test_conv3x3_first(K):
     import torch.nn.functional as F
     g = torch.Generator().manual_seed(3)

@@ -421,6 +421,37 @@ def test_decode_is_bit_stable_beside_matrix_heavy_kernels(hip_model, state4981):
     assert differing == 0
 
 
+def test_ragged_batch_skips_dead_rows_bit_identically(hip_model, monkeypatch):
+    """Ragged batch (3 ... 10 s clips, zero-padded to the longest as the collate does): the default conv tier does not
+    convolve the rows a clip's own length cannot bring to one of its output frames (cnn_encoder.rows_needed).  What the
+    model returns - the GRU's attn_emb / fc_emb, logits, ids - must be BIT-identical to the run that convolves all the
+    padding like the reference (collate_func.py:29-32, cnn_encoder.py:446-450), and each clip must equal the clip run
+    alone under the same padding (1e-5: the GEMM paths are chosen by row count)."""
+    from audiocaption_amd import procedural as P
+    secs = [10.0, 3.1, 7.4, 5.0, 9.2, 4.3]
+    wav_len = [int(s_ * 32000) for s_ in secs]
+    L = max(wav_len)
+    wav = P.synthetic_wav(len(secs), L, seed=41, varied=True)
+    for i, n in enumerate(wav_len):
+        wav[i, n:] = 0.0
+    wav = torch.from_numpy(wav).cuda()
+    inp = {"mode": "inference", "wav": wav, "wav_len": wav_len, "specaug": False, "sample_method": "greedy", "max_length": 12}
+    assert hip_model.encoder.cnn.conv_algo == "wino1d"
+    monkeypatch.setenv("AUDIOCAPTION_SKIP_DEAD_ROWS", "0")
+    full = hip_model(dict(inp))
+    monkeypatch.setenv("AUDIOCAPTION_SKIP_DEAD_ROWS", "1")
+    skip = hip_model(dict(inp))
+    for k in ("attn_emb", "fc_emb", "logit", "sampled_logprob"):
+        assert torch.equal(full[k], skip[k]), k
+    assert torch.equal(full["seq"], skip["seq"])
+    for i, n in enumerate(wav_len):
+        one = hip_model(dict(inp, wav=wav[i:i + 1].contiguous(), wav_len=[n]))   # padded like in the batch (the mel of the
+        #                                                                          last frames sees the zeros, not a reflection)
+        t = int(one["attn_emb_len"][0])
+        assert _maxdiff(f"clip {i} alone: attn_emb", one["attn_emb"][0, :t], skip["attn_emb"][i, :t]) < 1e-5
+        assert torch.equal(one["seq"][0], skip["seq"][i])
+
+
 def test_forward_async_pair_decode_mixed_shapes(hip_model):
     """Pair decode only joins consecutive submissions of the same shape; anything else is decoded on its own - in every
     case with the results of the blocking call, whatever order result() is asked in."""
