@@ -214,7 +214,7 @@ class Cnn14Encoder(nn.Module):
         ``min_frames``: output frames of the shortest clip of the batch (``forward`` passes it).  The "f16x2" tier's
         logit error grows as clips get shorter (fewer frames for the decoder's attention to average the fp16 rounding
         over: 3e-4 at 10 s, 6e-4 at 3 s, up to 1.7e-3 at 1 s - DESIGN.md section 4), so a batch that contains a clip of
-        fewer than ``f16x2_min_frames`` (8, = 2.6 s) frames runs on the split-bf16 tier (3e-5 at any length).
+        fewer than ``f16x2_min_frames`` (10, = 3.2 s) frames runs on the split-bf16 tier (3e-5 at any length).
         ``algo``: conv tier of this call (default ``self.conv_algo``).  ``overflow``: int32 device word the fp16 tier ORs
         with 1 when an activation left the fp16 range (``forward`` returns it as ``f16_overflow``).
         ``clip_frames``: int32 device tensor (B,) of every clip's own ``attn_emb_len`` - ragged batches: the "wino1d" tier

@@ -66,6 +66,9 @@ __device__ __forceinline__ float ac_sigmoid_fast(float v) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896f * v));
 }
 __device__ __forceinline__ float ac_swish_fast(float v) { return v * ac_sigmoid_fast(v); }
+// The accurate forms (expf + IEEE division) for the kernels documented as exact f32 (gemm_general / gemm_nt / gemm_kk).
+__device__ __forceinline__ float ac_sigmoid_exact(float v) { return 1.0f / (1.0f + expf(-v)); }
+__device__ __forceinline__ float ac_swish_exact(float v) { return v * ac_sigmoid_exact(v); }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter
 // (s_waitcnt vmcnt(0)), which would force every global prefetch in flight to land at each barrier.

@@ -53,9 +53,10 @@ struct ConvParams {
 // wave at the end, and only when something overflowed (never on healthy activations).
 struct F16Guard {
   float mx = 0.f;
-  __device__ __forceinline__ void track(float y) { mx = fmaxf(mx, y); }   // post-ReLU values: y >= 0
+  // post-ReLU values: y >= 0.  Written so that a NaN sticks (fmaxf would drop it) and trips the flag in commit().
+  __device__ __forceinline__ void track(float y) { mx = (y <= mx) ? mx : y; }
   __device__ __forceinline__ void commit(unsigned* flag) const {
-    if (flag != nullptr && mx > 65504.f) atomicOr(flag, 1u);
+    if (flag != nullptr && !(mx <= 65504.f)) atomicOr(flag, 1u);
   }
 };
 
@@ -150,7 +151,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 
               const bool valid = by_hp.mod(gr) < p.H;
               const size_t o = ((size_t)gr * p.W + gc) * p.Cout + ch;
               if (OUT16) {
-                guard.track(y[e]);
+                guard.track(valid ? y[e] : 0.f);   // padding rows are stored as zeros: they cannot overflow
                 ((_Float16*)p.out)[o] = (_Float16)(valid ? y[e] : 0.f);
               } else p.out[o] = valid ? y[e] : 0.f;
             }
@@ -162,7 +163,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x16 
             const float o = 0.25f * ((y[0] + y[1]) + (y[2] + y[3]));
             const size_t oi = ((size_t)orow * p.W_out + ocol) * p.Cout + ch;
             if (OUT16 && !p.out32) {
-              guard.track(o);
+              guard.track(valid ? o : 0.f);
               ((_Float16*)p.out)[oi] = (_Float16)(valid ? o : 0.f);
             } else p.out[oi] = valid ? o : 0.f;
           }

@@ -126,8 +126,8 @@ __global__ __launch_bounds__(256) void gemm_general_kernel(GemmP p) {
     } else {
       float v = acc[r] + bias;
       if (p.relu == 1) v = fmaxf(v, 0.f);
-      else if (p.relu == 2) v = ac_swish_fast(v);
-      else if (p.relu == 3) v = ac_sigmoid_fast(v);
+      else if (p.relu == 2) v = ac_swish_exact(v);
+      else if (p.relu == 3) v = ac_sigmoid_exact(v);
       v *= p.drop.mask((uint64_t)(p.row0 + m) * (uint64_t)p.N + (uint64_t)n);
       if (p.beta != 0.f) v += p.beta * *c;
       *c = v;
@@ -238,8 +238,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
         } else {
           float v = acc[i][j][r] + bias;
           if (p.relu == 1) v = fmaxf(v, 0.f);
-          else if (p.relu == 2) v = ac_swish_fast(v);
-          else if (p.relu == 3) v = ac_sigmoid_fast(v);
+          else if (p.relu == 2) v = ac_swish_exact(v);
+          else if (p.relu == 3) v = ac_sigmoid_exact(v);
           v *= p.drop.mask((uint64_t)(p.row0 + m) * (uint64_t)p.N + (uint64_t)n);
           if (p.beta != 0.f) v += p.beta * *c;
           *c = v;
@@ -311,8 +311,8 @@ __global__ __launch_bounds__(256) void gemm_kk_kernel(GemmP p) {
     if (m >= p.M) continue;
     float v = ((acc[r] + red[0][row][col]) + (red[1][row][col] + red[2][row][col])) + bias;
     if (p.relu == 1) v = fmaxf(v, 0.f);
-    else if (p.relu == 2) v = ac_swish_fast(v);
-    else if (p.relu == 3) v = ac_sigmoid_fast(v);
+    else if (p.relu == 2) v = ac_swish_exact(v);
+    else if (p.relu == 3) v = ac_sigmoid_exact(v);
     v *= p.drop.mask((uint64_t)(p.row0 + m) * (uint64_t)p.N + (uint64_t)n);
     float* c = p.C + (long)m * p.ldc + n;
     if (p.beta != 0.f) v += p.beta * *c;

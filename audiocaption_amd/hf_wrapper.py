@@ -21,6 +21,7 @@ model), so ``demo.py``-style callers can use the Cnn14Rnn-Trm captioner without 
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .config import merge_load_state_dict
 from .effnet_encoder import EfficientNetB2
@@ -64,8 +65,9 @@ def _input_dict(device, audio, audio_length, sample_method, beam_size, max_lengt
 
 class ContraEncoderKdWrapper(nn.Module, CaptionMetaMixin):
     """hf_wrapper.py:1071-1112.  Holds the captioner plus the contrastive knowledge-distillation heads that exist in the
-    published state dict.  Inference passes straight through to the captioner; the distillation loss (``tchr_output`` in
-    the input dict) is a training recipe outside the accelerated path."""
+    published state dict.  Inference passes straight through to the captioner (HIP path); with ``tchr_output`` in the input
+    dict the symmetric contrastive loss between the projected clip embedding and the teacher's embedding is added as
+    ``enc_kd_loss`` (hf_wrapper.py:1095-1111) - a few torch ops on ``fc_emb``, outside the accelerated path."""
 
     def __init__(self, model, shared_dim, tchr_dim):
         super().__init__()
@@ -77,12 +79,15 @@ class ContraEncoderKdWrapper(nn.Module, CaptionMetaMixin):
         self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
 
     def forward(self, input_dict):
+        out = self.model.encoder(input_dict) if input_dict.get("unsup", False) else self.model(input_dict)
         if "tchr_output" in input_dict:
-            raise NotImplementedError("ContraEncoderKdWrapper (HIP path): the encoder knowledge-distillation loss is a "
-                                      "training recipe outside the accelerated path (SURVEY.md section 2.1 row 10)")
-        if input_dict.get("unsup", False):
-            return self.model.encoder(input_dict)
-        return self.model(input_dict)
+            # CLIP-style loss: cosine similarities of every (student clip, teacher clip) pair, scaled, matched on the diagonal
+            student = F.normalize(self.stdnt_proj(out["fc_emb"]), dim=-1)
+            teacher = F.normalize(self.tchr_proj(input_dict["tchr_output"]["embedding"]), dim=-1)
+            sim = self.logit_scale * (student @ teacher.t())
+            target = torch.arange(sim.shape[0], device=sim.device)
+            out["enc_kd_loss"] = 0.5 * (F.cross_entropy(sim, target) + F.cross_entropy(sim.t(), target))
+        return out
 
 
 class Effb2TrmConfig(PretrainedConfig):

@@ -244,14 +244,18 @@ def pack_conv_weight_wino1d_frag(w):
 
 def pack_conv_weight_winograd(w):
     """OIHW (Cout, Cin, 3, 3) -> U = G g G^T as [Cin/32][4 j][4 i][Cout][32] (csrc/conv3x3_winograd.hip).
-    The transform is evaluated in float64 and rounded once to fp32."""
+    The transform is evaluated in float64 and rounded once to fp32 - with elementwise adds only (G has entries 0, +-1/2,
+    1), so packing launches no library GEMM."""
     cout, cin = w.shape[0], w.shape[1]
-    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]],
-                     dtype=torch.float64, device=w.device)
+
+    def g_times(t, dim):   # G applied along one 3-tap axis: (t0, (t0 + t1 + t2) / 2, (t0 - t1 + t2) / 2, t2)
+        t0, t1, t2 = t.select(dim, 0), t.select(dim, 1), t.select(dim, 2)
+        return torch.stack([t0, 0.5 * (t0 + t1 + t2), 0.5 * (t0 - t1 + t2), t2], dim=dim)
+
     out = torch.empty(cin // 32, 4, 4, cout, 32, device=w.device, dtype=torch.float32)
     step = max(1, (1 << 22) // (cin * 16))  # bound the float64 temporary
     for o0 in range(0, cout, step):
-        u = torch.einsum("ia,ocab,jb->ocij", G, w[o0:o0 + step].double(), G)  # (o, c, i, j)
+        u = g_times(g_times(w[o0:o0 + step].double(), 2), 3)  # (o, c, i, j) = G g G^T
         u = u.permute(1, 3, 2, 0).reshape(cin // 32, 32, 4, 4, -1).permute(0, 2, 3, 4, 1)  # [c/32][j][i][o][32]
         out[:, :, :, o0:o0 + step] = u.float()
     return out

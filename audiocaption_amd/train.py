@@ -910,6 +910,13 @@ class TrainEngine:
                 w_.wait()
         self.flat.attach_grads()
         clip = clip_grad_norm_(self.flat.params, max_grad_norm, grad_div=float(world), scale_now=False)
+        # A partner timeout of the split GRU kernel (four cooperating workgroups per (clip, direction); GPU shared or
+        # over-subscribed) leaves stale hidden values behind: its sticky error word is folded into the clip state's
+        # non-finite flag ON THE DEVICE, so the update is skipped exactly like a NaN loss (run.py:123) without a host
+        # synchronisation; ``gru_timeout()`` reads it for callers that want to raise.
+        err = self._gru_error_word(st)
+        if err is not None:
+            clip.state[3:4].add_((err != 0).to(clip.state.dtype))
         if isinstance(optimizer, FusedAdam):
             optimizer.step(clip=clip)
         else:
@@ -927,6 +934,29 @@ class TrainEngine:
         out = self._outputs(st)
         return {"loss": st["ws"].tensor("loss")[0], "total_norm": clip.total_norm, "logit": out["logit"],
                 "seq": out.get("seq")}
+
+
+def _gru_error_word(self, st):
+    """The split-GRU kernel's sticky error word of this engine's workspace as a 1-element int32 device view, or None."""
+    if self.gru_algo != "split" or not st.get("gru_xch_zeroed"):
+        return None
+    return st["ws"].tensor("gru_xch").view(torch.int32)[:1]
+
+
+def gru_timeout(self):
+    """True if a split-GRU launch of any shape state of this engine timed out waiting for a partner workgroup (reads the
+    device: synchronises).  The affected iterations' updates were skipped on the device; clears the word."""
+    hit = False
+    for st in self._states.values():
+        err = _gru_error_word(self, st)
+        if err is not None and int(err.item()) != 0:
+            hit = True
+            err.zero_()
+    return hit
+
+
+TrainEngine._gru_error_word = _gru_error_word
+TrainEngine.gru_timeout = gru_timeout
 
 
 class _TrainBridge(torch.autograd.Function):

@@ -18,6 +18,7 @@ import ctypes
 
 import numpy as np
 import os
+import weakref
 
 import torch
 import torch.nn as nn
@@ -78,6 +79,10 @@ class CaptionModel(nn.Module, CaptionMetaMixin):
     def _check_flags(self, host_flags, input_dict):
         """host_flags = [fp16 overflow of the conv tier, split-GRU partner timeout] read back with the results."""
         if int(host_flags[1]) != 0:
+            for m in self.encoder.modules():   # the word is sticky on the device: clear it so that the NEXT batch is judged on its own
+                ws = getattr(m, "_split_ws", None)
+                if ws is not None:
+                    ws.view(torch.int32)[:1].zero_()
             raise _lib.HipLibraryError("split GRU kernel: a workgroup's partner never started (GPU shared with another "
                                        "process?); set AUDIOCAPTION_GRU_ALGO=single")
         if int(host_flags[0]) != 0:
@@ -264,7 +269,9 @@ class TransformerModel(CaptionModel):
         pending._lazy = (dict(input_dict), enc, enc_done)
         if getattr(self, "_lazy_queue", None) is None:
             self._lazy_queue = []
-        self._lazy_queue.append(pending)
+        # weak references: a handle the caller dropped without asking for its result() must not keep its encoder outputs alive
+        self._lazy_queue = [r for r in self._lazy_queue if r() is not None and r()._lazy is not None]
+        self._lazy_queue.append(weakref.ref(pending))
         return pending
 
     @staticmethod
@@ -281,7 +288,8 @@ class TransformerModel(CaptionModel):
         clips do).  Unlike the 64-row greedy chain, the search over 384 rows is no pure latency chain: measured on
         EffB2-Trm (128 clips, beam 3) two submissions as one search cost 8.8 ms per submission against 7.9 ms separately,
         so grouping stays opt-in."""
-        queue = getattr(self, "_lazy_queue", None) or []
+        refs = getattr(self, "_lazy_queue", None) or []
+        queue = [q for q in (r() for r in refs) if q is not None and q._lazy is not None]
         # AUDIOCAPTION_BEAM_CONCURRENT=n (default 1): the searches of n consecutive submissions run side by side, each on
         # its own decode stream over its own static buffers, driven in lockstep by this thread.  Measured on EffB2-Trm
         # (128 clips, beam 3): 9.4 ms per submission with two searches in flight, 8.9 with three, 7.7 one by one - the
@@ -302,8 +310,7 @@ class TransformerModel(CaptionModel):
         items = [g._lazy for g in group]
         for g in group:
             g._lazy = None
-            if g in queue:
-                queue.remove(g)
+        self._lazy_queue = [r for r in refs if r() is not None and r()._lazy is not None]
         enc_s, dec_s = self._streams
         if len(items) > 1 and not merge:
             return self._run_concurrent(group, items)

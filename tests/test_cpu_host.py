@@ -239,3 +239,46 @@ def test_product_code_never_imports_the_oracle():
     assert not offenders, offenders
     bench = open(os.path.join(REPO, "bench.py")).read()
     assert len(pat.findall(bench)) == 1 and "cpu_baseline" in bench[bench.index("from oracle"):][:3000]
+
+
+def test_contrastive_kd_wrapper_loss():
+    """ContraEncoderKdWrapper (hf_wrapper.py:1071-1112): with ``tchr_output`` the symmetric contrastive loss between the
+    projected clip embedding and the projected teacher embedding comes back as ``enc_kd_loss`` - checked against the
+    formula in float64 numpy; ``unsup`` routes through the encoder only.  (The captioner is a stub: no GPU here.)"""
+    from audiocaption_amd.hf_wrapper import ContraEncoderKdWrapper
+
+    class Enc(torch.nn.Module):
+        fc_emb_size = 24
+
+        def forward(self, d):
+            return {"fc_emb": d["feat"], "from": "encoder"}
+
+    class Cap(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.encoder = Enc()
+
+        def forward(self, d):
+            return {"fc_emb": d["feat"] * 2.0, "from": "model"}
+
+    torch.manual_seed(3)
+    w = ContraEncoderKdWrapper(Cap(), shared_dim=16, tchr_dim=12)
+    assert abs(float(w.logit_scale) - np.log(1 / 0.07)) < 1e-6
+    feat, tchr = torch.randn(5, 24), torch.randn(5, 12)
+    for unsup, scale in ((False, 2.0), (True, 1.0)):
+        out = w({"feat": feat, "unsup": unsup, "tchr_output": {"embedding": tchr}})
+        assert out["from"] == ("encoder" if unsup else "model")
+        s = (feat.double().numpy() * scale) @ w.stdnt_proj.weight.double().detach().numpy().T + w.stdnt_proj.bias.double().detach().numpy()
+        t = tchr.double().numpy() @ w.tchr_proj.weight.double().detach().numpy().T + w.tchr_proj.bias.double().detach().numpy()
+        s /= np.linalg.norm(s, axis=1, keepdims=True)
+        t /= np.linalg.norm(t, axis=1, keepdims=True)
+        z = float(w.logit_scale) * s @ t.T
+
+        def ce(z):
+            lse = np.log(np.exp(z - z.max(1, keepdims=True)).sum(1)) + z.max(1)
+            return float((lse - np.diag(z)).mean())
+        want = 0.5 * (ce(z) + ce(z.T))
+        assert abs(float(out["enc_kd_loss"]) - want) < 1e-5
+    assert "enc_kd_loss" not in w({"feat": feat})
+    out["enc_kd_loss"].backward()
+    assert w.stdnt_proj.weight.grad is not None and w.logit_scale.grad is not None

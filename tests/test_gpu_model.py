@@ -696,3 +696,21 @@ def _worst_logit_error(hip_model, state4981, seconds):
     print(f"{seconds} s clips ({want['attn_emb_len'].tolist()} frames), tier {hip_model.encoder.cnn.conv_algo}: "
           f"worst |logit diff| over 5 seeds {worst:.2e}")
     return worst
+
+
+def test_dropped_beam_handles_do_not_pile_up(hip_model):
+    """forward_async(sample_method="beam") keeps the submitted batch until result() is asked for: the model only holds WEAK
+    references, so a handle the caller dropped takes its encoder outputs with it, and later handles still resolve."""
+    import gc
+    from audiocaption_amd import procedural as P
+    w = torch.from_numpy(P.synthetic_wav(2, 48000, seed=21, varied=True)).cuda()
+    inp = {"mode": "inference", "wav": w, "wav_len": [48000, 40000], "specaug": False, "sample_method": "beam",
+           "beam_size": 3, "max_length": 6}
+    want = hip_model(dict(inp))
+    for _ in range(5):
+        hip_model.forward_async(dict(inp))            # dropped at once
+    gc.collect()
+    keep = hip_model.forward_async(dict(inp))
+    assert len(hip_model._lazy_queue) == 1
+    assert torch.equal(keep.result()["seq"], want["seq"])
+    assert len(hip_model._lazy_queue) == 0

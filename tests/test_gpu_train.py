@@ -773,3 +773,35 @@ def test_changing_batch_shapes_share_one_workspace(train_model):
     grown = torch.cuda.memory_allocated() - mem0
     print(f"memory growth over 24 shapes: {grown / 2**20:.0f} MiB, states {len(eng._states)}, workspace generation {eng._wsg.gen}")
     assert grown < 3 * 2**30
+
+
+def test_split_gru_timeout_skips_the_update_on_the_device(train_model):
+    """A partner timeout of the split GRU kernel (sticky error word of its exchange area) must not reach the parameters:
+    the word is folded into the clip state's non-finite flag on the device, the update is skipped like a NaN loss
+    (run.py:123), ``gru_timeout()`` reports and clears it, and training goes on."""
+    from audiocaption_amd import procedural as Pr
+    from audiocaption_amd.optim import FusedAdam
+    from audiocaption_amd.train import TrainEngine
+    model = train_model
+    B, L = 2, 96000
+    wav = torch.from_numpy(Pr.synthetic_wav(B, L, seed=4)).cuda()
+    cap = torch.tensor([[1, 9, 30, 2, 0], [1, 7, 7, 12, 2]])
+    batch = {"mode": "train", "wav": wav, "wav_len": [L] * B, "specaug": False, "cap": cap.cuda(),
+             "cap_len": np.array([4, 5]), "ss_ratio": 0.9}
+    eng = TrainEngine(model)
+    if eng.gru_algo != "split":
+        pytest.skip("single-workgroup GRU: no partner protocol")
+    opt = FusedAdam([p for p in model.parameters() if p.requires_grad], lr=1e-3)
+    for _ in range(3):                                   # eager, capture, replay
+        eng.step(batch, opt)
+    assert eng.gru_timeout() is False
+    st = next(iter(eng._states.values()))
+    before = eng.flat.flat.clone()
+    eng._gru_error_word(st).fill_(1)                    # what a timed-out workgroup leaves behind
+    r = eng.step(batch, opt)
+    assert np.isfinite(float(r["loss"]))
+    assert torch.equal(eng.flat.flat, before)
+    assert all(int(v["step"]) == 3 for v in opt.state_dict()["state"].values())
+    assert eng.gru_timeout() is True and eng.gru_timeout() is False
+    eng.step(batch, opt)
+    assert not torch.equal(eng.flat.flat, before)
