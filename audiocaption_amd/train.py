@@ -124,16 +124,72 @@ def dist_world_size(process_group=None):
     return dist.get_world_size(process_group)
 
 
-def allreduce_flat_gradients(flat_grad, process_group=None, async_op=False):
+class _RsAgWork:
+    """Handle of a reduce-scatter + all-gather pair (and the all-reduce of the few trailing elements): ``wait()`` like a
+    torch work handle.  On RCCL both collectives are issued at once (stream-ordered on the communicator's stream); a
+    backend whose asynchronous operations may run concurrently (gloo) gets the all-gather issued once the scatter is in."""
+
+    def __init__(self, first, then, extra):
+        self._first, self._then, self._extra = first, then, extra
+
+    def wait(self):
+        for w in self._first:
+            if w is not None:
+                w.wait()
+        for w in self._then():
+            if w is not None:
+                w.wait()
+        if self._extra is not None:
+            self._extra.wait()
+        return True
+
+
+_RS_SHARDS = {}
+
+
+def allreduce_flat_gradients(flat_grad, process_group=None, async_op=False, algo=None):
     """Sum (a slice of) the flat gradient buffer over the ranks - the reference's DDP gradient all-reduce
     (run_ddp.py:98-108) as ONE collective per slice instead of per-parameter buckets - and return the world size (or,
     with ``async_op``, the work handle, None for a single rank); the division by the world size is folded into the clip
-    coefficient (``clip_grad_norm_(..., grad_div=world)``).  No-op without an initialised process group."""
+    coefficient (``clip_grad_norm_(..., grad_div=world)``).  No-op without an initialised process group.
+
+    ``algo`` (default AUDIOCAPTION_GRAD_SYNC, "all_reduce"): "rs_ag" spells the sum out as ``reduce_scatter_tensor`` into
+    this rank's 1/N shard followed by ``all_gather_into_tensor`` back into the slice (the < N trailing elements that do not
+    divide go through a tiny all-reduce).  Same sums, same bytes per link as a ring all-reduce; it exists so that the two
+    halves are separate collectives on the wire of a fully connected xGMI node (7 links per GPU: each of the N - 1 peers
+    receives its shard directly) and so that later work can sit between them.  Bit-equal to "all_reduce" for two ranks
+    (tests/test_train_oracle.py, tests/test_gpu_train_ddp.py)."""
     import torch.distributed as dist
     world = dist_world_size(process_group)
     work = None
     if world > 1:
-        work = dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=process_group, async_op=async_op)
+        algo = algo or os.environ.get("AUDIOCAPTION_GRAD_SYNC", "all_reduce")
+        if algo == "all_reduce":
+            work = dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=process_group, async_op=async_op)
+        elif algo == "rs_ag":
+            n = flat_grad.numel()
+            body = n - n % world
+            key = (flat_grad.device, body // world)
+            shard = _RS_SHARDS.get(key)
+            if shard is None:
+                shard = _RS_SHARDS[key] = torch.empty(body // world, device=flat_grad.device, dtype=flat_grad.dtype)
+            head, tail = flat_grad[:body], flat_grad[body:]
+            extra = dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=process_group, async_op=async_op) if n > body else None
+            ordered = dist.get_backend(process_group) == "nccl"
+            first = [dist.reduce_scatter_tensor(shard, head, op=dist.ReduceOp.SUM, group=process_group, async_op=async_op)] if body else []
+
+            def gather():
+                return [dist.all_gather_into_tensor(head, shard, group=process_group, async_op=async_op)] if body else []
+
+            if not async_op:
+                gather()
+            elif ordered:
+                second = gather()
+                work = _RsAgWork(first + second, lambda: [], extra)
+            else:
+                work = _RsAgWork(first, gather, extra)
+        else:
+            raise ValueError(f"AUDIOCAPTION_GRAD_SYNC={algo!r}: 'all_reduce' or 'rs_ag'")
     return work if async_op else world
 
 

@@ -152,6 +152,22 @@ class Ranks:
                 dist.init_process_group(self.backend)
             self.dist = dist
 
+    def describe(self):
+        """One record per rank (gathered on every rank): which device it runs on - so that an N-GPU line shows that the
+        ranks really sat on N different GPUs."""
+        me = {"rank": self.rank, "local_rank": self.local_rank, "device": str(self.dev), "host": socket.gethostname(),
+              "pid": os.getpid()}
+        if self.gpu:
+            pr = torch.cuda.get_device_properties(self.dev)
+            me.update({"name": pr.name, "gcn_arch": getattr(pr, "gcnArchName", None),
+                       "uuid": str(getattr(pr, "uuid", "")) or None, "pci_bus_id": getattr(pr, "pci_bus_id", None),
+                       "visible": os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES"))})
+        if self.dist is None:
+            return [me]
+        got = [None] * self.world
+        self.dist.all_gather_object(got, me)
+        return got
+
     def sync_all(self):
         if self.gpu:
             torch.cuda.synchronize()
@@ -180,7 +196,8 @@ def timed_steps(ranks, run, steps):
     t0 = time.perf_counter()
     out = run(steps)
     ranks.sync_all()
-    return ranks.max_seconds(time.perf_counter() - t0), out
+    ranks.last_own = time.perf_counter() - t0   # this rank's own clock (the line reports the MAX over ranks)
+    return ranks.max_seconds(ranks.last_own), out
 
 
 def bench_stub(args, ranks):
@@ -197,7 +214,8 @@ def bench_stub(args, ranks):
 
     run(args.warmup)
     elapsed, _ = timed_steps(ranks, run, args.steps)
-    return {"metric": "stub steps/sec (launch plumbing only)", "value": ranks.world * args.steps / elapsed, "unit": "steps/s",
+    who = ranks.describe()      # collective: every rank calls it
+    return {"ranks": who, "metric": "stub steps/sec (launch plumbing only)", "value": ranks.world * args.steps / elapsed, "unit": "steps/s",
             "n_gpus": ranks.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "stub (no HIP path): one 128x128 CPU matmul per step", "backend": ranks.backend,
@@ -326,6 +344,9 @@ def bench_train(args, ranks, steps, warmup, with_rccl=False):
     }
     if rccl is not None:
         res["rccl"] = rccl
+    if world > 1:
+        res["ranks"] = ranks.describe()
+        res["config"]["gradient_sync_algo"] = os.environ.get("AUDIOCAPTION_GRAD_SYNC", "all_reduce")
     return res
 
 
@@ -356,8 +377,25 @@ def time_allreduce(ranks, flat_grad):
         ms = e0.elapsed_time(e1) / n
         world = dist.get_world_size()
         nbytes = buf.numel() * 4
+        # the same sum spelled as reduce_scatter + all_gather (AUDIOCAPTION_GRAD_SYNC=rs_ag, audiocaption_amd/train.py)
+        from audiocaption_amd.train import allreduce_flat_gradients
+        rs_ms = None
+        if world > 1:
+            for _ in range(2):
+                allreduce_flat_gradients(buf, algo="rs_ag")
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(n):
+                allreduce_flat_gradients(buf, algo="rs_ag")
+            e1.record()
+            torch.cuda.synchronize()
+            rs_ms = e0.elapsed_time(e1) / n
+        bus = lambda t: (2.0 * (world - 1) / world) * nbytes / (t * 1e-3) / 1e9 if world > 1 and t else None
         return {"world_size": world, "backend": dist.get_backend(), "all_reduce_ms": ms, "bytes": nbytes,
-                "bus_gbs": (2.0 * (world - 1) / world) * nbytes / (ms * 1e-3) / 1e9 if world > 1 else None}
+                "bus_gbs": bus(ms), "rs_ag_ms": rs_ms, "rs_ag_bus_gbs": bus(rs_ms),
+                "grad_sync": os.environ.get("AUDIOCAPTION_GRAD_SYNC", "all_reduce"),
+                "xgmi_note": "8 GPUs fully connected, 7 links x ~153 GB/s per GPU: a ring is bound by ONE link per hop, "
+                             "direct reduce-scatter / all-gather can use all 7"}
     except Exception as e:  # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}"}
     finally:
@@ -635,6 +673,8 @@ def main():
             res = bench_train(args, ranks, args.steps, max(args.warmup, 3), with_rccl=True)
         else:
             res = bench_effb2(args, ranks, args.steps, max(args.warmup, 1))
+            if world > 1:
+                res["ranks"] = ranks.describe()
         if rank == 0:
             print(json.dumps(res), flush=True)
         ranks.finish()
@@ -732,6 +772,7 @@ def main():
             run_steps(n_prime)
     # ---- timed region: exactly K steps of the default tier ----
     elapsed, out, events = measure(default_tier, args.steps, args.warmup)
+    elapsed_own = ranks.last_own
     ref_steps = min(int((out["unfinished_cnt"].cpu() > 0).sum().item()) + 1, args.max_length)
     headline_roof = conv_roofline(default_tier, events)
     tiers = {default_tier: {"value": world * B * args.steps / elapsed, "unit": "clips/s", "ms_per_step": elapsed / args.steps * 1e3,
@@ -834,6 +875,17 @@ def main():
                                                       "encoder_roofline")}
         except Exception as e:  # noqa: BLE001
             extra["effb2_trm"] = {"error": f"{type(e).__name__}: {e}"}
+    multi = None
+    if world > 1:
+        # N > 1: the inference path has no collective (clips are sharded), so the line carries what makes the run
+        # self-describing - where every rank sat, its own time, and the node's collective rates on a buffer of the
+        # training step's gradient size (42.8 MB) - next to the max-over-ranks headline
+        own = torch.tensor([elapsed_own], dtype=torch.float64, device=dev if ranks.backend == "nccl" else "cpu")
+        every = [torch.zeros_like(own) for _ in range(world)]
+        ranks.dist.all_gather(every, own)
+        multi = {"ranks": ranks.describe(), "seconds_per_rank": [float(t) for t in every],
+                 "rccl": time_allreduce(ranks, torch.zeros(10_700_000, device=dev)) if ranks.backend == "nccl" else
+                         {"backend": ranks.backend, "world_size": world}}
     if rank == 0:
         clips = world * B * args.steps
         val = lambda d_, k="value": (d_ or {}).get(k) if isinstance(d_, dict) else None
@@ -888,6 +940,8 @@ def main():
             "effb2_trm_clips_per_s": val(extra.get("effb2_trm")),
             "logmel_hbm_frac": extra["mel_roofline"]["frac"],
         }
+        if multi is not None:
+            result.update({"ranks": multi["ranks"], "seconds_per_rank": multi["seconds_per_rank"], "rccl": multi["rccl"]})
         details = {"tiers": tiers, "steady_state": steady, "blocking_model_call": blocking, "latency_b1_ms": latency,
                    "rooflines_other": {"logmel": extra["mel_roofline"], "decoder": extra["decoder_roofline"]},
                    "train_step": extra.get("train_step"), "effb2_trm": extra.get("effb2_trm")}

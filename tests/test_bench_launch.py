@@ -28,6 +28,8 @@ def test_bench_gpus_2_self_spawns_two_ranks():
     assert res["n_gpus"] == 2 and res["steps"] == 4 and res["warmup"] == 1
     assert res["config"]["backend"] == "gloo" and res["config"]["requested_gpus"] == 2
     assert res["scaling"] == "weak" and res["value"] > 0 and res["ms_per_step"] > 0
+    # the line says where every rank sat (two different processes, ranks 0 and 1)
+    assert [r["rank"] for r in res["ranks"]] == [0, 1] and res["ranks"][0]["pid"] != res["ranks"][1]["pid"]
 
 
 def test_bench_under_a_launcher_reads_the_ranks_from_the_environment():

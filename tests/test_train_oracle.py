@@ -88,7 +88,18 @@ def _allreduce_worker(rank, world, port, out):
         # the division by the world size is folded into the clip coefficient (csrc/train.hip clip_coef_kernel)
         norm = float((flat / w).norm())
         coef = min(1.0, 1.0 / (norm + 1e-6)) / w
-        out.put((rank, w, flat.clone(), coef))
+        # reduce-scatter + all-gather spelling of the same sum: odd lengths (a tail that does not divide), blocking and
+        # asynchronous, on random data - bit-equal to the all-reduce
+        same = True
+        for n in (1001, 7, 1, 4096):
+            g = torch.Generator().manual_seed(100 * rank + n)
+            x = torch.randn(n, generator=g)
+            a, b, c = x.clone(), x.clone(), x.clone()
+            allreduce_flat_gradients(a, algo="all_reduce")
+            assert allreduce_flat_gradients(b, algo="rs_ag") == world
+            allreduce_flat_gradients(c, async_op=True, algo="rs_ag").wait()
+            same = same and torch.equal(a, b) and torch.equal(a, c)
+        out.put((rank, w, flat.clone(), coef, same))
     finally:
         dist.destroy_process_group()
 
@@ -105,10 +116,11 @@ def test_flat_gradient_allreduce_world2_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     want = torch.arange(1000, dtype=torch.float32) * 3
-    for rank, w, flat, coef in res:
+    for rank, w, flat, coef, same in res:
         assert w == 2 and torch.equal(flat, want)
         avg = want / 2
         assert coef * 2 == pytest.approx(min(1.0, 1.0 / (float(avg.norm()) + 1e-6)))
+        assert same, "reduce_scatter + all_gather differs from all_reduce"
 
 
 def test_scheduled_sampling_ratio_follows_run_py():
