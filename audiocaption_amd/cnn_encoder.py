@@ -39,10 +39,15 @@ def cnn14_feat_len(wav_len, hop, ratio=32):
     return torch.div(n, ratio, rounding_mode="floor").long()
 
 
+def wino1d_covers(cout):
+    """Layers the F(2,3) kernel runs: 128-channel column tiles, and the 64-channel / 16-column form of conv2 of block 1
+    (AUDIOCAPTION_W1_C64=0 sends that layer back to the direct split-bf16 kernel).  Anything else: direct split-bf16."""
+    return cout % 128 == 0 or (cout == 64 and os.environ.get("AUDIOCAPTION_W1_C64", "1") != "0")
+
+
 def _conv_wino1d(x, w, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode=-1, need=None):
-    """The "wino1d" tier's launcher: the F(2,3) kernel covers 128-channel column tiles; conv2 of block 1 (Cout = 64)
-    runs on the direct split-bf16 kernel (``_pack`` packs its weights for that kernel)."""
-    if Cout % 128:
+    """The "wino1d" tier's launcher (``_pack`` packs a layer's weights for the kernel ``wino1d_covers`` names)."""
+    if not wino1d_covers(Cout):
         return K.conv3x3_bn_relu_bf16x3_gw(x, w, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode)
     return K.conv3x3_bn_relu_wino1d(x, w, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode, need=need)
 
@@ -154,7 +159,7 @@ class Cnn14Encoder(nn.Module):
                         wp = K.pack_conv_weight_winograd(w)
                     elif algo == "direct":
                         wp = K.pack_conv_weight(w)
-                    elif algo == "bf16x3" or (algo == "wino1d" and w.shape[0] % 128):
+                    elif algo == "bf16x3" or (algo == "wino1d" and not wino1d_covers(w.shape[0])):
                         wp = K.pack_conv_weight_bf16x3_frag(w)
                     elif algo == "wino1d":
                         wp = K.pack_conv_weight_wino1d_frag(w)
@@ -288,7 +293,7 @@ class Cnn14Encoder(nn.Module):
                 conv(pooled, w1, s1, t1, full, B, Hp[b], H[b], W, cin, cout, 0, **need(b + 1, 1))
             if b < 5:
                 if not (b == 0 and fuse1):
-                    conv(full, w2, s2, t2, pool_out, B, Hp[b], H[b], W, cout, cout, 1, **(need(b + 1, 2) if cout % 128 == 0 else {}))
+                    conv(full, w2, s2, t2, pool_out, B, Hp[b], H[b], W, cout, cout, 1, **(need(b + 1, 2) if algo != "wino1d" or wino1d_covers(cout) else {}))
                 pooled = pool_out
                 W //= 2
                 if dropout is not None:

@@ -30,6 +30,9 @@
 //   * W >= 8 (blocks 2-4: short K, many pixels): 256-thread workgroups of 128 pixels (16 pairs x 4 columns) x 128
 //     channels, TWO per CU, so that one's prologue / epilogue (a third of a workgroup's life at K = 64...256) runs under
 //     the other's MFMAs; a tile is 16 pairs x 2 columns.
+//   * Cout = 64 (conv2 of block 1, W = 64): the same 256-thread form over 8 pairs x 16 columns x 64 channels - waves =
+//     2 channel groups x 2 column halves, a tile is 8 pairs x 4 columns (18 x 18 staged positions for 16 x 16 outputs:
+//     the smallest halo of all forms; 78 KB of planes, two workgroups per CU).
 #include <type_traits>
 
 #include "ac_common.h"
@@ -38,6 +41,30 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// Development only (tools/w1_knockout.py): -DW1_KO=<bits> removes one ingredient of the K loop at a time to price it
+// (results are then wrong).  1 weight loads, 2 A-fragment reads, 4 plane stores, 8 patch loads, 16 barrier, 32 MFMAs.
+#ifndef W1_KO
+#define W1_KO 0
+#endif
+// Tuning switches of the same tool: raw-row register sets of the wide form, depth of the weight ring (groups ahead + 1),
+// MFMA / VALU interleaving hints.
+#ifndef W1_NSET
+#define W1_NSET 1
+#endif
+#ifndef W1_RING
+#define W1_RING 3
+#endif
+#ifndef W1_SGB
+#define W1_SGB 0
+#endif
+#ifndef W1_PRIO
+#define W1_PRIO 0
+#endif
+
+#ifdef W1_CLK   // development: shader-clock cycles and 100 MHz ticks spent between kernel entry and the end of the K loop
+__device__ unsigned long long w1_clk[4];
+#endif
 
 constexpr int KS = 16;          // input channels per K step (one MFMA k-step); the packed weights come in chunks of 32
 constexpr int BROW = KS;        // bf16 elements per (pair, column) item in LDS: 32 bytes = 2 bank slots
@@ -136,9 +163,10 @@ __device__ __forceinline__ bool block_map(const W1Params& p, int& m_tile, int& n
 //   pairs of one column + 8 of the next) land in 16 different slots.
 template <int TC, bool FULLW, bool WIDE>
 struct W1Geom {
-  static_assert(!WIDE || (TC == 4 && !FULLW), "the wide form is 4 columns with halo");
+  static_assert(!WIDE || ((TC == 4 || TC == 16) && !FULLW), "the wide forms are 4 or 16 columns with halo");
+  static constexpr bool C64 = TC == 16;                    // the 64-channel form (conv2 of block 1): see the kernel
   static constexpr int THREADS = WIDE ? 256 : 512;
-  static constexpr int PR = WIDE ? 16 : 128 / TC;          // pair rows per block
+  static constexpr int PR = WIDE ? (C64 ? 8 : 16) : 128 / TC;   // pair rows per block
   static constexpr int COFF = FULLW ? 1 : 0;
   static constexpr int PWS = TC + 2 - 2 * COFF;            // staged columns: image columns col0 - 1 + COFF ..
   static constexpr int PAIR_PITCH = WIDE ? BROW : PWS * BROW + 8;
@@ -146,10 +174,11 @@ struct W1Geom {
   static constexpr int PLANE = WIDE ? PWS * COL_PITCH : PR * PAIR_PITCH;   // one (position, hi | lo) plane
   static constexpr int VBUF = 8 * PLANE;
   // staging item = NP vertically adjacent pairs x one staged column x one channel quad: 2 NP + 2 input rows
-  static constexpr int NP = FULLW ? 1 : 2;
+  static constexpr int NP = FULLW ? 1 : (C64 ? 4 : 2);
   static constexpr int NROW = 2 * NP + 2;
   static constexpr int NITEM = (PR / NP) * PWS * (KS / 4);
   static_assert(NITEM <= THREADS, "one staging item per thread");
+  static constexpr int NSET = WIDE ? W1_NSET : 1;                // register sets of raw rows in flight (see the kernel)
 };
 
 template <int MODE, int TC, bool FULLW, bool WIDE>
@@ -162,11 +191,15 @@ __global__ __launch_bounds__((W1Geom<TC, FULLW, WIDE>::THREADS), 2) void conv3x3
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform for the compiler: scalar branches below
-  const int wn = wave & 3, wg = wave >> 2;
+  constexpr bool C64 = G::C64;
+  const int wn = C64 ? (wave & 1) : (wave & 3), wg = C64 ? (wave >> 1) : (wave >> 2);
   const int half = lane >> 5;
 
   int m_tile, n_tile;
   if (!block_map(p, m_tile, n_tile)) return;
+#ifdef W1_CLK
+  const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int pair0 = (m_tile / p.mt_cols) * PR;
   const int col0 = (m_tile % p.mt_cols) * TC;
   const bool at_left = col0 == 0, at_right = col0 + TC == p.W;
@@ -174,15 +207,16 @@ __global__ __launch_bounds__((W1Geom<TC, FULLW, WIDE>::THREADS), 2) void conv3x3
 
   // this wave's two tiles.  !WIDE: 32 pairs of one column each - TC = 4: columns 2 wg, 2 wg + 1; TC = 2: columns 0, 1 of
   // pair group wg.  WIDE (wg = 0): tile m = 16 pairs x columns 2 m, 2 m + 1; MFMA row i = pair i & 15 of column i >> 4
+  // C64: tile m of column half wg = 8 pairs x columns 8 wg + 4 m .. + 3; MFMA row i = pair i & 7 of column i >> 3
   const int mrow = (WIDE || TC == 4) ? 0 : wg * 32;
-  const int mcol0 = (!WIDE && TC == 4) ? 2 * wg : 0;
+  const int mcol0 = C64 ? 8 * wg : ((!WIDE && TC == 4) ? 2 * wg : 0);
   int pbase[MW];
   {
     const int i = lane & 31;
-    const int pr = WIDE ? (i & 15) : mrow + i, dc = WIDE ? (i >> 4) : 0;
+    const int pr = C64 ? (i & 7) : (WIDE ? (i & 15) : mrow + i), dc = C64 ? (i >> 3) : (WIDE ? (i >> 4) : 0);
 #pragma unroll
     for (int m = 0; m < MW; ++m)
-      pbase[m] = pr * PAIR_PITCH + (mcol0 + (WIDE ? 2 * m : m) + dc - COFF) * COL_PITCH + half * 8;
+      pbase[m] = pr * PAIR_PITCH + (mcol0 + (C64 ? 4 * m : (WIDE ? 2 * m : m)) + dc - COFF) * COL_PITCH + half * 8;
   }
 
   f32x16 acc[4][MW];
@@ -224,7 +258,7 @@ __global__ __launch_bounds__((W1Geom<TC, FULLW, WIDE>::THREADS), 2) void conv3x3
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
         (void*)p.wpk, 0, (int)((unsigned)(p.Cin / 32) * 24u * ks_bytes), 0x00020000);
     // weight fragment of (K step s = 2 chunk + k-step, group gi = kx * 4 + p, plane) for this wave's 32 channels
-    const unsigned wvoff = (unsigned)((n_tile * 4 + wn) * 2048 + lane * 16);
+    const unsigned wvoff = (unsigned)((n_tile * (C64 ? 2 : 4) + wn) * 2048 + lane * 16);
     auto w_load = [&](int s, int gi, bf16x8 (&w)[2]) {
       const unsigned soff = (unsigned)(((s >> 1) * 12 + gi) * 2 + (s & 1)) * ks_bytes;
       w[0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff, soff, 0));
@@ -245,18 +279,24 @@ __global__ __launch_bounds__((W1Geom<TC, FULLW, WIDE>::THREADS), 2) void conv3x3
       lofs = (unsigned)(pr * PAIR_PITCH + pc * COL_PITCH + q * 4);
     }
     const unsigned row_bytes = (unsigned)(p.W * p.Cin) * 4u;
-    f32x4 pre[NROW];
-    auto patch_request = [&](int s) {
+    // Raw rows of the step(s) ahead.  WIDE keeps TWO sets: the rows of step s + 2 are requested at the top of step s and
+    // transformed during step s + 1, i.e. the request has a whole step plus four groups (~3000 cycles) to come back from
+    // HBM; with one set (the 512-thread forms, whose registers are spoken for) it has four groups (~770 cycles).
+    constexpr int NSET = G::NSET;
+    f32x4 pre[NSET][NROW];
+    auto patch_request = [&](int s, auto SET_) {
+      constexpr int st = decltype(SET_)::value;
       const unsigned v0 = vbase + (unsigned)(s * KS * 4);
 #pragma unroll
       for (int r = 0; r < NROW; ++r)
-        pre[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, v0 + (unsigned)r * row_bytes, 0, 0));
+        pre[st][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, v0 + (unsigned)r * row_bytes, 0, 0));
     };
     // one of the 4 NP (pair, position) pieces of the item: transform, split, two 8-byte LDS stores
-    auto commit_piece = [&](__bf16* buf, int piece) {
+    auto commit_piece = [&](__bf16* buf, int piece, auto SET_) {
+      constexpr int st = decltype(SET_)::value;
       if (!has_item) return;
       const int e = piece >> 2, q = piece & 3;
-      const f32x4 d0 = pre[2 * e], d1 = pre[2 * e + 1], d2 = pre[2 * e + 2], d3 = pre[2 * e + 3];
+      const f32x4 d0 = pre[st][2 * e], d1 = pre[st][2 * e + 1], d2 = pre[st][2 * e + 2], d3 = pre[st][2 * e + 3];
       const f32x4 v = q == 0 ? d0 - d2 : (q == 1 ? d1 + d2 : (q == 2 ? d2 - d1 : d1 - d3));
       u32x2 hi, lo;
       split_bf16x4(v, hi, lo);
@@ -266,12 +306,17 @@ __global__ __launch_bounds__((W1Geom<TC, FULLW, WIDE>::THREADS), 2) void conv3x3
     };
 
     // prologue: step 0 into buffer 0
-    bf16x8 wr[3][2];   // ring of weight fragments: group gi lives in wr[gi % 3]
-    w_load(0, 0, wr[0]);
-    w_load(0, 1, wr[1]);
-    patch_request(0);
+    constexpr int RING = W1_RING;   // 12 % RING == 0: the ring position of a group is static
+    static_assert(12 % RING == 0, "ring");
+    bf16x8 wr[RING][2];   // ring of weight fragments: group gi lives in wr[gi % RING], requested RING - 1 groups ahead
 #pragma unroll
-    for (int piece = 0; piece < 4 * NP; ++piece) commit_piece(sV, piece);
+    for (int g0 = 0; g0 < RING - 1; ++g0) w_load(0, g0, wr[g0]);
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, NSET - 1>;
+    patch_request(0, I0{});
+    if (NSET == 2 && nstep > 1) patch_request(1, I1{});
+#pragma unroll
+    for (int piece = 0; piece < 4 * NP; ++piece) commit_piece(sV, piece, I0{});
     __syncthreads();
 
     // SL / SR (compile time): this wave's tile 0 is the first / its tile 1 the last column of the IMAGE, whose kx = 0 /
@@ -290,37 +335,75 @@ __global__ __launch_bounds__((W1Geom<TC, FULLW, WIDE>::THREADS), 2) void conv3x3
         }
       };
       bf16x8 af[2][MW][2];   // A fragments (tile, hi | lo) of the current and the next group
-#pragma unroll 1
-      for (int s = 0; s < nstep; ++s) {
+      // one K step.  NXT_: the register set that holds the raw rows of step s + 1 (NSET == 2: requested a step ago; the
+      // set they leave behind at the end of this step is the one step s + 3 will use, the other one is free NOW for s + 2)
+      auto step = [&](int s, auto NXT_) {
+        constexpr int nx = decltype(NXT_)::value;
+        using Other = std::integral_constant<int, NSET == 2 ? 1 - nx : 0>;
         const __bf16* cur = sV + (s & 1) * VBUF;
         __bf16* nxt = sV + ((s + 1) & 1) * VBUF;
         const bool more = s + 1 < nstep;
-        if (more) patch_request(s + 1);
-        a_load(cur, 0, af[0]);
+        if (!(W1_KO & 8)) {
+          if (NSET == 2) { if (s + 2 < nstep) patch_request(s + 2, Other{}); }
+          else if (more) patch_request(s + 1, NXT_);
+        }
+        if (!(W1_KO & 2) || s == 0) a_load(cur, 0, af[0]);
 #pragma unroll
         for (int gi = 0; gi < 12; ++gi) {
           const int kx = gi >> 2, q = gi & 3;
           // the next group's fragments are requested before this group's MFMAs; weights two groups ahead (the ring
           // position of a group is static: 12 % 3 == 0)
-          if (gi + 1 < 12) a_load(cur, gi + 1, af[(gi + 1) & 1]);
-          if (gi + 2 < 12) w_load(s, gi + 2, wr[(gi + 2) % 3]);
-          else if (more) w_load(s + 1, gi + 2 - 12, wr[(gi + 2) % 3]);
+          if (gi + 1 < 12 && (!(W1_KO & 2) || (s == 0 && gi == 0))) a_load(cur, gi + 1, af[(gi + 1) & 1]);
+          if (!(W1_KO & 1) || (s == 0 && gi == 0)) {
+            constexpr int AH = RING - 1;
+            if (gi + AH < 12) w_load(s, gi + AH, wr[(gi + AH) % RING]);
+            else if (more) w_load(s + 1, gi + AH - 12, wr[(gi + AH) % RING]);
+          }
+          if (W1_PRIO) __builtin_amdgcn_s_setprio(W1_PRIO);   // the wave that has its operands issues its MFMAs first
 #pragma unroll
           for (int m = 0; m < MW; ++m) {
             if ((kx == 0 && m == 0 && SL) || (kx == 2 && m == 1 && SR)) continue;
             const bf16x8 ah = af[gi & 1][m][0], al = af[gi & 1][m][1];
-            acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wr[gi % 3][0], acc[q][m], 0, 0, 0);
-            acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wr[gi % 3][1], acc[q][m], 0, 0, 0);
-            acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wr[gi % 3][0], acc[q][m], 0, 0, 0);
+            if (W1_KO & 32) {   // keep the operands alive without the matrix instructions
+              asm volatile("" :: "v"(ah), "v"(al), "v"(wr[gi % RING][0]), "v"(wr[gi % RING][1]));
+              continue;
+            }
+            acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wr[gi % RING][0], acc[q][m], 0, 0, 0);
+            acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wr[gi % RING][1], acc[q][m], 0, 0, 0);
+            acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wr[gi % RING][0], acc[q][m], 0, 0, 0);
           }
-          // the next step's planes, a piece per group (the raw rows were requested at the top of the step)
+          if (W1_PRIO) __builtin_amdgcn_s_setprio(0);
+          // the next step's planes, a piece per group
           if (more) {
-            constexpr int FIRST = 12 - 4 * NP;
-            if (gi >= FIRST) commit_piece(nxt, gi - FIRST);
+            constexpr int PPG = NP > 2 ? NP / 2 : 1, FIRST = 12 - 4 * NP / PPG;   // NP = 4: two pieces per group
+            if (gi >= FIRST && !(W1_KO & 4)) {
+#pragma unroll
+              for (int k = 0; k < PPG; ++k) commit_piece(nxt, (gi - FIRST) * PPG + k, NXT_);
+            }
+          }
+          if (W1_SGB) {   // the group's requests first, then its VALU / LDS-store work spread between its MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // DS reads
+            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);   // VMEM reads
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // one MFMA
+              __builtin_amdgcn_sched_group_barrier(0x002, W1_SGB, 0);   // a few VALU
+            }
+            __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);   // DS writes
           }
           __builtin_amdgcn_sched_barrier(0);   // keep every group's requests and pieces inside the group
         }
-        lds_barrier();   // step s + 1 is complete in `nxt`; every wave is done reading `cur` (weight requests stay in flight)
+        if (!(W1_KO & 16)) lds_barrier();   // step s + 1 is complete in `nxt`; every wave is done reading `cur` (weight requests stay in flight)
+      };
+      if (NSET == 2) {
+#pragma unroll 1
+        for (int s = 0; s < nstep; s += 2) {
+          step(s, I1{});                        // step 1's rows went into set 1 in the prologue, step 2's go into set 0, ...
+          if (s + 1 < nstep) step(s + 1, I0{});
+        }
+      } else {
+#pragma unroll 1
+        for (int s = 0; s < nstep; ++s) step(s, I0{});
       }
     };
     using T_ = std::true_type;
@@ -337,22 +420,30 @@ __global__ __launch_bounds__((W1Geom<TC, FULLW, WIDE>::THREADS), 2) void conv3x3
     }
   }
 
+#ifdef W1_CLK
+  if (tid == 0) {
+    atomicAdd(&w1_clk[0], __builtin_readcyclecounter() - clk0);
+    atomicAdd(&w1_clk[1], __builtin_amdgcn_s_memrealtime() - rt0);
+    atomicAdd(&w1_clk[2], 1ull);
+  }
+#endif
   // ---- epilogue: output transform, BN, ReLU, pooling / mean, zero rows.  Lane l owns channel l % 32 and the MFMA rows
   // i = 8 (r / 4) + 4 (l / 32) + r % 4 of each tile: both rows of a pair, and the two columns of a pooling window / of the
   // last layer's mean - the wave's two tiles (!WIDE), registers r and r + 8 of one tile (WIDE) - sit in this lane ----
-  const int ch = n_tile * 128 + wn * 32 + (lane & 31);
+  const int ch = n_tile * (C64 ? 64 : 128) + wn * 32 + (lane & 31);
   const float sc = all_pad ? 0.f : p.scale[ch], sh = all_pad ? 0.f : p.shift[ch];   // dead blocks store zeros
   const FastDiv by_hp(p.Hp), by_hp_out(MODE == MODE_POOL ? p.Hp_out : 1);
 #pragma unroll
-  for (int r = 0; r < (WIDE ? 8 : 16); ++r) {
-    const int i = 8 * (r >> 2) + 4 * half + (r & 3);                      // WIDE: r < 8 -> i < 16 = the pair
+  for (int r = 0; r < (C64 ? 4 : (WIDE ? 8 : 16)); ++r) {
+    const int i = C64 ? 4 * half + r : 8 * (r >> 2) + 4 * half + (r & 3);   // WIDE: r < 8 -> i < 16 = the pair; C64: i < 8
     const int prow = pair0 + mrow + i;                                    // global pair index
-    // y[row of the pair][column slot]: !WIDE: slot = tile; WIDE: slot = 2 tile + (column inside the tile)
-    constexpr int NS = WIDE ? 4 : 2;
+    // y[row of the pair][column slot]: !WIDE: slot = tile; WIDE: slot = 2 tile + (column inside the tile); C64: slot =
+    // 4 tile + (column inside the tile), register 4 c + r of the tile
+    constexpr int NS = C64 ? 8 : (WIDE ? 4 : 2);
     float y0[NS], y1[NS];
 #pragma unroll
     for (int sl = 0; sl < NS; ++sl) {
-      const int m = WIDE ? sl >> 1 : sl, rr = WIDE ? r + 8 * (sl & 1) : r;
+      const int m = C64 ? sl >> 2 : (WIDE ? sl >> 1 : sl), rr = C64 ? r + 4 * (sl & 3) : (WIDE ? r + 8 * (sl & 1) : r);
       const float m0 = acc[0][m][rr], m1 = acc[1][m][rr], m2 = acc[2][m][rr], m3 = acc[3][m][rr];
       y0[sl] = fmaxf(fmaf((m0 + m1) + m2, sc, sh), 0.f);
       y1[sl] = fmaxf(fmaf((m1 - m2) - m3, sc, sh), 0.f);
@@ -407,22 +498,32 @@ int launch_w1(W1Params p, hipStream_t s) {
 
 }  // namespace
 
+#ifdef W1_CLK
+extern "C" int ac_w1_clk_read(unsigned long long* out3, int reset) {
+  if (hipMemcpyFromSymbol(out3, HIP_SYMBOL(w1_clk), 24) != hipSuccess) return -2;
+  if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(w1_clk), z, 32) != hipSuccess) return -2; }
+  return 0;
+}
+#endif
+
 // C ABI: see include/audiocaption_hip.h
 extern "C" int ac_conv3x3_bn_relu_wino1d(const float* in, const void* wfrag, const float* scale, const float* shift,
                                          float* out, int B, int Hp, int H, int W, int Cin, int Cout, int mode,
                                          int map_mode, const int* clip_frames, int need_mul, int need_add,
                                          void* stream) {
   if (!in || !wfrag || !scale || !shift || !out) return AC_ERR_ARG;
-  if (B <= 0 || Hp <= H || (Hp & 1) || W < 2 || (W != 2 && (W & 3)) || Cin % 32 || Cout % 128) return AC_ERR_ARG;
+  const bool c64 = Cout == 64;   // conv2 of block 1: the 16-column form
+  if (B <= 0 || Hp <= H || (Hp & 1) || W < 2 || (W != 2 && (W & 3)) || Cin % 32 || (Cout % 128 && !c64)) return AC_ERR_ARG;
+  if (c64 && (W % 16 || mode == MODE_MEANW)) return AC_ERR_ARG;
   if (mode < 0 || mode > 2) return AC_ERR_ARG;
   if (mode == MODE_MEANW && W != 2) return AC_ERR_ARG;
   if ((unsigned long long)(B * (unsigned long long)Hp + 2) * W * Cin >= (1ull << 31)) return AC_ERR_ARG;   // 32-bit offsets
   W1Params p;
   p.in = in; p.wpk = wfrag; p.scale = scale; p.shift = shift; p.out = out;
   p.rows_total = B * Hp; p.Hp = Hp; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
-  p.mt_cols = W == 2 ? 1 : W / 4;
+  p.mt_cols = c64 ? W / 16 : (W == 2 ? 1 : W / 4);
   p.MT = 0;
-  p.NT = Cout / 128;
+  p.NT = c64 ? 1 : Cout / 128;
   p.Hp_out = Hp / 2; p.H_out = H / 2; p.W_out = W / 2;
   if (map_mode < 0) map_mode = (p.NT % 8 == 0) ? 1 : ((p.NT == 1 || p.NT == 2 || p.NT == 4) ? 3 : 2);
   if (map_mode == 1 && p.NT % 8 != 0) return AC_ERR_ARG;
@@ -430,6 +531,10 @@ extern "C" int ac_conv3x3_bn_relu_wino1d(const float* in, const void* wfrag, con
   p.map_mode = map_mode;
   p.clip_frames = clip_frames; p.need_mul = need_mul; p.need_add = need_add;
   hipStream_t s = (hipStream_t)stream;
+  if (c64) {
+    if (mode == MODE_FULL) return launch_w1<MODE_FULL, 16, false, true>(p, s);
+    return launch_w1<MODE_POOL, 16, false, true>(p, s);
+  }
   if (W == 2) {
     if (mode == MODE_FULL) return launch_w1<MODE_FULL, 2, true, false>(p, s);
     if (mode == MODE_MEANW) return launch_w1<MODE_MEANW, 2, true, false>(p, s);

@@ -150,8 +150,8 @@ def conv3x3_bn_relu_bf16x3_gw(x, wfrag, scale, shift, out, B, Hp, H, W, Cin, Cou
 
 def conv3x3_bn_relu_wino1d(x, wfrag, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode=-1, need=None):
     """F(2,3) Winograd along time on split-bf16 operands (csrc/conv3x3_wino1d.hip); ``wfrag`` from
-    ``pack_conv_weight_wino1d_frag``.  Layers the kernel does not cover (Cout % 128 != 0: conv2 of block 1) must be
-    routed to ``conv3x3_bn_relu_bf16x3_gw`` by the caller.  ``need = (clip_frames int32 device tensor, mul, add)``: ragged
+    ``pack_conv_weight_wino1d_frag``.  Covers Cout % 128 == 0 and Cout == 64 with W % 16 == 0 (conv2 of block 1); other
+    layers must be routed to ``conv3x3_bn_relu_bf16x3_gw`` by the caller.  ``need = (clip_frames int32 device tensor, mul, add)``: ragged
     batches - output rows at or beyond ``mul * clip_frames[b] + add`` of clip b are not computed (stored as zeros)."""
     lib = _lib.load()
     hook = CONV_LAUNCH_HOOK

@@ -199,18 +199,25 @@ class TransformerModel(CaptionModel):
         the decode of batch i fills the gaps of the matrix-bound encoder of batch i+1.  Results are identical
         to ``model(input_dict)``; only the schedule differs.  Returns a ``PendingCaption``.
 
-        ``pair`` (default: AUDIOCAPTION_PAIR_DECODE, off): a batch waits for the next submission of the same shape and
-        the two are decoded as ONE chain (rows are independent: same tokens, same logits; the chain is latency-bound, so
-        128 rows cost what 64 do); a batch without a partner is decoded on its own as soon as its ``result()`` is asked
-        for.  It paid off only while the host was held back by blocking length uploads; with the host
-        running ahead of the device it is neutral, so results are not delayed by default."""
+        ``pair`` (default: AUDIOCAPTION_PAIR_DECODE = "auto"): two consecutive submissions of the same shape can be decoded
+        as ONE chain (rows are independent: same tokens, same logits; the chain is latency-bound, so 128 rows cost what 64
+        do).  Beside a running encoder a chain advances at a quarter of its stand-alone speed (its ~200 dependent launches
+        each wait for workgroup slots: 8.5 ms instead of 1.9 ms per batch against an encoder of 6.3 ms,
+        tools/stream_timeline.py), so under load the CHAIN bounds the step - one chain per two batches hands the bound back
+        to the encoder: 6.78 -> 6.37 ms per step.  "auto" holds a batch for its partner only while the decode stream is
+        still busy with earlier chains (it could not have started anyway); an idle decode stream decodes on submission, so
+        single requests are not delayed.  True / "1" always waits for a partner, False / "0" never.  A batch without a
+        partner is decoded on its own as soon as its ``result()`` is asked for."""
         method = input_dict.get("sample_method", "greedy")
         if input_dict.get("mode") != "inference" or method not in ("greedy", "beam"):
             raise NotImplementedError("forward_async: greedy or beam inference only; use model(input_dict) otherwise")
         if method == "beam":
             return self._forward_async_beam(input_dict)
         if pair is None:
-            pair = os.environ.get("AUDIOCAPTION_PAIR_DECODE", "0") != "0"
+            pair = os.environ.get("AUDIOCAPTION_PAIR_DECODE", "auto")
+        pair = {True: "1", False: "0"}.get(pair, pair)
+        if pair not in ("0", "1", "auto"):
+            raise ValueError(f"AUDIOCAPTION_PAIR_DECODE={pair!r}: '0', '1' or 'auto'")
         dev = input_dict["wav"].device
         if self._streams is None or self._streams[0].device != dev:
             self._streams = _make_streams(dev)
@@ -242,11 +249,11 @@ class TransformerModel(CaptionModel):
             self._held = None
             same = (held[3] == max_length and held[1]["attn_emb"].shape == enc["attn_emb"].shape
                     and held[1]["attn_emb"].device == enc["attn_emb"].device)
-            if pair and same:
+            if pair != "0" and same:
                 self._decode_group([held, item])
                 return item[0]
             self._decode_group([held])
-        if pair:
+        if pair == "1" or (pair == "auto" and not dec_s.query()):
             self._held = item
         else:
             self._decode_group([item])

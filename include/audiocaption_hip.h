@@ -79,8 +79,8 @@ int ac_conv3x3_bn_relu_bf16x3_gw(const float* in, const void* wfrag, const float
  * products per f32 product of the direct form (ac_conv3x3_bn_relu_bf16x3_gw: three) at the same f32-grade accuracy.
  * in / out f32 with the layouts of ac_conv3x3_bn_relu.  wfrag = U split and packed in MFMA fragment order
  * [Cin/32][3 kx][4 positions][2 k-steps][Cout/32][2 (hi, lo)][64 lanes][8] bf16, lane = (cout % 32) + 32 * ((cin % 16) / 8),
- * element = cin % 8.  Requires Hp even, W = 2 or a multiple of 4, Cin % 32 == 0, Cout % 128 == 0 (AC_ERR_ARG otherwise;
- * mode 1 needs W >= 4, mode 2 needs W == 2).
+ * element = cin % 8.  Requires Hp even, W = 2 or a multiple of 4, Cin % 32 == 0, and Cout % 128 == 0 or Cout == 64 with
+ * W % 16 == 0 (conv2 of block 1) (AC_ERR_ARG otherwise; mode 1 needs W >= 4, mode 2 needs W == 2).
  * Ragged batches (the reference pads every clip to the batch maximum and convolves the padding, collate_func.py:29-32,
  * cnn_encoder.py:446-450): clip_frames (device int32 [B], may be NULL) = every clip's own attn_emb_len; workgroups whose
  * output rows all lie at or beyond need_mul * clip_frames[b] + need_add of their clip(s) skip the convolution and store

@@ -58,7 +58,7 @@ def main():
                 wp = K.pack_conv_weight_bf16x3(w)
                 fn = lambda: K.conv3x3_bn_relu_bf16x3(x, wp, sc, sh, out, B, Hp, H, W, Cin, Cout, mode)
             elif algo == "wino1d":
-                if Cout % 128:
+                if Cout % 128 and not (Cout == 64 and W % 16 == 0):
                     continue
                 wp = K.pack_conv_weight_wino1d_frag(w)
                 fn = lambda: K.conv3x3_bn_relu_wino1d(x, wp, sc, sh, out, B, Hp, H, W, Cin, Cout, mode, args.map_mode)
