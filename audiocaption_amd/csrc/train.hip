@@ -1241,13 +1241,28 @@ inline int grid_for(long n, int block = 256, int cap = 65535 * 4) {
 }  // namespace
 
 // ============================================== C ABI ====================================================
+// C[M][N] (row pitch ldc) = 0: the starting point of a split-K product with beta == 0.  (A kernel, not hipMemset2DAsync:
+// inside a captured graph the 2-D memset node was not replayed and the slices accumulated onto the previous iteration.)
+__global__ void zero2d_kernel(float* C, long ldc, int M, int N) {
+  const long n = (long)M * N;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    C[(i / N) * ldc + i % N] = 0.f;
+}
+static inline void zero2d(float* C, long ldc, int M, int N, hipStream_t s) {
+  hipLaunchKernelGGL(zero2d_kernel, dim3(grid_for((long)M * N)), dim3(256), 0, s, C, ldc, M, N);
+}
+
 extern "C" {
 
 int ac_gemm(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc, int M, int N,
             int K, const float* bias, int relu, float beta, int splitk, float drop_p, unsigned long long drop_seed,
             const unsigned long long* seed_dev, long row0, const float* a_scale, int a_rows, void* stream) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || relu < 0 || relu > 3 || (a_scale && a_rows <= 0)) return AC_ERR_ARG;
-  if (splitk > 1 && (bias || relu || drop_p > 0.f || beta != 1.0f)) return AC_ERR_ARG;
+  if (splitk > 1 && (bias || relu || drop_p > 0.f || (beta != 1.0f && beta != 0.0f))) return AC_ERR_ARG;
+  if (splitk > 1 && beta == 0.0f) {   // the slices accumulate with atomics: start from zeros
+    zero2d(C, ldc, M, N, (hipStream_t)stream);
+    beta = 1.0f;
+  }
   GemmP p;
   p.A = A; p.sam = sam; p.sak = sak; p.B = B; p.sbk = sbk; p.sbn = sbn; p.C = C; p.ldc = ldc;
   p.M = M; p.N = N; p.K = K; p.bias = bias; p.relu = relu; p.beta = beta;
@@ -1290,13 +1305,17 @@ int ac_gemm_bf16x3(const float* A, long sam, long sak, const float* B, long sbk,
                    unsigned long long drop_seed, const unsigned long long* seed_dev, long row0, const float* a_scale,
                    int a_rows, void* stream) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || relu < 0 || relu > 3 || (a_scale && a_rows <= 0)) return AC_ERR_ARG;
-  if (splitk > 1 && (bias || relu || drop_p > 0.f || beta != 1.0f)) return AC_ERR_ARG;
+  if (splitk > 1 && (bias || relu || drop_p > 0.f || (beta != 1.0f && beta != 0.0f))) return AC_ERR_ARG;
   // small or oddly laid out products: the exact-f32 kernels (a split-bf16 tile would be mostly padding / latency)
   const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64) * (splitk < 1 ? 1 : splitk);
   if ((double)M * N * K < 3.0e7 || t64 < 200 || !gb_operand_ok(A, sam, sak, M, K) || !gb_operand_ok(B, sbn, sbk, N, K) ||
       (a_scale && (sak != 1 || ((uintptr_t)a_scale & 15) != 0)))
     return ac_gemm(A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, bias, relu, beta, splitk, drop_p, drop_seed, seed_dev, row0,
                    a_scale, a_rows, stream);
+  if (splitk > 1 && beta == 0.0f) {
+    zero2d(C, ldc, M, N, (hipStream_t)stream);
+    beta = 1.0f;
+  }
   GemmP p;
   p.A = A; p.sam = sam; p.sak = sak; p.B = B; p.sbk = sbk; p.sbn = sbn; p.C = C; p.ldc = ldc;
   p.M = M; p.N = N; p.K = K; p.bias = bias; p.relu = relu; p.beta = beta;

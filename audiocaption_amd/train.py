@@ -194,6 +194,7 @@ def allreduce_flat_gradients(flat_grad, process_group=None, async_op=False, algo
 
 
 _WS_POISON = os.environ.get("AUDIOCAPTION_WS_POISON", "0") == "1"
+_DX_SPLITK = os.environ.get("AUDIOCAPTION_TRAIN_DX_SPLITK", "1") != "0"   # development: 0 = input gradients never split-K
 
 
 class _Ws:
@@ -350,7 +351,12 @@ class TrainEngine:
             if hook is not None:
                 hook("post", info)
             return
-        self._gemm(s, dy, lddy, 1, W, K, 1, dx, lddx, M, K, N, None, 0, beta)
+        # few output tiles over a long reduction (the classifier's dx: 672 x 256 outputs over 4981 vocabulary entries; the
+        # GRU's dx: 992 x 512 over 1536 gate columns): slices of the reduction on separate workgroups (atomic accumulation,
+        # like the weight gradients) instead of 44 / 128 workgroups walking all of it
+        tiles = ((M + 63) // 64) * ((K + 63) // 64)
+        sk = max(1, min((255 + tiles) // tiles, N // 256)) if tiles < 200 and beta in (0.0, 1.0) and _DX_SPLITK else 1
+        self._gemm(s, dy, lddy, 1, W, K, 1, dx, lddx, M, K, N, None, 0, beta, sk)
 
     @staticmethod
     def _splitk(M, N, K):

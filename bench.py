@@ -295,6 +295,11 @@ def bench_train(args, ranks, steps, warmup, with_rccl=False):
         fl_b, ms_b = sum(i["flops"] for _, i in bwd), sum(t for t, _ in bwd)
         fl_f, ms_f = sum(i["flops"] for _, i in fwd), sum(t for t, _ in fwd)
         big = max(bwd, key=lambda x: x[1]["flops"])
+        if os.environ.get("AUDIOCAPTION_BENCH_GEMM_LIST"):   # development: every GEMM launch of the iteration, slowest first
+            rows = sorted(((t, i["phase"], i["M"], i["N"], i["K"]) for t, i in bwd + fwd), reverse=True)
+            with open(os.environ["AUDIOCAPTION_BENCH_GEMM_LIST"], "w") as f:
+                for t, ph, M_, N_, K_ in rows:
+                    f.write(f"{t * 1e3:8.1f} us  {ph:8s} M {M_:6d} N {N_:6d} K {K_:6d}  {2.0 * M_ * N_ * K_ / t / 1e9:7.1f} TFLOP/s\n")
         split = engine.gemm_algo in ("bf16x3", "pw")
         peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
         roof = {"bound": "mfma",

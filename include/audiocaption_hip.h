@@ -255,8 +255,9 @@ int ac_trm_beam_reorder(const ac_trm_weights* w, int R, int max_len, int t, cons
 /* C[M][N] (row pitch ldc) = epi( sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] ): X W^T / dY W / dY^T X with one kernel
  * (replaces F.linear and its autograd, e.g. transformer_decoder.py:86-101, rnn_encoder.py:41).
  * epi: + bias[n], activation (relu = 1: ReLU, 2: swish x*sigmoid(x), 3: sigmoid), dropout(drop_p, drop_seed, index (row0+m)*N+n),
- * + beta*C.  splitk > 1: K is cut into splitk slices whose partial sums are atomically ADDED to C (weight gradients;
- * needs beta == 1, no bias/activation/dropout).  a_scale (optional): A(m,k) is multiplied by
+ * + beta*C.  splitk > 1: K is cut into splitk slices whose partial sums are atomically ADDED to C (weight gradients, and
+ * input gradients with few output tiles over a long reduction; beta == 1, or beta == 0: C is zero-filled first; no
+ * bias/activation/dropout).  a_scale (optional): A(m,k) is multiplied by
  * a_scale[(m / a_rows)*K + k] on the way in - the squeeze-excite gate of an MBConv block applied inside its 1x1
  * projection (efficientnet_pytorch MBConvBlock.forward; call site hf_wrapper.py:231). */
 int ac_gemm(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc, int M, int N,
