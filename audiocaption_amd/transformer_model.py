@@ -190,7 +190,7 @@ class TransformerModel(CaptionModel):
         super().__init__(encoder, decoder, **kwargs)
         self._streams = None
         self._pinned = {}
-        self._held = None   # forward_async: a submitted batch whose decode waits for a partner batch
+        self._held = None   # forward_async: submitted batches whose decode waits for partner batches (a list)
 
     # ---- throughput mode: encoder of batch i+1 overlaps the (latency-bound) decode of batch i ---------
     def forward_async(self, input_dict, pair=None):
@@ -199,14 +199,14 @@ class TransformerModel(CaptionModel):
         the decode of batch i fills the gaps of the matrix-bound encoder of batch i+1.  Results are identical
         to ``model(input_dict)``; only the schedule differs.  Returns a ``PendingCaption``.
 
-        ``pair`` (default: AUDIOCAPTION_PAIR_DECODE = "auto"): two consecutive submissions of the same shape can be decoded
-        as ONE chain (rows are independent: same tokens, same logits; the chain is latency-bound, so 128 rows cost what 64
+        ``pair`` (default: AUDIOCAPTION_PAIR_DECODE = "auto"): up to AUDIOCAPTION_DECODE_GROUP (2) consecutive submissions of
+        the same shape can be decoded as ONE chain (rows are independent: same tokens, same logits; the chain is latency-bound, so 128 rows cost what 64
         do).  Beside a running encoder a chain advances at a quarter of its stand-alone speed (its ~200 dependent launches
         each wait for workgroup slots: 8.5 ms instead of 1.9 ms per batch against an encoder of 6.3 ms,
-        tools/stream_timeline.py), so under load the CHAIN bounds the step - one chain per two batches hands the bound back
-        to the encoder: 6.78 -> 6.37 ms per step.  "auto" holds a batch for its partner only while the decode stream is
+        tools/stream_timeline.py), so under load the CHAIN bounds the step - one chain per two or three batches hands the
+        bound back to the encoder: 6.78 -> 6.37 ms per step.  "auto" holds a batch for its partner only while the decode stream is
         still busy with earlier chains (it could not have started anyway); an idle decode stream decodes on submission, so
-        single requests are not delayed.  True / "1" always waits for a partner, False / "0" never.  A batch without a
+        single requests are not delayed.  True / "1" always waits for a full group, False / "0" never.  A batch without a
         partner is decoded on its own as soon as its ``result()`` is asked for."""
         method = input_dict.get("sample_method", "greedy")
         if input_dict.get("mode") != "inference" or method not in ("greedy", "beam"):
@@ -244,19 +244,25 @@ class TransformerModel(CaptionModel):
         max_length = int(input_dict.get("max_length", self.max_length))
         item = (PendingCaption(self), enc, enc_done, max_length)
         item[0]._input = input_dict
-        held = self._held
-        if held is not None:
+        # AUDIOCAPTION_DECODE_GROUP (default 2): submissions per chain at most (one chain per 1 / 2 / 3 / 4 batches of 64
+        # clips: 6.39 / 6.21 / 6.05 / 6.04 ms per step over 24 steps, 6.37 / 6.08 / 6.03 / 5.91 over 60; the default bench run
+        # of 20 steps measures 6.15 with 2 and 6.19 with 3 - its last chains run after the last encoder)
+        gmax = max(1, int(os.environ.get("AUDIOCAPTION_DECODE_GROUP", "2"))) if pair != "0" else 1
+        held = self._held or []
+        if held:
+            h = held[0]
+            same = (h[3] == max_length and h[1]["attn_emb"].shape == enc["attn_emb"].shape
+                    and h[1]["attn_emb"].device == enc["attn_emb"].device)
+            if not same:
+                self._decode_group(held)
+                held = []
+        held = held + [item]
+        # "auto": a lone batch waits only while the decode stream is still busy; held batches go as soon as it is idle
+        if len(held) >= gmax or (pair == "auto" and dec_s.query()):
             self._held = None
-            same = (held[3] == max_length and held[1]["attn_emb"].shape == enc["attn_emb"].shape
-                    and held[1]["attn_emb"].device == enc["attn_emb"].device)
-            if pair != "0" and same:
-                self._decode_group([held, item])
-                return item[0]
-            self._decode_group([held])
-        if pair == "1" or (pair == "auto" and not dec_s.query()):
-            self._held = item
+            self._decode_group(held)
         else:
-            self._decode_group([item])
+            self._held = held
         return item[0]
 
     def _forward_async_beam(self, input_dict):
@@ -385,8 +391,8 @@ class TransformerModel(CaptionModel):
 
     def _flush_held(self):
         held, self._held = self._held, None
-        if held is not None:
-            self._decode_group([held])
+        if held:
+            self._decode_group(held)
 
     def _decode_group(self, items):
         """One greedy chain over the rows of all ``items`` (pending, enc, enc_done, max_length) on the decode stream."""

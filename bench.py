@@ -773,7 +773,10 @@ def main():
     # use of a shape (audiocaption_amd/transformer_decoder.py), so the shape is used twice here and neither the W warm-up
     # steps nor the K timed steps contain a graph capture - the same role as loading the weights.
     if not args.sync_steps:
-        for n_prime in (4, 1, 1):
+        # forward_async decodes up to AUDIOCAPTION_DECODE_GROUP submissions as one chain: every chain shape a run can
+        # produce (a lone batch, a full group, the shorter groups left at the end of a run) is used twice here
+        gmax = max(1, int(os.environ.get("AUDIOCAPTION_DECODE_GROUP", "2")))
+        for n_prime in [1 + 2 * gmax] + [1 + gmax + k for k in range(1, gmax) for _ in (0, 1)] + [1, 1]:
             run_steps(n_prime)
     # ---- timed region: exactly K steps of the default tier ----
     elapsed, out, events = measure(default_tier, args.steps, args.warmup)
