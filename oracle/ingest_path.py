@@ -3,11 +3,14 @@ rank 1): float16 HDF5 samples -> float32 (caption_dataset.py:131-145), ``torchau
 target_sr)`` (caption_dataset.py:110-120; Clotho 44.1 kHz -> 32 kHz, train_data.yaml:11-12) and the zero-padding
 collate with its ``min_duration`` blacklist (``WavPadCollate``, inference.py:81-111).
 
-The collate is the reference's own code (pinned by restating it).  **The resampler is PARITY UNPINNED**: its arithmetic
-is torchaudio==0.13.1's ``_get_sinc_resample_kernel`` / ``_apply_sinc_resample_kernel`` (not vendored); restated here
-from the published algorithm - windowed-sinc polyphase filter, ``lowpass_filter_width=6``, ``rolloff=0.99``, Hann window
-(``sinc_interpolation``), computed in float64 and cast like torchaudio does when no dtype is given - and checked against
-closed-form answers in tests/test_ingest_oracle.py.
+The collate is the reference's own code (pinned by restating it).  The resampler's arithmetic is torchaudio==0.13.1's
+``_get_sinc_resample_kernel`` / ``_apply_sinc_resample_kernel`` (not vendored, not installed here); restated from the
+published algorithm - windowed-sinc polyphase filter, ``lowpass_filter_width=6``, ``rolloff=0.99``, Hann window
+(``sinc_interpolation``), computed in float64 and cast like torchaudio does when no dtype is given.  Pinned in two
+parts (tests/test_ingest_oracle.py): the polyphase machinery (kernel bank, phase order, padding, block reshape, output
+length) against an independent engine, ``scipy.signal.upfirdn`` driven by the prototype filter on the fine grid (5e-7 on
+five rate pairs); the prototype's FORMULA itself only by closed-form properties (DC gain, tap count, sinusoid
+amplitudes) - **that part stays "restated", parity unpinned**: no implementation of it exists in this image.
 """
 import math
 
