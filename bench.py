@@ -597,6 +597,24 @@ def _decoder_rooflines(model, dev, B, vocab, max_length):
 # ---------------------------------------------------------------------------------------------------------------------
 # headline: Cnn14Rnn-Trm greedy inference (BASELINE configs[1])
 # ---------------------------------------------------------------------------------------------------------------------
+def sustained_mfma_tflops(dev):
+    """The dense bf16 matrix rate this part sustains (csrc/probe.hip: bare v_mfma_f32_32x32x16_bf16 loops on every CU, no
+    memory traffic), measured in this run: a few launches of ~4 ms until the clock has settled, the last one reported."""
+    from audiocaption_amd import _lib
+    lib = _lib.load()
+    blocks, iters = 512, 12000
+    out = torch.empty(blocks * 256, device=dev)
+    rate = None
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(lib.ac_mfma_bf16_probe(out.data_ptr(), blocks, iters, _lib.stream()), "ac_mfma_bf16_probe")
+        e1.record()
+        torch.cuda.synchronize()
+        rate = blocks * 4 * iters * 32 * 32768.0 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    return rate
+
+
 def conv_roofline(tier, events):
     """Roofline object of the dominant conv kernel from the HIP events the launch hook collected.  One convention for every
     tier: ``achieved`` = ALGORITHMIC direct-convolution f32 FLOPs / kernel time; ``frac`` = MFMA FLOPs actually issued
@@ -894,6 +912,16 @@ def main():
         multi = {"ranks": ranks.describe(), "seconds_per_rank": [float(t) for t in every],
                  "rccl": time_allreduce(ranks, torch.zeros(10_700_000, device=dev)) if ranks.backend == "nccl" else
                          {"backend": ranks.backend, "world_size": world}}
+    sustained = {}
+    if rank == 0 and TIERS[default_tier]["peak"] == BF16_MFMA_PEAK_TFLOPS:
+        try:   # context for `frac` (denominator: the nominal dense peak): what a bare MFMA loop reaches on this part
+            sm = sustained_mfma_tflops(dev)
+            sustained = {"sustained_mfma_tflops_measured": sm,
+                         "frac_of_sustained": headline_roof["achieved"] * headline_roof["issued_per_algorithmic"] / sm,
+                         "sustained_note": "csrc/probe.hip: v_mfma_f32_32x32x16_bf16 only, all CUs, no memory traffic, "
+                                           "measured in this run (the part holds ~1.7 of 2.4 GHz under matrix load)"}
+        except Exception as e:  # noqa: BLE001
+            sustained = {"sustained_mfma_tflops_measured": None, "sustained_note": f"{type(e).__name__}: {e}"}
     if rank == 0:
         clips = world * B * args.steps
         val = lambda d_, k="value": (d_ or {}).get(k) if isinstance(d_, dict) else None
@@ -930,9 +958,9 @@ def main():
                        "sharding": f"clips sharded over {world} rank(s), no data-path collective",
                        "schedule": "blocking model() per step" if args.sync_steps else
                                    "forward_async: encoder of step i+1 under the decode chain of step i (two HIP streams)"},
-            "roofline": {k: headline_roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "algorithmic_frac",
-                                                       "issued_per_algorithmic", "traffic", "avg_launch_ms", "launches_timed",
-                                                       "kernel")},
+            "roofline": dict({k: headline_roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "algorithmic_frac",
+                                                            "issued_per_algorithmic", "traffic", "avg_launch_ms",
+                                                            "launches_timed", "kernel")}, **sustained),
             # flat scalars, all measured in this run
             "value_f32_exact": val(tiers.get("f32")),
             "value_bf16x3_direct": val(tiers.get("bf16x3")),

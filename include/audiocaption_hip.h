@@ -451,6 +451,12 @@ int ac_ingest_resample(const void* src, int src_half, const long* src_off, const
                        const int* tap_hi, float* out, const int* out_len, int B, int lmax, int orig, int new_, int width,
                        void* stream);
 
+/* Diagnostic (bench.py, not the hot path): `blocks` workgroups of 4 waves each issue iters x 32 dependent-free
+ * v_mfma_f32_32x32x16_bf16 (8 accumulators per wave, no memory traffic); out[blocks * 256] receives the accumulator sums.
+ * FLOPs = blocks * 4 * iters * 32 * 32768.  Timed by the caller, it gives the matrix rate the part sustains at the clock it
+ * holds under matrix load - the context of `roofline.frac`, whose denominator is the NOMINAL dense peak. */
+int ac_mfma_bf16_probe(float* out, int blocks, int iters, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
