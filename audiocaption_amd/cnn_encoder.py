@@ -45,11 +45,16 @@ def wino1d_covers(cout):
     return cout % 128 == 0 or (cout == 64 and os.environ.get("AUDIOCAPTION_W1_C64", "1") != "0")
 
 
-def _conv_wino1d(x, w, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode=-1, need=None):
-    """The "wino1d" tier's launcher (``_pack`` packs a layer's weights for the kernel ``wino1d_covers`` names)."""
+def _conv_wino1d(x, w, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode=-1, need=None, splitk_buf=None):
+    """The "wino1d" tier's launcher (``_pack`` packs a layer's weights for the kernel ``wino1d_covers`` names).
+    ``splitk_buf(floats) -> tensor``: workspace provider for the K-sliced launches of single clips."""
     if not wino1d_covers(Cout):
         return K.conv3x3_bn_relu_bf16x3_gw(x, w, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode)
-    return K.conv3x3_bn_relu_wino1d(x, w, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode, need=need)
+    ws = None
+    if splitk_buf is not None:
+        floats = K.wino1d_splitk_floats(B, Hp, W, Cin, Cout)
+        ws = splitk_buf(floats) if floats else None
+    return K.conv3x3_bn_relu_wino1d(x, w, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode, need=need, workspace=ws)
 
 
 def rows_needed(block, conv):
@@ -270,6 +275,9 @@ class Cnn14Encoder(nn.Module):
             import functools
             conv = functools.partial(conv, overflow=overflow)
         fuse1 = algo == "f16x2" and os.environ.get("AUDIOCAPTION_FUSE_BLOCK1", "1") != "0"
+        if algo == "wino1d" and dropout is None and os.environ.get("AUDIOCAPTION_W1_SPLITK", "1") != "0":
+            import functools   # single clips: layers of a few workgroups run K-sliced over a shared workspace
+            conv = functools.partial(conv, splitk_buf=lambda n: self._buf("w1_splitk", n, dev))
 
         def need(block, j):   # ragged batches: the rows of this layer a clip's own length can bring to an output frame
             return {"need": (clip_frames,) + rows_needed(block, j)} if clip_frames is not None and algo == "wino1d" else {}

@@ -83,6 +83,11 @@ struct W1Params {
   // beyond can never reach an output frame the temporal encoder reads); null = every row of the geometry
   const int* clip_frames;
   int need_mul, need_add;
+  // few-workgroup launches (single clips): blockIdx.y walks slices of `ksteps` K steps each and stores its transformed,
+  // not yet normalised sums to partial[slice][row][col][Cout]; w1_finish_kernel adds the slices in order and applies the
+  // epilogue.  partial == nullptr: one slice, epilogue in this kernel.
+  float* partial;
+  int ksteps;
 };
 
 enum { MODE_FULL = 0, MODE_POOL = 1, MODE_MEANW = 2 };
@@ -151,6 +156,27 @@ __device__ __forceinline__ bool block_map(const W1Params& p, int& m_tile, int& n
     m_tile = bid / p.NT;
   }
   return true;
+}
+
+// Dead block: every one of its `nrows` rows from `row0` lies in the padding of its clip(s) - beyond the geometry's H valid
+// rows, or (ragged batches) beyond the rows the clip's own length can bring to an output frame.  Such a block convolves
+// nothing and stores zeros.
+__device__ __forceinline__ bool w1_block_live(const W1Params& p, int row0, int nrows) {
+  bool live = false;
+  if (row0 < p.rows_total) {
+    const int r_end = row0 + nrows < p.rows_total ? row0 + nrows : p.rows_total;
+    int b = row0 / p.Hp;
+    for (int base = b * p.Hp; base < r_end; base += p.Hp, ++b) {
+      const int lo = (row0 > base ? row0 : base) - base;
+      int lim = p.H;
+      if (p.clip_frames) {
+        const int need = p.need_mul * p.clip_frames[b] + p.need_add;
+        lim = need < lim ? need : lim;
+      }
+      live = live || lo < lim;
+    }
+  }
+  return live;
 }
 
 // TC: columns of the block (4, or 2 for the 2-column layers).  FULLW: the block spans the whole image width (W == TC):
@@ -230,24 +256,11 @@ __global__ __launch_bounds__((W1Geom<TC, FULLW, WIDE>::THREADS), 2) void conv3x3
   const int row0 = 2 * pair0;
   const int rc0 = row0 % p.Hp;
   (void)rc0;
-  // dead block: every row of it lies in the padding of its clip(s) - beyond the geometry's H valid rows, or (ragged
-  // batches) beyond the rows the clip's own length can bring to an output frame
-  bool live = false;
-  if (row0 < p.rows_total) {
-    const int r_end = row0 + 2 * PR < p.rows_total ? row0 + 2 * PR : p.rows_total;
-    int b = row0 / p.Hp;
-    for (int base = b * p.Hp; base < r_end; base += p.Hp, ++b) {
-      const int lo = (row0 > base ? row0 : base) - base;
-      int lim = p.H;
-      if (p.clip_frames) {
-        const int need = p.need_mul * p.clip_frames[b] + p.need_add;
-        lim = need < lim ? need : lim;
-      }
-      live = live || lo < lim;
-    }
-  }
+  const bool live = w1_block_live(p, row0, 2 * PR);
   const bool all_pad = !live;
-  const int nstep = p.Cin / KS;
+  const int nstep_all = p.Cin / KS;
+  const int sbeg = p.partial ? (int)blockIdx.y * p.ksteps : 0;                                   // even
+  const int nstep = p.partial ? (sbeg + p.ksteps < nstep_all ? sbeg + p.ksteps : nstep_all) : nstep_all;   // end of this slice
   if (!all_pad) {
     // Buffer descriptors (wave-uniform): out-of-range offsets read as zero, so the rows above / below the batch and the
     // threads without a staging item need no branches.
@@ -310,13 +323,13 @@ __global__ __launch_bounds__((W1Geom<TC, FULLW, WIDE>::THREADS), 2) void conv3x3
     static_assert(12 % RING == 0, "ring");
     bf16x8 wr[RING][2];   // ring of weight fragments: group gi lives in wr[gi % RING], requested RING - 1 groups ahead
 #pragma unroll
-    for (int g0 = 0; g0 < RING - 1; ++g0) w_load(0, g0, wr[g0]);
+    for (int g0 = 0; g0 < RING - 1; ++g0) w_load(sbeg, g0, wr[g0]);
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, NSET - 1>;
-    patch_request(0, I0{});
-    if (NSET == 2 && nstep > 1) patch_request(1, I1{});
+    patch_request(sbeg, I0{});
+    if (NSET == 2 && sbeg + 1 < nstep) patch_request(sbeg + 1, I1{});
 #pragma unroll
-    for (int piece = 0; piece < 4 * NP; ++piece) commit_piece(sV, piece, I0{});
+    for (int piece = 0; piece < 4 * NP; ++piece) commit_piece(sV, piece, I0{});   // sbeg is even: buffer 0
     __syncthreads();
 
     // SL / SR (compile time): this wave's tile 0 is the first / its tile 1 the last column of the IMAGE, whose kx = 0 /
@@ -347,14 +360,14 @@ __global__ __launch_bounds__((W1Geom<TC, FULLW, WIDE>::THREADS), 2) void conv3x3
           if (NSET == 2) { if (s + 2 < nstep) patch_request(s + 2, Other{}); }
           else if (more) patch_request(s + 1, NXT_);
         }
-        if (!(W1_KO & 2) || s == 0) a_load(cur, 0, af[0]);
+        if (!(W1_KO & 2) || s == sbeg) a_load(cur, 0, af[0]);
 #pragma unroll
         for (int gi = 0; gi < 12; ++gi) {
           const int kx = gi >> 2, q = gi & 3;
           // the next group's fragments are requested before this group's MFMAs; weights two groups ahead (the ring
           // position of a group is static: 12 % 3 == 0)
-          if (gi + 1 < 12 && (!(W1_KO & 2) || (s == 0 && gi == 0))) a_load(cur, gi + 1, af[(gi + 1) & 1]);
-          if (!(W1_KO & 1) || (s == 0 && gi == 0)) {
+          if (gi + 1 < 12 && (!(W1_KO & 2) || (s == sbeg && gi == 0))) a_load(cur, gi + 1, af[(gi + 1) & 1]);
+          if (!(W1_KO & 1) || (s == sbeg && gi == 0)) {
             constexpr int AH = RING - 1;
             if (gi + AH < 12) w_load(s, gi + AH, wr[(gi + AH) % RING]);
             else if (more) w_load(s + 1, gi + AH - 12, wr[(gi + AH) % RING]);
@@ -397,13 +410,13 @@ __global__ __launch_bounds__((W1Geom<TC, FULLW, WIDE>::THREADS), 2) void conv3x3
       };
       if (NSET == 2) {
 #pragma unroll 1
-        for (int s = 0; s < nstep; s += 2) {
+        for (int s = sbeg; s < nstep; s += 2) {
           step(s, I1{});                        // step 1's rows went into set 1 in the prologue, step 2's go into set 0, ...
           if (s + 1 < nstep) step(s + 1, I0{});
         }
       } else {
 #pragma unroll 1
-        for (int s = 0; s < nstep; ++s) step(s, I0{});
+        for (int s = sbeg; s < nstep; ++s) step(s, I0{});
       }
     };
     using T_ = std::true_type;
@@ -445,11 +458,25 @@ __global__ __launch_bounds__((W1Geom<TC, FULLW, WIDE>::THREADS), 2) void conv3x3
     for (int sl = 0; sl < NS; ++sl) {
       const int m = C64 ? sl >> 2 : (WIDE ? sl >> 1 : sl), rr = C64 ? r + 4 * (sl & 3) : (WIDE ? r + 8 * (sl & 1) : r);
       const float m0 = acc[0][m][rr], m1 = acc[1][m][rr], m2 = acc[2][m][rr], m3 = acc[3][m][rr];
-      y0[sl] = fmaxf(fmaf((m0 + m1) + m2, sc, sh), 0.f);
-      y1[sl] = fmaxf(fmaf((m1 - m2) - m3, sc, sh), 0.f);
+      if (p.partial) {   // this slice's share of the two output rows, before BatchNorm
+        y0[sl] = (m0 + m1) + m2;
+        y1[sl] = (m1 - m2) - m3;
+      } else {
+        y0[sl] = fmaxf(fmaf((m0 + m1) + m2, sc, sh), 0.f);
+        y1[sl] = fmaxf(fmaf((m1 - m2) - m3, sc, sh), 0.f);
+      }
     }
     const int gr = 2 * prow;
     if (gr >= p.rows_total) continue;
+    if (p.partial) {
+#pragma unroll
+      for (int sl = 0; sl < NS; ++sl) {
+        float* o = p.partial + (((size_t)blockIdx.y * p.rows_total + gr) * p.W + col0 + mcol0 + sl) * p.Cout + ch;
+        o[0] = all_pad ? 0.f : y0[sl];
+        o[(size_t)p.W * p.Cout] = all_pad ? 0.f : y1[sl];
+      }
+      continue;
+    }
     if (MODE == MODE_FULL) {
       const int h = by_hp.mod(gr);   // Hp is even: both rows of a pair belong to one clip
 #pragma unroll
@@ -474,6 +501,63 @@ __global__ __launch_bounds__((W1Geom<TC, FULLW, WIDE>::THREADS), 2) void conv3x3
   }
 }
 
+// Adds the K slices of a split launch in slice order (deterministic) and applies the epilogue of conv3x3_w1_kernel: one
+// thread per 4 channels of one output element (FULL: a pixel; POOL: a pooled pixel; MEANW: a (clip, row)).
+template <int MODE>
+__global__ __launch_bounds__(256) void w1_finish_kernel(W1Params p, int slices, int block_rows) {
+  const int c4n = p.Cout / 4;
+  const long n_out = MODE == MODE_FULL ? (long)p.rows_total * p.W * c4n
+                   : MODE == MODE_POOL ? (long)(p.rows_total / 2) * p.W_out * c4n : (long)p.rows_total * c4n;
+  const long slice_stride = (long)p.rows_total * p.W * p.Cout;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n_out; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    const long e = i / c4n;
+    const f32x4 sc = *(const f32x4*)(p.scale + c), sh = *(const f32x4*)(p.shift + c);
+    auto pixel = [&](long row, int col) {   // BN + ReLU of the summed slices of one full-resolution pixel
+      if (!w1_block_live(p, (int)(row / block_rows) * block_rows, block_rows)) return (f32x4){0.f, 0.f, 0.f, 0.f};   // as the conv kernel stores
+      const float* q = p.partial + ((size_t)row * p.W + col) * p.Cout + c;
+      f32x4 v = *(const f32x4*)q;
+      for (int k = 1; k < slices; ++k) v += *(const f32x4*)(q + k * slice_stride);
+      f32x4 y;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[j] = fmaxf(fmaf(v[j], sc[j], sh[j]), 0.f);
+      return y;
+    };
+    if (MODE == MODE_FULL) {
+      const int col = (int)(e % p.W);
+      const long row = e / p.W;
+      const f32x4 y = pixel(row, col);
+      const bool valid = (int)(row % p.Hp) < p.H;
+      *(f32x4*)(p.out + ((size_t)row * p.W + col) * p.Cout + c) = valid ? y : (f32x4){0.f, 0.f, 0.f, 0.f};
+    } else if (MODE == MODE_POOL) {
+      const int pc = (int)(e % p.W_out);
+      const long prow = e / p.W_out;
+      const f32x4 a = pixel(2 * prow, 2 * pc), b = pixel(2 * prow + 1, 2 * pc), c0 = pixel(2 * prow, 2 * pc + 1),
+                  d = pixel(2 * prow + 1, 2 * pc + 1);
+      const bool valid = (int)(prow % p.Hp_out) < p.H_out;
+      const f32x4 o = 0.25f * ((a + b) + (c0 + d));   // the kernel's order: (y0[2 oc] + y1[2 oc]) + (y0[2 oc + 1] + y1[2 oc + 1])
+      *(f32x4*)(p.out + ((size_t)prow * p.W_out + pc) * p.Cout + c) = valid ? o : (f32x4){0.f, 0.f, 0.f, 0.f};
+    } else {
+      const int h = (int)(e % p.Hp);
+      const long b = e / p.Hp;
+      if (h < p.H) *(f32x4*)(p.out + ((size_t)b * p.H + h) * p.Cout + c) = 0.5f * (pixel(e, 0) + pixel(e, 1));
+    }
+  }
+}
+
+// K slices of a launch with `wgs` workgroups over `nstep` K steps: as many as fill ~256 CUs, at least 4 steps (even) each
+static inline int w1_slices(long wgs, int nstep, int* ksteps) {
+  int S = 1;
+  if (wgs <= 64 && nstep >= 16) {
+    S = (int)(256 / wgs);
+    if (S > nstep / 4) S = nstep / 4;
+  }
+  int k = (nstep + S - 1) / S;
+  k += k & 1;
+  *ksteps = k;
+  return (nstep + k - 1) / k;
+}
+
 template <int MODE, int TC, bool FULLW, bool WIDE>
 int launch_w1(W1Params p, hipStream_t s) {
   using G = W1Geom<TC, FULLW, WIDE>;
@@ -492,8 +576,27 @@ int launch_w1(W1Params p, hipStream_t s) {
       return AC_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3x3_w1_kernel<MODE, TC, FULLW, WIDE>), dim3(grid), dim3(G::THREADS), lds, s, p);
-  return ac_check_launch();
+  int slices = 1;
+  if (p.partial) {
+    slices = w1_slices(grid, p.Cin / KS, &p.ksteps);
+    if (slices == 1) p.partial = nullptr;
+  }
+  hipLaunchKernelGGL((conv3x3_w1_kernel<MODE, TC, FULLW, WIDE>), dim3(grid, slices), dim3(G::THREADS), lds, s, p);
+  if (ac_check_launch() != 0) return AC_ERR_LAUNCH;
+  if (slices > 1) {
+    const long n_out = (MODE == MODE_FULL ? (long)p.rows_total * p.W : MODE == MODE_POOL ? (long)(p.rows_total / 2) * p.W_out
+                                                                                         : (long)p.rows_total) * (p.Cout / 4);
+    hipLaunchKernelGGL(w1_finish_kernel<MODE>, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s, p, slices, 2 * G::PR);
+    return ac_check_launch();
+  }
+  return 0;
+}
+
+// workgroups of a launch (before slicing): the same arithmetic as launch_w1
+static long w1_grid(int rows_total, int W, int Cout) {
+  const bool c64 = Cout == 64;
+  const int pr = c64 ? 8 : (W >= 8 ? 16 : 128 / W), cols = c64 ? W / 16 : (W == 2 ? 1 : W / 4), nt = c64 ? 1 : Cout / 128;
+  return (long)(((rows_total / 2) + pr - 1) / pr) * cols * nt;
 }
 
 }  // namespace
@@ -506,11 +609,9 @@ extern "C" int ac_w1_clk_read(unsigned long long* out3, int reset) {
 }
 #endif
 
-// C ABI: see include/audiocaption_hip.h
-extern "C" int ac_conv3x3_bn_relu_wino1d(const float* in, const void* wfrag, const float* scale, const float* shift,
-                                         float* out, int B, int Hp, int H, int W, int Cin, int Cout, int mode,
-                                         int map_mode, const int* clip_frames, int need_mul, int need_add,
-                                         void* stream) {
+static int w1_dispatch(const float* in, const void* wfrag, const float* scale, const float* shift, float* out, int B,
+                       int Hp, int H, int W, int Cin, int Cout, int mode, int map_mode, const int* clip_frames,
+                       int need_mul, int need_add, float* workspace, long workspace_floats, void* stream) {
   if (!in || !wfrag || !scale || !shift || !out) return AC_ERR_ARG;
   const bool c64 = Cout == 64;   // conv2 of block 1: the 16-column form
   if (B <= 0 || Hp <= H || (Hp & 1) || W < 2 || (W != 2 && (W & 3)) || Cin % 32 || (Cout % 128 && !c64)) return AC_ERR_ARG;
@@ -530,6 +631,12 @@ extern "C" int ac_conv3x3_bn_relu_wino1d(const float* in, const void* wfrag, con
   if (map_mode == 3 && !(p.NT == 1 || p.NT == 2 || p.NT == 4 || p.NT == 8)) return AC_ERR_ARG;
   p.map_mode = map_mode;
   p.clip_frames = clip_frames; p.need_mul = need_mul; p.need_add = need_add;
+  p.partial = nullptr; p.ksteps = 0;
+  if (workspace) {   // K slices for launches of a few workgroups, if the caller's workspace holds them
+    int ksteps;
+    const int slices = w1_slices(w1_grid(p.rows_total, W, Cout), Cin / KS, &ksteps);
+    if (slices > 1 && (long)slices * p.rows_total * W * Cout <= workspace_floats) p.partial = workspace;
+  }
   hipStream_t s = (hipStream_t)stream;
   if (c64) {
     if (mode == MODE_FULL) return launch_w1<MODE_FULL, 16, false, true>(p, s);
@@ -548,4 +655,30 @@ extern "C" int ac_conv3x3_bn_relu_wino1d(const float* in, const void* wfrag, con
   if (mode == MODE_FULL) return launch_w1<MODE_FULL, 4, false, true>(p, s);
   if (mode == MODE_POOL) return launch_w1<MODE_POOL, 4, false, true>(p, s);
   return AC_ERR_ARG;
+}
+
+// C ABI: see include/audiocaption_hip.h
+extern "C" int ac_conv3x3_bn_relu_wino1d(const float* in, const void* wfrag, const float* scale, const float* shift,
+                                         float* out, int B, int Hp, int H, int W, int Cin, int Cout, int mode,
+                                         int map_mode, const int* clip_frames, int need_mul, int need_add,
+                                         void* stream) {
+  return w1_dispatch(in, wfrag, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode, clip_frames, need_mul, need_add,
+                     nullptr, 0, stream);
+}
+
+extern "C" long ac_conv3x3_wino1d_splitk_floats(int B, int Hp, int W, int Cin, int Cout) {
+  if (B <= 0 || Hp <= 0 || W < 2 || Cin % 32 || Cin <= 0 || Cout <= 0) return 0;
+  int ksteps;
+  const int slices = w1_slices(w1_grid(B * Hp, W, Cout), Cin / KS, &ksteps);
+  return slices > 1 ? (long)slices * B * Hp * W * Cout : 0;
+}
+
+extern "C" int ac_conv3x3_bn_relu_wino1d_splitk(const float* in, const void* wfrag, const float* scale,
+                                                const float* shift, float* out, int B, int Hp, int H, int W, int Cin,
+                                                int Cout, int mode, int map_mode, const int* clip_frames,
+                                                int need_mul, int need_add, float* workspace,
+                                                long workspace_floats, void* stream) {
+  if (!workspace || workspace_floats <= 0) return AC_ERR_ARG;
+  return w1_dispatch(in, wfrag, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode, clip_frames, need_mul, need_add,
+                     workspace, workspace_floats, stream);
 }

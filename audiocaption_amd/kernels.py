@@ -148,20 +148,34 @@ def conv3x3_bn_relu_bf16x3_gw(x, wfrag, scale, shift, out, B, Hp, H, W, Cin, Cou
     return out
 
 
-def conv3x3_bn_relu_wino1d(x, wfrag, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode=-1, need=None):
+def wino1d_splitk_floats(B, Hp, W, Cin, Cout):
+    """Floats of workspace ``conv3x3_bn_relu_wino1d(..., workspace=...)`` needs to run this geometry K-sliced (launches of
+    a few workgroups: single clips); 0 = the launch is not split."""
+    return int(_lib.load().ac_conv3x3_wino1d_splitk_floats(B, Hp, W, Cin, Cout))
+
+
+def conv3x3_bn_relu_wino1d(x, wfrag, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode=-1, need=None,
+                           workspace=None):
     """F(2,3) Winograd along time on split-bf16 operands (csrc/conv3x3_wino1d.hip); ``wfrag`` from
     ``pack_conv_weight_wino1d_frag``.  Covers Cout % 128 == 0 and Cout == 64 with W % 16 == 0 (conv2 of block 1); other
     layers must be routed to ``conv3x3_bn_relu_bf16x3_gw`` by the caller.  ``need = (clip_frames int32 device tensor, mul, add)``: ragged
-    batches - output rows at or beyond ``mul * clip_frames[b] + add`` of clip b are not computed (stored as zeros)."""
+    batches - output rows at or beyond ``mul * clip_frames[b] + add`` of clip b are not computed (stored as zeros).
+    ``workspace`` (f32 tensor of at least ``wino1d_splitk_floats`` elements): few-workgroup launches run K-sliced over it."""
     lib = _lib.load()
     hook = CONV_LAUNCH_HOOK
     if hook is not None:
         info = {"B": B, "H": H, "Hp": Hp, "W": W, "Cin": Cin, "Cout": Cout, "mode": mode, "algo": "wino1d"}
         hook("pre", info)
     cf, mul, add = need if need is not None else (None, 0, 0)
-    check(lib.ac_conv3x3_bn_relu_wino1d(ptr(x), ptr(wfrag), ptr(scale), ptr(shift), ptr(out), B, Hp, H, W, Cin,
-                                        Cout, mode, map_mode, ptr(cf), int(mul), int(add), stream()),
-          "ac_conv3x3_bn_relu_wino1d")
+    if workspace is not None:
+        check(lib.ac_conv3x3_bn_relu_wino1d_splitk(ptr(x), ptr(wfrag), ptr(scale), ptr(shift), ptr(out), B, Hp, H, W, Cin,
+                                                   Cout, mode, map_mode, ptr(cf), int(mul), int(add), ptr(workspace),
+                                                   workspace.numel(), stream()),
+              "ac_conv3x3_bn_relu_wino1d_splitk")
+    else:
+        check(lib.ac_conv3x3_bn_relu_wino1d(ptr(x), ptr(wfrag), ptr(scale), ptr(shift), ptr(out), B, Hp, H, W, Cin,
+                                            Cout, mode, map_mode, ptr(cf), int(mul), int(add), stream()),
+              "ac_conv3x3_bn_relu_wino1d")
     if hook is not None:
         hook("post", info)
     return out

@@ -89,6 +89,17 @@ int ac_conv3x3_bn_relu_bf16x3_gw(const float* in, const void* wfrag, const float
 int ac_conv3x3_bn_relu_wino1d(const float* in, const void* wfrag, const float* scale, const float* shift,
                               float* out, int B, int Hp, int H, int W, int Cin, int Cout, int mode,
                               int map_mode, const int* clip_frames, int need_mul, int need_add, void* stream);
+/* The same layer for launches of a few workgroups (single clips: conv2 of block 6 at B = 1 is 16 workgroups streaming
+ * 200 MB of weights): the K loop is cut into slices on separate workgroups, every slice stores its transformed sums to
+ * workspace[slice][B*Hp][W][Cout], and a second kernel adds the slices IN ORDER (deterministic) and applies BN / ReLU /
+ * pool / mean.  ac_conv3x3_wino1d_splitk_floats: floats of workspace the geometry needs, 0 when the launch is not split
+ * (the call then equals ac_conv3x3_bn_relu_wino1d).  clip_frames / need_mul / need_add as above: skipped blocks come out
+ * as zeros here too. */
+long ac_conv3x3_wino1d_splitk_floats(int B, int Hp, int W, int Cin, int Cout);
+int ac_conv3x3_bn_relu_wino1d_splitk(const float* in, const void* wfrag, const float* scale, const float* shift,
+                                     float* out, int B, int Hp, int H, int W, int Cin, int Cout, int mode,
+                                     int map_mode, const int* clip_frames, int need_mul, int need_add,
+                                     float* workspace, long workspace_floats, void* stream);
 
 /* "f16x2" tier of the same kernel.  Activations live in HBM as fp16 (in: [B*Hp][W][Cin] fp16; out: fp16 for modes 0
  * and 1, f32 for mode 2 = the attn_emb the rest of the path consumes), weights as fp16 hi + lo (2^-22) in the same

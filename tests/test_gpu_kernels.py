@@ -288,6 +288,35 @@ def test_conv3x3_wino1d_dead_row_skipping(K, W, Cin, Cout, mode, block, conv):
     assert zeroed > 0
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,mode", [(1, 31, 2, 2048, 2048, 2), (2, 31, 2, 1024, 2048, 0), (1, 62, 4, 1024, 1024, 1),
+                                                  (1, 62, 4, 512, 1024, 0), (1, 125, 8, 512, 512, 1), (3, 9, 8, 256, 512, 1)])
+def test_conv3x3_wino1d_k_sliced_launch(K, B, H, W, Cin, Cout, mode):
+    """Single clips: a layer of a few workgroups runs K-sliced (slices of the channel loop on separate workgroups, a second
+    kernel adds them in order and applies the epilogue).  Same result as the one-slice launch up to the order of the
+    channel sum, identical from run to run, and the geometry that fills the chip on its own is not split."""
+    g = torch.Generator().manual_seed(B * 100 + W)
+    Hp = H + 1 + ((H + 1) % 2)
+    x = torch.zeros(B, Hp, W, Cin)
+    x[:, :H] = torch.randn(B, H, W, Cin, generator=g)
+    x = x.reshape(B * Hp, W, Cin).cuda()
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * math.sqrt(2.0 / (9 * Cin))
+    wp = K.pack_conv_weight_wino1d_frag(w.cuda())
+    sc, sh = (torch.rand(Cout, generator=g) + 0.5).cuda(), (torch.randn(Cout, generator=g) * 0.1).cuda()
+    shape = (B * Hp, W, Cout) if mode == 0 else ((B * Hp // 2, W // 2, Cout) if mode == 1 else (B, H, Cout))
+    one = torch.full(shape, 7.0).cuda()
+    K.conv3x3_bn_relu_wino1d(x, wp, sc, sh, one, B, Hp, H, W, Cin, Cout, mode)
+    floats = K.wino1d_splitk_floats(B, Hp, W, Cin, Cout)
+    assert floats > 0 and floats % (B * Hp * W * Cout) == 0 and floats // (B * Hp * W * Cout) >= 2
+    ws = torch.full((floats,), float("nan")).cuda()
+    a, b = torch.full(shape, 7.0).cuda(), torch.full(shape, 7.0).cuda()
+    K.conv3x3_bn_relu_wino1d(x, wp, sc, sh, a, B, Hp, H, W, Cin, Cout, mode, workspace=ws)
+    ws.fill_(float("nan"))
+    K.conv3x3_bn_relu_wino1d(x, wp, sc, sh, b, B, Hp, H, W, Cin, Cout, mode, workspace=ws)
+    assert torch.equal(a, b)
+    assert _report(f"k-sliced conv {B}x{H}x{W} {Cin}->{Cout} mode{mode}", a, one) < 2e-5
+    assert K.wino1d_splitk_floats(64, 32, 2, 2048, 2048) == 0      # 16 row blocks x 16 channel tiles: not split
+
+
 def test_conv3x3_first(K):
     import torch.nn.functional as F
     g = torch.Generator().manual_seed(3)
