@@ -29,7 +29,7 @@ for d in (f"{R}_pmc_{TIER}", f"{R}_pmc_effb2"):
         shutil.copy(f, os.path.join(dst, d, os.path.basename(f)))
 
 # the dominant kernel of bench.py's roofline: conv2 + BN + ReLU + 2x2 pool of blocks 2-5 (MODE_POOL = 1), 4 launches per step
-INST = {"wino1d": r"conv3x3_w1_kernel<1, ", "f16x2": r"conv3x3_gw_kernel<128, 1, 1, 1, 256, false, 9, (8|4)>"}[TIER]
+INST = {"wino1d": r"conv3x3_w1_kernel<1, 4, ", "f16x2": r"conv3x3_gw_kernel<128, 1, 1, 1, 256, false, 9, (8|4)>"}[TIER]
 
 
 def pmc(counter):
