@@ -7,6 +7,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -48,3 +50,16 @@ def test_bench_under_a_launcher_reads_the_ranks_from_the_environment():
 def test_bench_single_rank_stub():
     res = _run(["--steps", "2", "--warmup", "0", "--stub-workload"])
     assert res["n_gpus"] == 1
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_real_workload_on_one_gpu():
+    """The N > 1 flow of the REAL inference bench (clips sharded over ranks, no data-path collective, barrier + MAX timing,
+    rank records, per-rank seconds) with two gloo ranks sharing the only GPU of the box - RCCL refuses two ranks on one
+    device, everything else is the code an 8-GPU run executes."""
+    res = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4", "--seconds", "2", "--max-length", "6",
+                "--no-tiers", "--no-train", "--no-effb2", "--no-steady-state", "--no-cpu-baseline"], timeout=600)
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 8 and res["value"] > 0
+    assert [r["rank"] for r in res["ranks"]] == [0, 1] and len(res["seconds_per_rank"]) == 2
+    assert res["rccl"]["world_size"] == 2 and res["scaling"] == "weak"
+    assert abs(res["value"] - 8 * 2 / (res["ms_per_step"] * 2e-3)) < 1e-6 * res["value"]
