@@ -44,6 +44,9 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // Development only (tools/w1_knockout.py): -DW1_KO=<bits> removes one ingredient of the K loop at a time to price it
 // (results are then wrong).  1 weight loads, 2 A-fragment reads, 4 plane stores, 8 patch loads, 16 barrier, 32 MFMAs.
+// 64 / 128 / 256: the weight loads / A-fragment reads / patch loads of the K loop are still ISSUED (same addresses, same
+// traffic) but into scratch registers nothing waits for, the MFMAs and the transform run on the prologue's registers:
+// prices the waiting for operands separately from the moving of them.
 #ifndef W1_KO
 #define W1_KO 0
 #endif
@@ -272,8 +275,28 @@ __global__ __launch_bounds__((W1Geom<TC, FULLW, WIDE>::THREADS), 2) void conv3x3
         (void*)p.wpk, 0, (int)((unsigned)(p.Cin / 32) * 24u * ks_bytes), 0x00020000);
     // weight fragment of (K step s = 2 chunk + k-step, group gi = kx * 4 + p, plane) for this wave's 32 channels
     const unsigned wvoff = (unsigned)((n_tile * (C64 ? 2 : 4) + wn) * 2048 + lane * 16);
+    typedef int ko_i32x4 __attribute__((ext_vector_type(4)));
+    bool fire = false;   // W1_KO & (64 | 128 | 256): true inside the K loop
+    const ko_i32x4 srd_w = {(int)(unsigned)(uintptr_t)p.wpk, (int)(((uintptr_t)p.wpk >> 32) & 0xffff),
+                            (int)((unsigned)(p.Cin / 32) * 24u * ks_bytes), 0x00020000};
+    const ko_i32x4 srd_in = {(int)(unsigned)(uintptr_t)p.in, (int)(((uintptr_t)p.in >> 32) & 0xffff),
+                             (int)((unsigned)p.rows_total * (unsigned)p.W * (unsigned)p.Cin * 4u), 0x00020000};
+    auto forget_buf = [&](const ko_i32x4& srd, unsigned voff, unsigned soff) {
+      ko_i32x4 scratch;
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(scratch) : "v"(voff), "s"(srd), "s"(soff) : "memory");
+    };
+    auto forget_lds = [&](const __bf16* ptr) {
+      ko_i32x4 scratch;
+      const unsigned a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(const char*)ptr;
+      asm volatile("ds_read_b128 %0, %1" : "=v"(scratch) : "v"(a) : "memory");
+    };
     auto w_load = [&](int s, int gi, bf16x8 (&w)[2]) {
       const unsigned soff = (unsigned)(((s >> 1) * 12 + gi) * 2 + (s & 1)) * ks_bytes;
+      if ((W1_KO & 64) && fire) {
+        forget_buf(srd_w, wvoff, soff);
+        forget_buf(srd_w, wvoff + 1024u, soff);
+        return;
+      }
       w[0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff, soff, 0));
       w[1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff + 1024u, soff, 0));
     };
@@ -300,6 +323,11 @@ __global__ __launch_bounds__((W1Geom<TC, FULLW, WIDE>::THREADS), 2) void conv3x3
     auto patch_request = [&](int s, auto SET_) {
       constexpr int st = decltype(SET_)::value;
       const unsigned v0 = vbase + (unsigned)(s * KS * 4);
+      if ((W1_KO & 256) && fire) {
+#pragma unroll
+        for (int r = 0; r < NROW; ++r) forget_buf(srd_in, v0 + (unsigned)r * row_bytes, 0u);
+        return;
+      }
 #pragma unroll
       for (int r = 0; r < NROW; ++r)
         pre[st][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, v0 + (unsigned)r * row_bytes, 0, 0));
@@ -343,6 +371,11 @@ __global__ __launch_bounds__((W1Geom<TC, FULLW, WIDE>::THREADS), 2) void conv3x3
 #pragma unroll
         for (int m = 0; m < MW; ++m) {
           if ((kx == 0 && m == 0 && SL) || (kx == 2 && m == 1 && SR)) continue;
+          if ((W1_KO & 128) && fire) {
+            forget_lds(vh + pbase[m]);
+            forget_lds(vh + PLANE + pbase[m]);
+            continue;
+          }
           a[m][0] = *(const bf16x8*)(vh + pbase[m]);
           a[m][1] = *(const bf16x8*)(vh + PLANE + pbase[m]);
         }
@@ -361,6 +394,10 @@ __global__ __launch_bounds__((W1Geom<TC, FULLW, WIDE>::THREADS), 2) void conv3x3
           else if (more) patch_request(s + 1, NXT_);
         }
         if (!(W1_KO & 2) || s == sbeg) a_load(cur, 0, af[0]);
+        if (W1_KO & (64 | 128 | 256)) {
+          if (s == sbeg) a_load(cur, 1, af[1]);   // both fragment sets hold real data before the loads turn into requests only
+          fire = true;
+        }
 #pragma unroll
         for (int gi = 0; gi < 12; ++gi) {
           const int kx = gi >> 2, q = gi & 3;

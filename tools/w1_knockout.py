@@ -14,6 +14,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VARIANTS = [0, 1, 2, 4, 8, 12, 16, 32, 3, 15, 31, 47]
+FORGET = {f"ko{v}": [f"-DW1_KO={v}"] for v in (0, 64, 128, 256, 192, 448, 1, 2, 8, 15)}
 # --tune: named flag sets instead of knockouts
 CLK = {f"clk{v}": ["-DW1_CLK", f"-DW1_KO={v}"] for v in (0, 32, 31, 15, 3)}
 TUNE = {"base": [], "prio1": ["-DW1_PRIO=1"], "prio3": ["-DW1_PRIO=3"], "prio1sgb3": ["-DW1_PRIO=1", "-DW1_SGB=3"]}
@@ -24,7 +25,7 @@ def build(tune):
     from audiocaption_amd import build as B
     os.makedirs(BIN, exist_ok=True)
     src = os.path.join(ROOT, "audiocaption_amd", "csrc", "conv3x3_wino1d.hip")
-    todo = {f"ko{v}": [f"-DW1_KO={v}"] for v in VARIANTS} if not tune else (CLK if tune == "clk" else TUNE)
+    todo = {f"ko{v}": [f"-DW1_KO={v}"] for v in VARIANTS} if not tune else (CLK if tune == "clk" else (FORGET if tune == "forget" else TUNE))
     for name, flags in todo.items():
         out = os.path.join(BIN, f"libw1_{name}.so")
         cmd = [B._hipcc(), "-x", "hip", src, "-shared", "-o", out] + flags + B.FLAGS + B.NO_PACKED_F32 + \
@@ -40,13 +41,14 @@ def main():
     ap.add_argument("--build", action="store_true")
     ap.add_argument("--tune", action="store_true", help="the named tuning variants instead of the knockouts")
     ap.add_argument("--clk", action="store_true", help="shader clock (cycle counter / 100 MHz counter) per variant")
+    ap.add_argument("--forget", action="store_true", help="loads issued but not waited for (W1_KO 64 / 128 / 256)")
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--layers", default="b2c1,b2c2,b3c2,b4c2,b5c2,b6c2")
     args = ap.parse_args()
     if args.build:
-        return build("clk" if args.clk else args.tune)
-    names = list(CLK) if args.clk else (list(TUNE) if args.tune else [f"ko{v}" for v in VARIANTS])
+        return build("clk" if args.clk else ("forget" if args.forget else args.tune))
+    names = list(CLK) if args.clk else (list(FORGET) if args.forget else (list(TUNE) if args.tune else [f"ko{v}" for v in VARIANTS]))
     import torch
     from audiocaption_amd import kernels as K
     from tools.conv_bench import LAYERS
