@@ -20,7 +20,8 @@ decoding, token ids back on the host) over one resident batch.  Rank 0 prints ON
   ``value_f16x2_half_precision_gate`` (the opt-in fp16 tier: NOT reference precision), ``value_blocking_model_call`` (the
   reference's own call, one blocking ``model(input_dict)`` per step), ``latency_b1_greedy_ms`` / ``latency_b1_beam3_ms``
   (one 10 s clip through ``model()``, what demo.py / the HF surface run), ``train_clips_per_s`` (BASELINE configs[3]),
-  ``effb2_trm_clips_per_s`` (configs[2]);
+  ``effb2_trm_clips_per_s`` (configs[2]), ``clotho_shape_clips_per_s`` / ``clotho_shape_no_skip_clips_per_s`` (32 ragged
+  15-30 s clips, zero-padded: with / without dead-row skipping);
 * ``cpu_baseline``: the oracle (CPU restatement of the reference) on all physical host cores, median of 5 passes over a
   bounded 32-clip sample.
 The per-tier rooflines, the steady-state window, the decoder GEMM table, the training-step and EffB2 objects go to
@@ -662,6 +663,7 @@ def main():
     ap.add_argument("--effb2-batch", type=int, default=128, help="clips per GPU per step in the EffB2 measurement")
     ap.add_argument("--beam", type=int, default=3, help="beam size of the EffB2 measurement (0: greedy)")
     ap.add_argument("--no-effb2", action="store_true", help="skip the secondary EffB2-Trm measurement")
+    ap.add_argument("--no-ragged", action="store_true", help="skip the secondary Clotho-shape (ragged batch) measurement")
     ap.add_argument("--clotho-shape", action="store_true",
                     help="ragged Clotho-shape set (SURVEY 8(d)): durations ~ U[15 s, 30 s] zero-padded to the batch "
                          "maximum, wav_len = true lengths, clips dealt to the ranks by total duration")
@@ -893,6 +895,45 @@ def main():
                                                        "roofline", "rccl") if k in tr}
         except Exception as e:  # noqa: BLE001
             extra["train_step"] = {"error": f"{type(e).__name__}: {e}"}
+    if world == 1 and not args.no_ragged and not args.clotho_shape and not args.sync_steps:
+        # secondary: a Clotho-shaped ragged batch (durations ~ U[15 s, 30 s], zero-padded to the longest) with
+        # and without dead-row skipping - 32 clips, two resident batches, forward_async like the headline
+        try:
+            import numpy as np
+            rng = np.random.default_rng(P.BASE_SEED)
+            dur = rng.uniform(15.0, 30.0, size=32)
+            r_len = [int(d_ * 32000) for d_ in dur]
+            r_L = max(r_len)
+            r_in = []
+            for k in range(2):
+                full = P.synthetic_wav(32, r_L, seed=P.BASE_SEED + 77 + k)
+                for j, n in enumerate(r_len):
+                    full[j, n:] = 0.0
+                r_in.append({"mode": "inference", "wav": torch.from_numpy(full).to(dev), "wav_len": r_len, "specaug": False,
+                             "sample_method": "greedy", "max_length": args.max_length})
+
+            def r_steps(n):
+                pend = [model.forward_async(dict(r_in[i % 2])) for i in range(n)]
+                for p_ in pend:
+                    last = p_.result()
+                return last
+
+            ragged = {"clips": 32, "live_fraction": float(sum(r_len)) / (32.0 * r_L), "steps": 10}
+            keep = os.environ.get("AUDIOCAPTION_SKIP_DEAD_ROWS")
+            for tag, flag in (("skip", "1"), ("no_skip", "0")):
+                os.environ["AUDIOCAPTION_SKIP_DEAD_ROWS"] = flag
+                for n_prime in (5, 4, 4, 1, 1):
+                    r_steps(n_prime)
+                t_r, _ = timed_steps(ranks, r_steps, 10)
+                ragged[tag] = {"value": 32 * 10 / t_r, "unit": "clips/s", "ms_per_step": t_r / 10 * 1e3}
+            if keep is None:
+                os.environ.pop("AUDIOCAPTION_SKIP_DEAD_ROWS", None)
+            else:
+                os.environ["AUDIOCAPTION_SKIP_DEAD_ROWS"] = keep
+            del r_in
+            extra["ragged"] = ragged
+        except Exception as e:  # noqa: BLE001
+            extra["ragged"] = {"error": f"{type(e).__name__}: {e}"}
     if world == 1 and not args.no_effb2:
         # secondary: EffB2-Transformer inference (BASELINE configs[2])
         try:
@@ -975,12 +1016,14 @@ def main():
             "train_ms_per_step": val(extra.get("train_step"), "ms_per_step"),
             "effb2_trm_clips_per_s": val(extra.get("effb2_trm")),
             "logmel_hbm_frac": extra["mel_roofline"]["frac"],
+            "clotho_shape_clips_per_s": val((extra.get("ragged") or {}).get("skip")),
+            "clotho_shape_no_skip_clips_per_s": val((extra.get("ragged") or {}).get("no_skip")),
         }
         if multi is not None:
             result.update({"ranks": multi["ranks"], "seconds_per_rank": multi["seconds_per_rank"], "rccl": multi["rccl"]})
         details = {"tiers": tiers, "steady_state": steady, "blocking_model_call": blocking, "latency_b1_ms": latency,
                    "rooflines_other": {"logmel": extra["mel_roofline"], "decoder": extra["decoder_roofline"]},
-                   "train_step": extra.get("train_step"), "effb2_trm": extra.get("effb2_trm")}
+                   "train_step": extra.get("train_step"), "effb2_trm": extra.get("effb2_trm"), "ragged": extra.get("ragged")}
         if not args.no_cpu_baseline and world == 1:
             try:
                 from oracle import cpu_path as O  # the CPU restatement, timed as a reported baseline only
