@@ -37,7 +37,9 @@ __global__ __launch_bounds__(256, WPS) void mix(const i32x4* wts, unsigned wbyte
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][m][c][r] = 0.f;
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wts, 0, (int)wbytes, 0x00020000);
-  const unsigned wvoff = (unsigned)((blockIdx.x * 4 + wave) * 4096 % (wbytes / 2)) + lane * 16;
+  // barrier & 4: every workgroup streams the SAME weight bytes in the same order (what the real kernel's workgroups of one
+  // channel tile do); otherwise the workgroups are spread over the buffer
+  const unsigned wvoff = (unsigned)((((barrier & 4) ? 0 : blockIdx.x * 4) + wave) * 4096 % (wbytes / 2)) + lane * 16;
   bf16x8 a[2][MW][2], w[RING][CG][2];
   auto a_load = [&](int g, bf16x8 (&x)[MW][2]) {
 #pragma unroll
@@ -173,6 +175,8 @@ int main() {
     g_steps = st;
     printf("---- %d K steps per workgroup; barrier 1 = rows from L2, 3 = rows streamed from HBM\n", st);
     run<2, 1, 2, 1, 0>("no staging", w, wbytes, o, 1);
+    run<2, 1, 2, 1, 0>("no staging, one weight stream", w, wbytes, o, 5);
+    run<2, 1, 2, 1, 7>("all staging, one weight stream", w, wbytes, o, 5);
     run<2, 1, 2, 1, 7>("all staging", w, wbytes, o, 1);
     run<2, 1, 2, 1, 7>("all staging", w, wbytes, o, 3);
     run<2, 1, 2, 1, 7, 6, 1>("all staging, ring 6", w, wbytes, o, 3);
