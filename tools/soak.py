@@ -1,46 +1,61 @@
-"""Development soak: repeated inference steps must give identical tokens; a few hundred training iterations must stay
-finite and keep reducing the loss; EffB2 beam search must be repeatable."""
-import random
-import numpy as np
+"""Development tool: soak test of the throughput schedule - N steps of forward_async (pair decode while the decode stream is
+busy, encoders and chains on two streams) over four rotating batches, every result compared BIT FOR BIT with the blocking
+call's result for that batch; then the same with mixed batch sizes (one clip ... full batch: K-sliced and plain launches,
+lone and grouped chains).  Prints the number of mismatching results (must be 0)."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+
 import audiocaption_amd as A
-from audiocaption_amd import procedural as Pr
-from audiocaption_amd.optim import FusedAdam
-from audiocaption_amd.train import TrainEngine
+from audiocaption_amd import build, procedural as P
 
-model = A.init_model_from_config(A.cnn14rnn_trm_config(4981), print_fn=lambda s: None)
-model.load_state_dict(Pr.to_torch(Pr.cnn14rnn_trm_state(4981)), strict=True)
-model = model.cuda().eval()
-B, L = 64, 320000
-wav = torch.from_numpy(Pr.synthetic_wav(B, L, seed=3, varied=True)).cuda()
-inp = {"mode": "inference", "wav": wav, "wav_len": [L] * B, "specaug": False, "sample_method": "greedy", "max_length": 20}
-ref = model(dict(inp))["seq"]
-bad = 0
-pend = [model.forward_async(dict(inp)) for _ in range(100)]
-for p in pend:
-    bad += int(not torch.equal(p.result()["seq"], ref))
-for _ in range(50):
-    bad += int(not torch.equal(model(dict(inp))["seq"], ref))
-bref = model(dict(inp, sample_method="beam", beam_size=3))["seq"]
-for _ in range(20):
-    bad += int(not torch.equal(model(dict(inp, sample_method="beam", beam_size=3))["seq"], bref))
-print("inference mismatches over 170 repeats:", bad)
 
-model.train()
-g = torch.Generator().manual_seed(0)
-Bt = 16
-cap = torch.randint(4, 4981, (Bt, 14), generator=g)
-cap[:, 0], cap[:, -1] = 1, 2
-batch = {"mode": "train", "wav": wav[:Bt].contiguous(), "wav_len": [L] * Bt, "specaug": True, "cap": cap.cuda(),
-         "cap_len": np.array([14] * Bt), "ss_ratio": 0.8}
-eng = TrainEngine(model)
-opt = FusedAdam([p for p in model.parameters() if p.requires_grad], lr=5e-4, weight_decay=1e-6)
-random.seed(0)
-losses = []
-for it in range(300):
-    r = eng.step(batch, opt)
-    if it % 50 == 0 or it == 299:
-        losses.append(float(r["loss"]))
-print("training losses every 50 iterations:", [f"{v:.3f}" for v in losses], "finite:", all(np.isfinite(losses)))
-assert bad == 0 and all(np.isfinite(losses)) and losses[-1] < 0.5 * losses[0]
-print("soak OK")
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--method", default="greedy", choices=["greedy", "beam"])
+    args = ap.parse_args()
+    build.build()
+    vocab = 4368
+    model = A.init_model_from_config(A.cnn14rnn_trm_config(vocab), print_fn=lambda s: None)
+    model.load_state_dict(P.to_torch(P.cnn14rnn_trm_state(vocab)), strict=True)
+    model = model.eval().cuda()
+    L = int(32000 * args.seconds)
+    sizes = [args.batch, args.batch, args.batch, args.batch, 1, 3, 17, args.batch // 2]
+    inputs = []
+    for k, n in enumerate(sizes):
+        w = torch.from_numpy(P.synthetic_wav(n, L, seed=50 + k, varied=True)).cuda()
+        lens = [L - 3200 * ((i * 7 + k) % 5) for i in range(n)] if k >= 4 else [L] * n
+        inputs.append({"mode": "inference", "wav": w, "wav_len": lens, "specaug": False, "sample_method": args.method, "beam_size": 3, "max_length": 20})
+    keys = ("seq", "logit", "attn_emb") if args.method == "greedy" else ("seq", "attn_emb")   # beam search leaves logit unset
+    with torch.no_grad():
+        want = []
+        for d in inputs:
+            o = model(dict(d))
+            want.append({k: o[k].clone() for k in keys})
+        bad = 0
+        for phase, pick in (("uniform batches", lambda i: i % 4), ("mixed sizes", lambda i: (i * 5 + i // 3) % len(inputs))):
+            pend = []
+            for i in range(args.steps):
+                j = pick(i)
+                pend.append((j, model.forward_async(dict(inputs[j]))))
+                if len(pend) >= 6:   # a bounded queue, like a server: results are taken while later batches are in flight
+                    j0, p0 = pend.pop(0)
+                    g = p0.result()
+                    ok = all(torch.equal(g[k], want[j0][k]) for k in keys)
+                    bad += int(not ok)
+            for j0, p0 in pend:
+                g = p0.result()
+                bad += int(not all(torch.equal(g[k], want[j0][k]) for k in keys))
+            print(f"{phase}: {args.steps} steps, mismatching results so far: {bad}", flush=True)
+    print("SOAK", "OK" if bad == 0 else f"FAILED ({bad})")
+    return 0 if bad == 0 else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
