@@ -224,10 +224,13 @@ class TransformerModel(CaptionModel):
         enc_s, dec_s = self._streams
         cur = torch.cuda.current_stream(dev)
         enc_s.wait_stream(cur)  # inputs produced on the caller's stream
-        # AUDIOCAPTION_GRU_STREAM=decode runs a composite encoder (CrnnEncoder) in two halves: the convolutions on the encoder
-        # stream, the GRU at the head of the decode chain on the decode stream.  Measured SLOWER (6.05 vs 5.83 ms per step:
-        # the recurrence's workgroups wait for conv workgroups to leave), so the default keeps the encoder on one stream.
-        split_enc = hasattr(self.encoder, "forward_front") and os.environ.get("AUDIOCAPTION_GRU_STREAM", "encoder") == "decode"
+        # A composite encoder (CrnnEncoder) runs in two halves: the convolutions on the encoder stream, the GRU (six launches of
+        # latency-bound work: 0.4 ms in which the matrix cores idle) at the head of the decode chain on the decode stream, under
+        # the next batch's convolutions.  Measured: 6.20 -> 6.00 ms per step (10.3 k -> 10.7 k clips/s).  It was SLOWER (6.05 vs
+        # 5.83 ms) while every batch still had its own decode chain and the decode stream was the bottleneck; the split-GRU
+        # kernel's workgroup groups form by start order, so waiting for slots beside conv workgroups cannot deadlock
+        # (csrc/gru.hip).  AUDIOCAPTION_GRU_STREAM=encoder keeps the whole encoder on one stream.
+        split_enc = hasattr(self.encoder, "forward_front") and os.environ.get("AUDIOCAPTION_GRU_STREAM", "decode") == "decode"
         with torch.cuda.stream(enc_s):
             enc = self.encoder.forward_front(input_dict) if split_enc else self.encoder(input_dict)
             enc_done = torch.cuda.Event()
