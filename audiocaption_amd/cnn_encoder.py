@@ -211,8 +211,25 @@ class Cnn14Encoder(nn.Module):
         Hp = [hp6 << (5 - k) for k in range(6)]
         return T, H, Hp
 
+    def logmel_front(self, wav):
+        """The first kernel of ``encode`` on its own (log-mel + bn0 in the conv stack's layout), so that a caller can run it
+        on another stream ahead of the convolutions (TransformerModel.forward_async); pass the result back as ``x0``."""
+        dev = wav.device
+        self._ensure_tables(dev)
+        pk = self._pack(dev, self.effective_algo(None, False, None))
+        Hp = self.geometry(wav.shape[1])[2]
+        return K.logmel(wav, self._tables, pk["bn0"][0], pk["bn0"][1], rows_per_clip=Hp[0], channels_last=True)
+
+    def _ensure_tables(self, dev):
+        mkey = self.melspec_extractor.key()
+        if self._tables is None or self._tables.window.device != dev or self._tables_key != mkey:
+            self._tables = MelTables(self.sample_rate, self.n_fft, self.hop_length, self.f_min, self.f_max, 64,
+                                     "slaney", "slaney", dev, window=self.melspec_extractor.spectrogram.window,
+                                     fb=self.melspec_extractor.mel_scale.fb)
+            self._tables_key = mkey
+
     def encode(self, wav, dropout=None, specaug=None, train=False, min_frames=None, algo=None, overflow=None,
-               clip_frames=None):
+               clip_frames=None, x0=None):
         """wav (B, L) on the ROCm device -> attn_emb (B, T // 32, 2048).
 
         ``dropout = (p, op_code, seed_dev_ptr)``: the train-mode forward of the frozen network, F.dropout(p) after
@@ -234,19 +251,15 @@ class Cnn14Encoder(nn.Module):
         if wav.dim() != 2:
             raise ValueError("wav must be (batch, samples)")
         dev = wav.device
-        mkey = self.melspec_extractor.key()
-        if self._tables is None or self._tables.window.device != dev or self._tables_key != mkey:
-            self._tables = MelTables(self.sample_rate, self.n_fft, self.hop_length, self.f_min, self.f_max, 64,
-                                     "slaney", "slaney", dev, window=self.melspec_extractor.spectrogram.window,
-                                     fb=self.melspec_extractor.mel_scale.fb)
-            self._tables_key = mkey
+        self._ensure_tables(dev)
         # the "f16x2" tier keeps its activations in HBM as fp16; the train-mode forward (dropout on f32 block outputs,
         # parity pinned by tests/golden/g8_train.npz) stays on the split-bf16 tier
         algo = self.effective_algo(algo, train or dropout is not None, min_frames)
         pk = self._pack(dev, algo)
         B, L = wav.shape
         T, H, Hp = self.geometry(L)
-        x0 = K.logmel(wav, self._tables, pk["bn0"][0], pk["bn0"][1], rows_per_clip=Hp[0], channels_last=True)
+        if x0 is None:   # (given: computed by logmel_front on another stream; bn0 is the same for every tier)
+            x0 = K.logmel(wav, self._tables, pk["bn0"][0], pk["bn0"][1], rows_per_clip=Hp[0], channels_last=True)
         if specaug is not None:
             K.specaug_(x0, specaug, pk["bn0"][1], B, Hp[0], T)
         return self.conv_stack(x0, B, H, Hp, pk, algo, dropout, overflow=overflow,
@@ -338,7 +351,8 @@ class Cnn14Encoder(nn.Module):
         ragged = skip_fc and algo == "wino1d" and os.environ.get("AUDIOCAPTION_SKIP_DEAD_ROWS", "1") != "0" \
             and int(feat_length.min()) < int(feat_length.max())
         frames = K.upload(feat_length, wav.device, torch.int32) if ragged else None
-        attn_emb = self.encode(wav, min_frames=min_frames, algo=algo, overflow=flag, clip_frames=frames)
+        attn_emb = self.encode(wav, min_frames=min_frames, algo=algo, overflow=flag, clip_frames=frames,
+                               x0=input_dict.get("_logmel"))
         out = {"attn_emb": attn_emb, "attn_emb_len": feat_length}
         if flag is not None:
             # non-zero: an activation exceeded the fp16 range (65504) and this result must not be used -

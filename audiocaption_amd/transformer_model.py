@@ -231,6 +231,25 @@ class TransformerModel(CaptionModel):
         # kernel's workgroup groups form by start order, so waiting for slots beside conv workgroups cannot deadlock
         # (csrc/gru.hip).  AUDIOCAPTION_GRU_STREAM=encoder keeps the whole encoder on one stream.
         split_enc = hasattr(self.encoder, "forward_front") and os.environ.get("AUDIOCAPTION_GRU_STREAM", "decode") == "decode"
+        # The log-mel kernel (FFT on the vector ALUs and LDS: nothing the matrix-bound convolutions wait for) runs on a third
+        # stream, ahead of its batch's convolutions and under the previous batch's: 6.02 -> 5.94 ms per step, steady state
+        # 10.8 k -> 11.05 k clips/s.  (conv1 of block 1 beside it, into its own buffers: no gain - it is bound by 1 GB of HBM
+        # writes.)  AUDIOCAPTION_LOGMEL_STREAM=encoder keeps it on the encoder stream.
+        submitted = input_dict   # what the caller passed (kept for a possible re-run)
+        cnn = getattr(self.encoder, "cnn", None)
+        if (split_enc and hasattr(cnn, "logmel_front") and "_logmel" not in input_dict
+                and os.environ.get("AUDIOCAPTION_LOGMEL_STREAM", "front") == "front"):
+            if getattr(self, "_pre_stream", None) is None or self._pre_stream.device != dev:
+                self._pre_stream = torch.cuda.Stream(dev)
+            pre_s = self._pre_stream
+            pre_s.wait_stream(cur)
+            with torch.cuda.stream(pre_s):
+                x0 = cnn.logmel_front(input_dict["wav"])
+                x0.record_stream(enc_s)
+                pre_done = torch.cuda.Event()
+                pre_done.record(pre_s)
+            enc_s.wait_event(pre_done)
+            input_dict = dict(input_dict, _logmel=x0)
         with torch.cuda.stream(enc_s):
             enc = self.encoder.forward_front(input_dict) if split_enc else self.encoder(input_dict)
             enc_done = torch.cuda.Event()
@@ -246,7 +265,7 @@ class TransformerModel(CaptionModel):
                 enc_done.record(dec_s)
         max_length = int(input_dict.get("max_length", self.max_length))
         item = (PendingCaption(self), enc, enc_done, max_length)
-        item[0]._input = input_dict
+        item[0]._input = submitted
         # AUDIOCAPTION_DECODE_GROUP (default 2): submissions per chain at most (one chain per 1 / 2 / 3 / 4 batches of 64
         # clips: 6.39 / 6.21 / 6.05 / 6.04 ms per step over 24 steps, 6.37 / 6.08 / 6.03 / 5.91 over 60; the default bench run
         # of 20 steps measures 6.15 with 2 and 6.19 with 3 - its last chains run after the last encoder)
