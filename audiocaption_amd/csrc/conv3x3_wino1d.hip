@@ -33,6 +33,8 @@
 //   * Cout = 64 (conv2 of block 1, W = 64): the same 256-thread form over 8 pairs x 16 columns x 64 channels - waves =
 //     2 channel groups x 2 column halves, a tile is 8 pairs x 4 columns (18 x 18 staged positions for 16 x 16 outputs:
 //     the smallest halo of all forms; 78 KB of planes, two workgroups per CU).
+#include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 
 #include "ac_common.h"
@@ -190,11 +192,15 @@ __device__ __forceinline__ bool w1_block_live(const W1Params& p, int row0, int n
 //   !WIDE: [pair][staged column], pair pitch an odd number of slots;  WIDE: [staged column][pair], column pitch an odd
 //   number of slots - either way the 16 lanes of every ds_read_b128 group (16 consecutive pairs of one column, or 8
 //   pairs of one column + 8 of the next) land in 16 different slots.
-template <int TC, bool FULLW, bool WIDE>
+// CW: output channels per workgroup.  256 (wide form only, 512 threads = eight channel groups over the SAME 128 pixels, one
+// workgroup per CU): the row loads, the transform / split and the LDS stores of a pixel tile then feed twice the MFMAs -
+// that staging chain, not operand traffic, is what the kernel loses time to (tools/w1_mix_probe.hip: +9 ... 14 %).
+template <int TC, bool FULLW, bool WIDE, int CW = 128>
 struct W1Geom {
   static_assert(!WIDE || ((TC == 4 || TC == 16) && !FULLW), "the wide forms are 4 or 16 columns with halo");
   static constexpr bool C64 = TC == 16;                    // the 64-channel form (conv2 of block 1): see the kernel
-  static constexpr int THREADS = WIDE ? 256 : 512;
+  static_assert(CW == 128 || (CW == 256 && WIDE && TC == 4), "256-channel workgroups: the 4-column wide form only");
+  static constexpr int THREADS = WIDE ? (CW == 256 ? 512 : 256) : 512;
   static constexpr int PR = WIDE ? (C64 ? 8 : 16) : 128 / TC;   // pair rows per block
   static constexpr int COFF = FULLW ? 1 : 0;
   static constexpr int PWS = TC + 2 - 2 * COFF;            // staged columns: image columns col0 - 1 + COFF ..
@@ -210,9 +216,9 @@ struct W1Geom {
   static constexpr int NSET = WIDE ? W1_NSET : 1;                // register sets of raw rows in flight (see the kernel)
 };
 
-template <int MODE, int TC, bool FULLW, bool WIDE>
-__global__ __launch_bounds__((W1Geom<TC, FULLW, WIDE>::THREADS), 2) void conv3x3_w1_kernel(W1Params p) {
-  using G = W1Geom<TC, FULLW, WIDE>;
+template <int MODE, int TC, bool FULLW, bool WIDE, int CW = 128>
+__global__ __launch_bounds__((W1Geom<TC, FULLW, WIDE, CW>::THREADS), 2) void conv3x3_w1_kernel(W1Params p) {
+  using G = W1Geom<TC, FULLW, WIDE, CW>;
   constexpr int PR = G::PR, MW = 2, COFF = G::COFF, PWS = G::PWS, PLANE = G::PLANE, VBUF = G::VBUF;
   constexpr int PAIR_PITCH = G::PAIR_PITCH, COL_PITCH = G::COL_PITCH;
   constexpr int NP = G::NP, NROW = G::NROW, NITEM = G::NITEM;
@@ -221,7 +227,7 @@ __global__ __launch_bounds__((W1Geom<TC, FULLW, WIDE>::THREADS), 2) void conv3x3
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform for the compiler: scalar branches below
   constexpr bool C64 = G::C64;
-  const int wn = C64 ? (wave & 1) : (wave & 3), wg = C64 ? (wave >> 1) : (wave >> 2);
+  const int wn = C64 ? (wave & 1) : (CW == 256 ? wave : (wave & 3)), wg = C64 ? (wave >> 1) : (CW == 256 ? 0 : (wave >> 2));
   const int half = lane >> 5;
 
   int m_tile, n_tile;
@@ -274,7 +280,7 @@ __global__ __launch_bounds__((W1Geom<TC, FULLW, WIDE>::THREADS), 2) void conv3x3
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
         (void*)p.wpk, 0, (int)((unsigned)(p.Cin / 32) * 24u * ks_bytes), 0x00020000);
     // weight fragment of (K step s = 2 chunk + k-step, group gi = kx * 4 + p, plane) for this wave's 32 channels
-    const unsigned wvoff = (unsigned)((n_tile * (C64 ? 2 : 4) + wn) * 2048 + lane * 16);
+    const unsigned wvoff = (unsigned)((n_tile * (C64 ? 2 : CW / 32) + wn) * 2048 + lane * 16);
     typedef int ko_i32x4 __attribute__((ext_vector_type(4)));
     bool fire = false;   // W1_KO & (64 | 128 | 256): true inside the K loop
     const ko_i32x4 srd_w = {(int)(unsigned)(uintptr_t)p.wpk, (int)(((uintptr_t)p.wpk >> 32) & 0xffff),
@@ -480,7 +486,7 @@ __global__ __launch_bounds__((W1Geom<TC, FULLW, WIDE>::THREADS), 2) void conv3x3
   // ---- epilogue: output transform, BN, ReLU, pooling / mean, zero rows.  Lane l owns channel l % 32 and the MFMA rows
   // i = 8 (r / 4) + 4 (l / 32) + r % 4 of each tile: both rows of a pair, and the two columns of a pooling window / of the
   // last layer's mean - the wave's two tiles (!WIDE), registers r and r + 8 of one tile (WIDE) - sit in this lane ----
-  const int ch = n_tile * (C64 ? 64 : 128) + wn * 32 + (lane & 31);
+  const int ch = n_tile * (C64 ? 64 : CW) + wn * 32 + (lane & 31);
   const float sc = all_pad ? 0.f : p.scale[ch], sh = all_pad ? 0.f : p.shift[ch];   // dead blocks store zeros
   const FastDiv by_hp(p.Hp), by_hp_out(MODE == MODE_POOL ? p.Hp_out : 1);
 #pragma unroll
@@ -595,9 +601,9 @@ static inline int w1_slices(long wgs, int nstep, int* ksteps) {
   return (nstep + k - 1) / k;
 }
 
-template <int MODE, int TC, bool FULLW, bool WIDE>
+template <int MODE, int TC, bool FULLW, bool WIDE, int CW = 128>
 int launch_w1(W1Params p, hipStream_t s) {
-  using G = W1Geom<TC, FULLW, WIDE>;
+  using G = W1Geom<TC, FULLW, WIDE, CW>;
   const int pairs = p.rows_total / 2;
   p.MT = ((pairs + G::PR - 1) / G::PR) * p.mt_cols;
   unsigned grid;
@@ -608,7 +614,7 @@ int launch_w1(W1Params p, hipStream_t s) {
   constexpr size_t lds = (size_t)2 * G::VBUF * 2;   // two buffers of 4 positions x (hi, lo) planes, bf16
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv3x3_w1_kernel<MODE, TC, FULLW, WIDE>,
+    if (hipFuncSetAttribute((const void*)conv3x3_w1_kernel<MODE, TC, FULLW, WIDE, CW>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return AC_ERR_LAUNCH;
     attr_set = true;
@@ -618,7 +624,7 @@ int launch_w1(W1Params p, hipStream_t s) {
     slices = w1_slices(grid, p.Cin / KS, &p.ksteps);
     if (slices == 1) p.partial = nullptr;
   }
-  hipLaunchKernelGGL((conv3x3_w1_kernel<MODE, TC, FULLW, WIDE>), dim3(grid, slices), dim3(G::THREADS), lds, s, p);
+  hipLaunchKernelGGL((conv3x3_w1_kernel<MODE, TC, FULLW, WIDE, CW>), dim3(grid, slices), dim3(G::THREADS), lds, s, p);
   if (ac_check_launch() != 0) return AC_ERR_LAUNCH;
   if (slices > 1) {
     const long n_out = (MODE == MODE_FULL ? (long)p.rows_total * p.W : MODE == MODE_POOL ? (long)(p.rows_total / 2) * p.W_out
@@ -663,6 +669,7 @@ static int w1_dispatch(const float* in, const void* wfrag, const float* scale, c
   p.MT = 0;
   p.NT = c64 ? 1 : Cout / 128;
   p.Hp_out = Hp / 2; p.H_out = H / 2; p.W_out = W / 2;
+  const bool map_mode_auto = map_mode < 0;
   if (map_mode < 0) map_mode = (p.NT % 8 == 0) ? 1 : ((p.NT == 1 || p.NT == 2 || p.NT == 4) ? 3 : 2);
   if (map_mode == 1 && p.NT % 8 != 0) return AC_ERR_ARG;
   if (map_mode == 3 && !(p.NT == 1 || p.NT == 2 || p.NT == 4 || p.NT == 8)) return AC_ERR_ARG;
@@ -688,6 +695,19 @@ static int w1_dispatch(const float* in, const void* wfrag, const float* scale, c
     if (mode == MODE_FULL) return launch_w1<MODE_FULL, 4, true, false>(p, s);
     if (mode == MODE_POOL) return launch_w1<MODE_POOL, 4, true, false>(p, s);
     return AC_ERR_ARG;
+  }
+  // 256-channel workgroups (one staging per 256 channels) when that still leaves two rounds of workgroups for the chip;
+  // AUDIOCAPTION_W1_CW=128 keeps 128 everywhere (development)
+  static const bool cw128 = getenv("AUDIOCAPTION_W1_CW") && !strcmp(getenv("AUDIOCAPTION_W1_CW"), "128");
+  if (!cw128 && !p.partial && Cout % 256 == 0 && w1_grid(p.rows_total, W, Cout) / 2 >= 512) {
+    p.NT = Cout / 256;
+    if (map_mode_auto) p.map_mode = (p.NT % 8 == 0) ? 1 : ((p.NT == 1 || p.NT == 2 || p.NT == 4) ? 3 : 2);
+    if (!((p.map_mode == 1 && p.NT % 8 != 0) || (p.map_mode == 3 && !(p.NT == 1 || p.NT == 2 || p.NT == 4 || p.NT == 8)))) {
+      if (mode == MODE_FULL) return launch_w1<MODE_FULL, 4, false, true, 256>(p, s);
+      if (mode == MODE_POOL) return launch_w1<MODE_POOL, 4, false, true, 256>(p, s);
+    }
+    p.NT = Cout / 128;
+    p.map_mode = map_mode;
   }
   if (mode == MODE_FULL) return launch_w1<MODE_FULL, 4, false, true>(p, s);
   if (mode == MODE_POOL) return launch_w1<MODE_POOL, 4, false, true>(p, s);

@@ -250,6 +250,32 @@ def test_conv3x3_bn_relu(K, B, H, W, Cin, Cout, mode, map_mode, algo):
     assert _report(f"conv[{algo}] {B}x{H}x{W} {Cin}->{Cout} mode{mode}", out.reshape(want_rows.shape), want_rows) < tol
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,mode", [(16, 250, 16, 128, 256, 0), (16, 250, 16, 256, 256, 1), (34, 125, 8, 256, 512, 1)])
+def test_conv3x3_wino1d_256_channel_workgroups(K, B, H, W, Cin, Cout, mode):
+    """Launches with >= 1024 workgroups of the 128-channel wide form run as 256-channel workgroups (512 threads, one staging
+    of a pixel tile for eight channel groups): same per-channel arithmetic, so the result must equal the CPU reference like
+    the small shapes of test_conv3x3_bn_relu do - and, bit for bit, a launch too small to take that form (the first clips
+    alone)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(B + W + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * math.sqrt(2.0 / (9 * Cin))
+    sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    y = F.relu(F.conv2d(x, w, padding=1) * sc[None, :, None, None] + sh[None, :, None, None])
+    Hp = H + 1 + ((H + 1) % 2)
+    want = _to_rows(F.avg_pool2d(y, 2) if mode == 1 else y, Hp // 2 if mode == 1 else Hp)
+    shape = (B * Hp // 2, W // 2, Cout) if mode == 1 else (B * Hp, W, Cout)
+    xr, wp = _to_rows(x, Hp).cuda(), K.pack_conv_weight_wino1d_frag(w.cuda())
+    out = torch.full(shape, 7.0).cuda()
+    K.conv3x3_bn_relu_wino1d(xr, wp, sc.cuda(), sh.cuda(), out, B, Hp, H, W, Cin, Cout, mode)
+    tol = 1e-3 * max(1.0, math.sqrt(9 * Cin / 576))
+    assert _report(f"conv[wino1d, 256-channel workgroups] {B}x{H}x{W} {Cin}->{Cout} mode{mode}", out.reshape(want.shape), want) < tol
+    nb = 2                                                     # two clips: the 128-channel form
+    few = torch.full((nb * shape[0] // B,) + shape[1:], 7.0).cuda()
+    K.conv3x3_bn_relu_wino1d(xr[:nb * Hp].contiguous(), wp, sc.cuda(), sh.cuda(), few, nb, Hp, H, W, Cin, Cout, mode)
+    assert torch.equal(few, out[:few.shape[0]])
+
+
 @pytest.mark.parametrize("W,Cin,Cout,mode,block,conv", [(64, 64, 64, 1, 1, 2), (16, 128, 256, 0, 3, 1), (8, 512, 512, 1, 4, 2), (4, 512, 1024, 0, 5, 1),
                                                        (2, 1024, 2048, 0, 6, 1), (2, 2048, 2048, 2, 6, 2)])
 def test_conv3x3_wino1d_dead_row_skipping(K, W, Cin, Cout, mode, block, conv):

@@ -20,12 +20,13 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // 8 pieces (~110 VALU), 4 = their 16 ds_write_b64 at the kernel's addresses, a piece per group from group 4 on
 // RING: weight fragments in flight (RING - 1 groups ahead).  NSET = 2: the rows of step s + 2 are requested in step s and
 // consumed in step s + 1 (two register sets)
-template <int MW, int CG, int WPS, int APAT = 0, int STAGE = 0, int RING = 3, int NSET = 1>
-__global__ __launch_bounds__(256, WPS) void mix(const i32x4* wts, unsigned wbytes, float* out, int steps, int barrier,
+// NWAVE: waves per workgroup (8: the staging of one pixel tile feeds twice the channels; one workgroup per CU)
+template <int MW, int CG, int WPS, int APAT = 0, int STAGE = 0, int RING = 3, int NSET = 1, int NWAVE = 4>
+__global__ __launch_bounds__(64 * NWAVE, 2) void mix(const i32x4* wts, unsigned wbytes, float* out, int steps, int barrier,
                                                 const float* act = nullptr, unsigned abytes = 0) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int i = threadIdx.x; i < 48 * 1024 / 16; i += 256) ((i32x4*)lds)[i] = (i32x4){i, 1, 2, 3};
+  for (int i = threadIdx.x; i < 48 * 1024 / 16; i += 64 * NWAVE) ((i32x4*)lds)[i] = (i32x4){i, 1, 2, 3};
   __syncthreads();
   f32x16 acc[4][MW][CG];
 #pragma unroll
@@ -137,28 +138,28 @@ __global__ __launch_bounds__(256, WPS) void mix(const i32x4* wts, unsigned wbyte
       for (int c = 0; c < CG; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) sum += acc[q][m][c][r];
-  out[(size_t)blockIdx.x * 256 + threadIdx.x] = sum;
+  out[(size_t)blockIdx.x * 64 * NWAVE + threadIdx.x] = sum;
 }
 
 static int g_steps = 400;
 static const float* g_act;
 static unsigned g_abytes;
-template <int MW, int CG, int WPS, int APAT = 0, int STAGE = 0, int RING = 3, int NSET = 1>
+template <int MW, int CG, int WPS, int APAT = 0, int STAGE = 0, int RING = 3, int NSET = 1, int NWAVE = 4>
 void run(const char* tag, const i32x4* w, unsigned wbytes, float* o, int barrier) {
-  const int steps = g_steps, blocks = 256 * WPS * 4 * (400 / g_steps);   // 4 rounds of resident workgroups at 400 steps
-  hipFuncSetAttribute((const void*)mix<MW, CG, WPS, APAT, STAGE, RING, NSET>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  const int steps = g_steps, blocks = 256 * WPS * 4 * (400 / g_steps) * 4 / NWAVE;   // 4 rounds of resident workgroups at 400 steps
+  hipFuncSetAttribute((const void*)mix<MW, CG, WPS, APAT, STAGE, RING, NSET, NWAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 3; ++rep) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL((mix<MW, CG, WPS, APAT, STAGE, RING, NSET>), dim3(blocks), dim3(256), 64 * 1024, 0, w, wbytes, o, steps, barrier, g_act, g_abytes);
+    hipLaunchKernelGGL((mix<MW, CG, WPS, APAT, STAGE, RING, NSET, NWAVE>), dim3(blocks), dim3(64 * NWAVE), 64 * 1024, 0, w, wbytes, o, steps, barrier, g_act, g_abytes);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
   }
   float ms;
   hipEventElapsedTime(&ms, e0, e1);
-  const double mfma = (double)blocks * 4 * steps * 12 * MW * CG * 3;
-  const double lds_kb = (double)blocks * 4 * steps * 12 * MW * 2.0, l1_kb = (double)blocks * 4 * steps * 12 * CG * 2.0;
+  const double mfma = (double)blocks * NWAVE * steps * 12 * MW * CG * 3;
+  const double lds_kb = (double)blocks * NWAVE * steps * 12 * MW * 2.0, l1_kb = (double)blocks * NWAVE * steps * 12 * CG * 2.0;
   printf("%-28s barrier %d: %7.2f ms  %7.1f TFLOP/s issued  (per MFMA: %4.0f B LDS, %4.0f B L1)\n", tag, barrier, ms,
          mfma * 32768.0 / ms / 1e9, lds_kb * 1024 / mfma, l1_kb * 1024 / mfma);
 }
@@ -181,6 +182,8 @@ int main() {
     run<2, 1, 2, 1, 7>("all staging", w, wbytes, o, 3);
     run<2, 1, 2, 1, 7, 6, 1>("all staging, ring 6", w, wbytes, o, 3);
     run<2, 1, 2, 1, 7, 3, 2>("all staging, 2 row sets", w, wbytes, o, 3);
+    run<2, 1, 2, 1, 7, 3, 1, 8>("all staging, 8 waves per workgroup", w, wbytes, o, 1);
+    run<2, 1, 2, 1, 0, 3, 1, 8>("no staging, 8 waves per workgroup", w, wbytes, o, 1);
   }
   for (int b = 0; b < 0; ++b) {
     run<2, 1, 2>("MW 2 CG 1, 2 waves/SIMD", w, wbytes, o, b);
