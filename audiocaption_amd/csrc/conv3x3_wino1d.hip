@@ -48,7 +48,8 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // (results are then wrong).  1 weight loads, 2 A-fragment reads, 4 plane stores, 8 patch loads, 16 barrier, 32 MFMAs.
 // 64 / 128 / 256: the weight loads / A-fragment reads / patch loads of the K loop are still ISSUED (same addresses, same
 // traffic) but into scratch registers nothing waits for, the MFMAs and the transform run on the prologue's registers:
-// prices the waiting for operands separately from the moving of them.
+// prices the waiting for operands separately from the moving of them.  512 / 1024: the weight requests keep their number
+// and size but all hit the same 16 KB (L1) / the same 0.8 MB (L2): prices where the weights come from.
 #ifndef W1_KO
 #define W1_KO 0
 #endif
@@ -297,7 +298,9 @@ __global__ __launch_bounds__((W1Geom<TC, FULLW, WIDE, CW>::THREADS), 2) void con
       asm volatile("ds_read_b128 %0, %1" : "=v"(scratch) : "v"(a) : "memory");
     };
     auto w_load = [&](int s, int gi, bf16x8 (&w)[2]) {
-      const unsigned soff = (unsigned)(((s >> 1) * 12 + gi) * 2 + (s & 1)) * ks_bytes;
+      unsigned soff = (unsigned)(((s >> 1) * 12 + gi) * 2 + (s & 1)) * ks_bytes;
+      if (W1_KO & 512) soff = (unsigned)(gi & 1) * ks_bytes;   // every request hits the same 2 x 8 KB: weights from the L1
+      if (W1_KO & 1024) soff = (unsigned)((gi * 8 + (s & 7)) % 96) * ks_bytes;   // 96 blocks: 0.8 MB per channel tile (L2)
       if ((W1_KO & 64) && fire) {
         forget_buf(srd_w, wvoff, soff);
         forget_buf(srd_w, wvoff + 1024u, soff);

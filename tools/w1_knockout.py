@@ -14,7 +14,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VARIANTS = [0, 1, 2, 4, 8, 12, 16, 32, 3, 15, 31, 47]
-FORGET = {f"ko{v}": [f"-DW1_KO={v}"] for v in (0, 64, 128, 256, 192, 448, 1, 2, 8, 15)}
+FORGET = {f"ko{v}": [f"-DW1_KO={v}"] for v in (0, 512, 1024, 1, 8, 520, 15)}
 # --tune: named flag sets instead of knockouts
 CLK = {f"clk{v}": ["-DW1_CLK", f"-DW1_KO={v}"] for v in (0, 32, 31, 15, 3)}
 TUNE = {"base": [], "prio1": ["-DW1_PRIO=1"], "prio3": ["-DW1_PRIO=3"], "prio1sgb3": ["-DW1_PRIO=1", "-DW1_SGB=3"]}
