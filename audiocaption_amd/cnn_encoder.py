@@ -45,11 +45,17 @@ def wino1d_covers(cout):
     return cout % 128 == 0 or (cout == 64 and os.environ.get("AUDIOCAPTION_W1_C64", "1") != "0")
 
 
-def _conv_wino1d(x, w, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode=-1, need=None, splitk_buf=None):
+def _conv_wino1d(x, w, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode=-1, need=None, splitk_buf=None,
+                 dropout=None):
     """The "wino1d" tier's launcher (``_pack`` packs a layer's weights for the kernel ``wino1d_covers`` names).
     ``splitk_buf(floats) -> tensor``: workspace provider for the K-sliced launches of single clips."""
     if not wino1d_covers(Cout):
-        return K.conv3x3_bn_relu_bf16x3_gw(x, w, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode)
+        K.conv3x3_bn_relu_bf16x3_gw(x, w, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode)
+        if dropout is not None:
+            K.dropout_(out, out.numel() if mode != 1 else B * (Hp // 2) * (W // 2) * Cout, *dropout)
+        return out
+    if dropout is not None:   # F.dropout on the block's output in the kernel's epilogue (no extra pass over the buffer)
+        return K.conv3x3_bn_relu_wino1d(x, w, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode, dropout=dropout)
     ws = None
     if splitk_buf is not None:
         floats = K.wino1d_splitk_floats(B, Hp, W, Cin, Cout)
@@ -313,11 +319,15 @@ class Cnn14Encoder(nn.Module):
             else:
                 conv(pooled, w1, s1, t1, full, B, Hp[b], H[b], W, cin, cout, 0, **need(b + 1, 1))
             if b < 5:
+                fused_drop = dropout is not None and algo == "wino1d" and not (b == 0 and fuse1)
                 if not (b == 0 and fuse1):
-                    conv(full, w2, s2, t2, pool_out, B, Hp[b], H[b], W, cout, cout, 1, **(need(b + 1, 2) if algo != "wino1d" or wino1d_covers(cout) else {}))
+                    kw = need(b + 1, 2) if algo != "wino1d" or wino1d_covers(cout) else {}
+                    if fused_drop:   # the block's F.dropout in the conv kernel's epilogue
+                        kw = {"dropout": (dropout[0], dropout[1] + b, dropout[2])}
+                    conv(full, w2, s2, t2, pool_out, B, Hp[b], H[b], W, cout, cout, 1, **kw)
                 pooled = pool_out
                 W //= 2
-                if dropout is not None:
+                if dropout is not None and not fused_drop:
                     K.dropout_(pooled, B * Hp[b + 1] * W * cout, dropout[0], dropout[1] + b, dropout[2])
                 if blocks is not None:
                     blk = pooled[:B * Hp[b + 1] * W * cout].reshape(B, Hp[b + 1], W, cout)[:, :H[b + 1]]
@@ -328,8 +338,12 @@ class Cnn14Encoder(nn.Module):
                     conv(full, w2, s2, t2, attn, B, Hp[b], H[b], W, cout, cout, 2, **need(6, 2))
                 else:  # dropout sits between the last block and the mean over mel bins
                     last = self._buf("last", B * Hp[5] * W * cout, dev)
-                    conv(full, w2, s2, t2, last, B, Hp[b], H[b], W, cout, cout, 0)
-                    K.dropout_(last, B * Hp[5] * W * cout, dropout[0], dropout[1] + b, dropout[2])
+                    if algo == "wino1d":
+                        conv(full, w2, s2, t2, last, B, Hp[b], H[b], W, cout, cout, 0,
+                             dropout=(dropout[0], dropout[1] + b, dropout[2]))
+                    else:
+                        conv(full, w2, s2, t2, last, B, Hp[b], H[b], W, cout, cout, 0)
+                        K.dropout_(last, B * Hp[5] * W * cout, dropout[0], dropout[1] + b, dropout[2])
                     K.rows_mean_w(last, attn, B, Hp[5], H[5], W, cout)
         return attn
 

@@ -38,6 +38,7 @@
 #include <type_traits>
 
 #include "ac_common.h"
+#include "ac_drop.h"
 
 namespace {
 
@@ -94,6 +95,10 @@ struct W1Params {
   // epilogue.  partial == nullptr: one slice, epilogue in this kernel.
   float* partial;
   int ksteps;
+  // train-mode forward of the frozen network (F.dropout after every conv block, cnn_encoder.py:431-442): the mask of the
+  // output element with linear index i of the output buffer is the counter hash of csrc/ac_drop.h - what ac_dropout over
+  // that buffer would apply; thresh 0 = off
+  Drop drop;
 };
 
 enum { MODE_FULL = 0, MODE_POOL = 1, MODE_MEANW = 2 };
@@ -527,16 +532,18 @@ __global__ __launch_bounds__((W1Geom<TC, FULLW, WIDE, CW>::THREADS), 2) void con
       const int h = by_hp.mod(gr);   // Hp is even: both rows of a pair belong to one clip
 #pragma unroll
       for (int sl = 0; sl < NS; ++sl) {
-        float* o = p.out + ((size_t)gr * p.W + col0 + mcol0 + sl) * p.Cout + ch;
-        o[0] = h < p.H ? y0[sl] : 0.f;
-        o[(size_t)p.W * p.Cout] = h + 1 < p.H ? y1[sl] : 0.f;
+        const size_t oi = ((size_t)gr * p.W + col0 + mcol0 + sl) * p.Cout + ch;
+        float* o = p.out + oi;
+        o[0] = (h < p.H ? y0[sl] : 0.f) * p.drop.mask(oi);
+        o[(size_t)p.W * p.Cout] = (h + 1 < p.H ? y1[sl] : 0.f) * p.drop.mask(oi + (size_t)p.W * p.Cout);
       }
     } else if (MODE == MODE_POOL) {   // a row pair IS a pooled row; column slots (0, 1) and (2, 3) are pooled columns
       const bool valid = by_hp_out.mod(prow) < p.H_out;
 #pragma unroll
       for (int oc = 0; oc < NS / 2; ++oc) {
         const float o = 0.25f * ((y0[2 * oc] + y1[2 * oc]) + (y0[2 * oc + 1] + y1[2 * oc + 1]));
-        p.out[((size_t)prow * p.W_out + ((col0 + mcol0) >> 1) + oc) * p.Cout + ch] = valid ? o : 0.f;
+        const size_t oi = ((size_t)prow * p.W_out + ((col0 + mcol0) >> 1) + oc) * p.Cout + ch;
+        p.out[oi] = (valid ? o : 0.f) * p.drop.mask(oi);
       }
     } else {   // MEANW: TC == 2
       int h;
@@ -657,7 +664,8 @@ extern "C" int ac_w1_clk_read(unsigned long long* out3, int reset) {
 
 static int w1_dispatch(const float* in, const void* wfrag, const float* scale, const float* shift, float* out, int B,
                        int Hp, int H, int W, int Cin, int Cout, int mode, int map_mode, const int* clip_frames,
-                       int need_mul, int need_add, float* workspace, long workspace_floats, void* stream) {
+                       int need_mul, int need_add, float* workspace, long workspace_floats, void* stream,
+                       Drop drop = make_drop(0.f, 0, nullptr)) {
   if (!in || !wfrag || !scale || !shift || !out) return AC_ERR_ARG;
   const bool c64 = Cout == 64;   // conv2 of block 1: the 16-column form
   if (B <= 0 || Hp <= H || (Hp & 1) || W < 2 || (W != 2 && (W & 3)) || Cin % 32 || (Cout % 128 && !c64)) return AC_ERR_ARG;
@@ -679,7 +687,9 @@ static int w1_dispatch(const float* in, const void* wfrag, const float* scale, c
   p.map_mode = map_mode;
   p.clip_frames = clip_frames; p.need_mul = need_mul; p.need_add = need_add;
   p.partial = nullptr; p.ksteps = 0;
-  if (workspace) {   // K slices for launches of a few workgroups, if the caller's workspace holds them
+  p.drop = drop;
+  if (drop.thresh != 0 && mode == MODE_MEANW) return AC_ERR_ARG;   // dropout sits BEFORE the mean over mel: use mode 0
+  if (workspace && drop.thresh == 0) {   // K slices for launches of a few workgroups, if the caller's workspace holds them
     int ksteps;
     const int slices = w1_slices(w1_grid(p.rows_total, W, Cout), Cin / KS, &ksteps);
     if (slices > 1 && (long)slices * p.rows_total * W * Cout <= workspace_floats) p.partial = workspace;
@@ -741,4 +751,14 @@ extern "C" int ac_conv3x3_bn_relu_wino1d_splitk(const float* in, const void* wfr
   if (!workspace || workspace_floats <= 0) return AC_ERR_ARG;
   return w1_dispatch(in, wfrag, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode, clip_frames, need_mul, need_add,
                      workspace, workspace_floats, stream);
+}
+
+
+extern "C" int ac_conv3x3_bn_relu_wino1d_drop(const float* in, const void* wfrag, const float* scale, const float* shift,
+                                              float* out, int B, int Hp, int H, int W, int Cin, int Cout, int mode,
+                                              int map_mode, float drop_p, unsigned long long drop_seed,
+                                              const unsigned long long* seed_dev, void* stream) {
+  if (!(drop_p >= 0.f) || drop_p >= 1.f) return AC_ERR_ARG;
+  return w1_dispatch(in, wfrag, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode, nullptr, 0, 0, nullptr, 0, stream,
+                     make_drop(drop_p, drop_seed, seed_dev));
 }

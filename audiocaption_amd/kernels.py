@@ -155,19 +155,27 @@ def wino1d_splitk_floats(B, Hp, W, Cin, Cout):
 
 
 def conv3x3_bn_relu_wino1d(x, wfrag, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode=-1, need=None,
-                           workspace=None):
+                           workspace=None, dropout=None):
     """F(2,3) Winograd along time on split-bf16 operands (csrc/conv3x3_wino1d.hip); ``wfrag`` from
     ``pack_conv_weight_wino1d_frag``.  Covers Cout % 128 == 0 and Cout == 64 with W % 16 == 0 (conv2 of block 1); other
     layers must be routed to ``conv3x3_bn_relu_bf16x3_gw`` by the caller.  ``need = (clip_frames int32 device tensor, mul, add)``: ragged
     batches - output rows at or beyond ``mul * clip_frames[b] + add`` of clip b are not computed (stored as zeros).
-    ``workspace`` (f32 tensor of at least ``wino1d_splitk_floats`` elements): few-workgroup launches run K-sliced over it."""
+    ``workspace`` (f32 tensor of at least ``wino1d_splitk_floats`` elements): few-workgroup launches run K-sliced over it.
+    ``dropout = (p, seed, seed_dev)``: F.dropout on the layer's output inside the epilogue - the mask ``dropout_`` over
+    ``out`` with the same seed would apply (train-mode forward of the frozen network; modes 0 and 1, uniform batches)."""
     lib = _lib.load()
     hook = CONV_LAUNCH_HOOK
     if hook is not None:
         info = {"B": B, "H": H, "Hp": Hp, "W": W, "Cin": Cin, "Cout": Cout, "mode": mode, "algo": "wino1d"}
         hook("pre", info)
     cf, mul, add = need if need is not None else (None, 0, 0)
-    if workspace is not None:
+    if dropout is not None:
+        if cf is not None:
+            raise ValueError("conv3x3_bn_relu_wino1d: dropout and dead-row skipping are not combined")
+        check(lib.ac_conv3x3_bn_relu_wino1d_drop(ptr(x), ptr(wfrag), ptr(scale), ptr(shift), ptr(out), B, Hp, H, W, Cin, Cout,
+                                                 mode, map_mode, float(dropout[0]), int(dropout[1]), dropout[2], stream()),
+              "ac_conv3x3_bn_relu_wino1d_drop")
+    elif workspace is not None:
         check(lib.ac_conv3x3_bn_relu_wino1d_splitk(ptr(x), ptr(wfrag), ptr(scale), ptr(shift), ptr(out), B, Hp, H, W, Cin,
                                                    Cout, mode, map_mode, ptr(cf), int(mul), int(add), ptr(workspace),
                                                    workspace.numel(), stream()),

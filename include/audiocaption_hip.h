@@ -95,6 +95,14 @@ int ac_conv3x3_bn_relu_wino1d(const float* in, const void* wfrag, const float* s
  * pool / mean.  ac_conv3x3_wino1d_splitk_floats: floats of workspace the geometry needs, 0 when the launch is not split
  * (the call then equals ac_conv3x3_bn_relu_wino1d).  clip_frames / need_mul / need_add as above: skipped blocks come out
  * as zeros here too. */
+/* The same layer followed by F.dropout(drop_p) on its output (the train-mode forward of the frozen network,
+ * cnn_encoder.py:431-442), applied in the epilogue: output element i of the output buffer is scaled by the counter-hash
+ * mask ac_dropout(seed, seed_dev) gives index i - bit-identical to the layer followed by ac_dropout over the buffer,
+ * without the extra pass over it.  Modes 0 and 1 (the mean over mel of the last block comes after its dropout). */
+int ac_conv3x3_bn_relu_wino1d_drop(const float* in, const void* wfrag, const float* scale, const float* shift,
+                                   float* out, int B, int Hp, int H, int W, int Cin, int Cout, int mode, int map_mode,
+                                   float drop_p, unsigned long long drop_seed, const unsigned long long* seed_dev,
+                                   void* stream);
 long ac_conv3x3_wino1d_splitk_floats(int B, int Hp, int W, int Cin, int Cout);
 int ac_conv3x3_bn_relu_wino1d_splitk(const float* in, const void* wfrag, const float* scale, const float* shift,
                                      float* out, int B, int Hp, int H, int W, int Cin, int Cout, int mode,

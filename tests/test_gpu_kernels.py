@@ -343,6 +343,31 @@ def test_conv3x3_wino1d_k_sliced_launch(K, B, H, W, Cin, Cout, mode):
     assert K.wino1d_splitk_floats(64, 32, 2, 2048, 2048) == 0      # 16 row blocks x 16 channel tiles: not split
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,mode", [(2, 29, 64, 64, 64, 1), (3, 21, 16, 128, 256, 1), (4, 7, 2, 1024, 2048, 0),
+                                                  (2, 13, 4, 512, 1024, 1)])
+def test_conv3x3_wino1d_dropout_in_the_epilogue(K, B, H, W, Cin, Cout, mode):
+    """Train-mode forward of the frozen network: F.dropout on a block's output applied inside the conv kernel's epilogue
+    equals, bit for bit, the layer followed by the counter-hash dropout pass over its output buffer (same seed, same
+    element indices) - with and without the device-side step seed."""
+    g = torch.Generator().manual_seed(B * 31 + W)
+    Hp = H + 1 + ((H + 1) % 2)
+    x = torch.zeros(B, Hp, W, Cin)
+    x[:, :H] = torch.randn(B, H, W, Cin, generator=g)
+    x = x.reshape(B * Hp, W, Cin).cuda()
+    wp = K.pack_conv_weight_wino1d_frag((torch.randn(Cout, Cin, 3, 3, generator=g) * math.sqrt(2.0 / (9 * Cin))).cuda())
+    sc, sh = (torch.rand(Cout, generator=g) + 0.5).cuda(), (torch.randn(Cout, generator=g) * 0.1).cuda()
+    shape = (B * Hp, W, Cout) if mode == 0 else (B * Hp // 2, W // 2, Cout)
+    step = torch.tensor([5], dtype=torch.int64, device="cuda")
+    for seed_dev in (None, step.data_ptr()):
+        two, one = torch.full(shape, 7.0).cuda(), torch.full(shape, 7.0).cuda()
+        K.conv3x3_bn_relu_wino1d(x, wp, sc, sh, two, B, Hp, H, W, Cin, Cout, mode)
+        K.dropout_(two, two.numel(), 0.2, 1234, seed_dev)
+        K.conv3x3_bn_relu_wino1d(x, wp, sc, sh, one, B, Hp, H, W, Cin, Cout, mode, dropout=(0.2, 1234, seed_dev))
+        assert torch.equal(one, two)
+        kept = float((one != 0).float().mean()) / max(float((two != 0).float().mean()), 1e-9)
+        assert kept == 1.0 and 0.1 < float((one == 0).float().mean()) < 0.9
+
+
 def test_conv3x3_first(K):
     import torch.nn.functional as F
     g = torch.Generator().manual_seed(3)
