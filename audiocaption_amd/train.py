@@ -193,6 +193,36 @@ def allreduce_flat_gradients(flat_grad, process_group=None, async_op=False, algo
     return work if async_op else world
 
 
+class _SideStream:
+    """The backward's OFF-CHAIN work - weight-gradient products dW += dy^T x and bias column sums: nothing downstream reads
+    them before the optimiser - on a second stream beside the input-gradient chain (dx products, attention / LayerNorm /
+    GRU backward kernels: each a few tens of microseconds of latency-bound work that leaves most of the chip idle).
+    ``fork()`` makes the side stream wait for everything queued on the current stream and returns its handle; ``join()``
+    makes the current stream wait for the side stream - called before a buffer the side stream still reads is written
+    again, before kernels that accumulate into the same gradients, and at the end of every captured part.  Works inside HIP
+    graph capture (the side stream joins the capture through the event waits).  AUDIOCAPTION_TRAIN_SIDE_STREAM=0: off."""
+
+    def __init__(self):
+        self.enabled = os.environ.get("AUDIOCAPTION_TRAIN_SIDE_STREAM", "1") != "0"
+        self.stream = None
+        self.dirty = False
+
+    def fork(self):
+        cur = torch.cuda.current_stream()
+        if not self.enabled or GEMM_HOOK is not None:   # (the per-launch timing hook records events on the current stream)
+            return cur.cuda_stream
+        if self.stream is None or self.stream.device != cur.device:
+            self.stream = torch.cuda.Stream(cur.device)
+        self.stream.wait_stream(cur)
+        self.dirty = True
+        return self.stream.cuda_stream
+
+    def join(self):
+        if self.dirty:
+            torch.cuda.current_stream().wait_stream(self.stream)
+            self.dirty = False
+
+
 _WS_POISON = os.environ.get("AUDIOCAPTION_WS_POISON", "0") == "1"
 _DX_SPLITK = os.environ.get("AUDIOCAPTION_TRAIN_DX_SPLITK", "1") != "0"   # development: 0 = input gradients never split-K
 
@@ -756,6 +786,7 @@ class TrainEngine:
         dp = "decoder."
         fp.grad.zero_()
         self._seed_ptr = sv["small"].data_ptr()
+        side = self._side = getattr(self, "_side", None) or _SideStream()
         qrow0, qlen = lay["qrow0"].data_ptr(), lay["qlen"].data_ptr()
         mrow0, mklen = lay["mrow0"].data_ptr(), lay["mklen"].data_ptr()
         cls_rows = lay["cls_rows"].data_ptr()
@@ -765,7 +796,7 @@ class TrainEngine:
         xtop = sv["acts"][-1]["x3"]
         xlast = ws.f("xlast", NT, D)
         check(lib.ac_gather_rows(xtop, cls_rows, xlast, NT, D, s), "ac_gather_rows")
-        self._lin_dw(s, dl, V, xlast, D, fp.g(dp + "classifier.weight"), NT, V, D)
+        self._lin_dw(side.fork(), dl, V, xlast, D, fp.g(dp + "classifier.weight"), NT, V, D)
         dxlast = ws.f("dxlast", NT, D)
         self._lin_dx(s, dl, fp.p(dp + "classifier.weight"), dxlast, NT, V, D)
         dx = ws.f("dx_a", R, D)
@@ -786,23 +817,28 @@ class TrainEngine:
             op = OP_LAYER + 10 * l
             x_in = sv["x0"] if l == 0 else sv["acts"][l - 1]["x3"]
             # norm3 / feed-forward
+            side.join()   # dsub (and, a layer on, dhdn / dq2 / dkv / dqkv) are about to be written again
             check(lib.ac_dropadd_ln_bwd(dx, a["pre3"], fp.p(lp + "norm3.weight"), dsub, dres, 0, None, 0,
                                         fp.g(lp + "norm3.weight"), fp.g(lp + "norm3.bias"), R, D, p_dec, op + 5,
                                         self._seed_ptr, 1e-5, s), "ln3 bwd")
-            self._lin_dw(s, dsub, D, a["hdn"], F, fp.g(lp + "linear2.weight"), R, D, F)
-            self._colsum(s, dsub, D, fp.g(lp + "linear2.bias"), R, D)
+            s2 = side.fork()
+            self._lin_dw(s2, dsub, D, a["hdn"], F, fp.g(lp + "linear2.weight"), R, D, F)
+            self._colsum(s2, dsub, D, fp.g(lp + "linear2.bias"), R, D)
             self._lin_dx(s, dsub, fp.p(lp + "linear2.weight"), dhdn, R, D, F)
             check(lib.ac_mask_pos_scale(dhdn, a["hdn"], R * F, scale, s), "ac_mask_pos_scale")
-            self._lin_dw(s, dhdn, F, a["x2"], D, fp.g(lp + "linear1.weight"), R, F, D)
-            self._colsum(s, dhdn, F, fp.g(lp + "linear1.bias"), R, F)
+            s2 = side.fork()
+            self._lin_dw(s2, dhdn, F, a["x2"], D, fp.g(lp + "linear1.weight"), R, F, D)
+            self._colsum(s2, dhdn, F, fp.g(lp + "linear1.bias"), R, F)
             self._lin_dx(s, dhdn, fp.p(lp + "linear1.weight"), dres, R, F, D, beta=1.0)
             dx, dres = dres, dx                                   # dx = d(x2)
             # norm2 / cross attention
+            side.join()
             check(lib.ac_dropadd_ln_bwd(dx, a["pre2"], fp.p(lp + "norm2.weight"), dsub, dres, 0, None, 0,
                                         fp.g(lp + "norm2.weight"), fp.g(lp + "norm2.bias"), R, D, p_dec, op + 3,
                                         self._seed_ptr, 1e-5, s), "ln2 bwd")
-            self._lin_dw(s, dsub, D, a["ctx2"], D, fp.g(lp + "multihead_attn.out_proj.weight"), R, D, D)
-            self._colsum(s, dsub, D, fp.g(lp + "multihead_attn.out_proj.bias"), R, D)
+            s2 = side.fork()
+            self._lin_dw(s2, dsub, D, a["ctx2"], D, fp.g(lp + "multihead_attn.out_proj.weight"), R, D, D)
+            self._colsum(s2, dsub, D, fp.g(lp + "multihead_attn.out_proj.bias"), R, D)
             self._lin_dx(s, dsub, fp.p(lp + "multihead_attn.out_proj.weight"), dctx, R, D, D)
             kvl = sv["kv"][l]
             check(lib.ac_attn_seq_bwd(a["q2"], D, kvl, 2 * D, kvl + 4 * D, 2 * D, sv["P2"][l], T, Tm, dctx, D, dq2, D, dkv,
@@ -810,27 +846,32 @@ class TrainEngine:
                                       op + 2, self._seed_ptr, s), "ac_attn_seq_bwd(cross)")
             w_in, g_in = fp.p(lp + "multihead_attn.in_proj_weight"), fp.g(lp + "multihead_attn.in_proj_weight")
             b_in_g = fp.g(lp + "multihead_attn.in_proj_bias")
-            self._lin_dw(s, dq2, D, a["x1"], D, g_in, R, D, D)
-            self._colsum(s, dq2, D, b_in_g, R, D)
+            s2 = side.fork()
+            self._lin_dw(s2, dq2, D, a["x1"], D, g_in, R, D, D)
+            self._colsum(s2, dq2, D, b_in_g, R, D)
+            self._lin_dw(s2, dkv, 2 * D, sv["mem"], D, g_in + 4 * D * D, Rm, 2 * D, D)
+            self._colsum(s2, dkv, 2 * D, b_in_g + 4 * D, Rm, 2 * D)
             self._lin_dx(s, dq2, w_in, dres, R, D, D, beta=1.0)
-            self._lin_dw(s, dkv, 2 * D, sv["mem"], D, g_in + 4 * D * D, Rm, 2 * D, D)
-            self._colsum(s, dkv, 2 * D, b_in_g + 4 * D, Rm, 2 * D)
             self._lin_dx(s, dkv, w_in + 4 * D * D, dmem, Rm, 2 * D, D, beta=0.0 if l == nlay - 1 else 1.0)
             dx, dres = dres, dx                                   # dx = d(x1)
             # norm1 / self attention
+            side.join()
             check(lib.ac_dropadd_ln_bwd(dx, a["pre1"], fp.p(lp + "norm1.weight"), dsub, dres, 0, None, 0,
                                         fp.g(lp + "norm1.weight"), fp.g(lp + "norm1.bias"), R, D, p_dec, op + 1,
                                         self._seed_ptr, 1e-5, s), "ln1 bwd")
-            self._lin_dw(s, dsub, D, a["ctx1"], D, fp.g(lp + "self_attn.out_proj.weight"), R, D, D)
-            self._colsum(s, dsub, D, fp.g(lp + "self_attn.out_proj.bias"), R, D)
+            s2 = side.fork()
+            self._lin_dw(s2, dsub, D, a["ctx1"], D, fp.g(lp + "self_attn.out_proj.weight"), R, D, D)
+            self._colsum(s2, dsub, D, fp.g(lp + "self_attn.out_proj.bias"), R, D)
             self._lin_dx(s, dsub, fp.p(lp + "self_attn.out_proj.weight"), dctx, R, D, D)
             check(lib.ac_attn_seq_bwd(a["qkv"], 3 * D, a["qkv"] + 4 * D, 3 * D, a["qkv"] + 8 * D, 3 * D, sv["P1"][l], T, T,
                                       dctx, D, dqkv, 3 * D, dqkv + 4 * D, 3 * D, dqkv + 8 * D, 3 * D, qrow0, qlen, qrow0,
                                       qlen, 0, S, nh, 64, T, T, p_dec, op + 0, self._seed_ptr, s), "ac_attn_seq_bwd")
-            self._lin_dw(s, dqkv, 3 * D, x_in, D, fp.g(lp + "self_attn.in_proj_weight"), R, 3 * D, D)
-            self._colsum(s, dqkv, 3 * D, fp.g(lp + "self_attn.in_proj_bias"), R, 3 * D)
+            s2 = side.fork()
+            self._lin_dw(s2, dqkv, 3 * D, x_in, D, fp.g(lp + "self_attn.in_proj_weight"), R, 3 * D, D)
+            self._colsum(s2, dqkv, 3 * D, fp.g(lp + "self_attn.in_proj_bias"), R, 3 * D)
             self._lin_dx(s, dqkv, fp.p(lp + "self_attn.in_proj_weight"), dres, R, 3 * D, D, beta=1.0)
             dx, dres = dres, dx                                   # dx = d(layer input)
+        side.join()   # the embedding's gradient may be the classifier's (tied weights): no two writers at once
         check(lib.ac_embed_bwd(dx, sv["word"], fp.g(dp + "word_embedding.weight"), R, D, p_dec, OP_EMB_A, p_dec, OP_EMB_B,
                                self._seed_ptr, s), "ac_embed_bwd")
 
@@ -842,13 +883,15 @@ class TrainEngine:
         da = ws.f("da", rows_m, D)
         check(lib.ac_sum_replicas(da_rep, da, rows_m * D, NP, s), "ac_sum_replicas")
         A = 2 * H
-        self._lin_dw(s, da, D, sv["attn_emb"], A, fp.g(dp + "attn_proj.0.weight"), rows_m, D, A)
-        self._colsum(s, da, D, fp.g(dp + "attn_proj.0.bias"), rows_m, D)
+        s2 = side.fork()
+        self._lin_dw(s2, da, D, sv["attn_emb"], A, fp.g(dp + "attn_proj.0.weight"), rows_m, D, A)
+        self._colsum(s2, da, D, fp.g(dp + "attn_proj.0.bias"), rows_m, D)
         rows_g = B * Tq
         dout = ws.f("gru_dout", rows_g, A)
         self._lin_dx(s, da, fp.p(dp + "attn_proj.0.weight"), dout, rows_m, D, A)
         if part == "all":
             self._launch_backward_gru(sv)
+        side.join()   # every decoder gradient is final (the all-reduce of part "head" reads them next)
 
     def _launch_backward_gru(self, sv):
         model, lib, fp = self.model, self.lib, self.flat
@@ -863,24 +906,32 @@ class TrainEngine:
         dout = ws.f("gru_dout", rows_g, A)
         lens_p = sv["small"].data_ptr() + 8
         nl = enc.rnn.num_layers
-        dgx, dgh, hprev = ws.f("dgx", rows_g, 6 * H), ws.f("dgh", rows_g, 6 * H), ws.f("hprev", rows_g, 2 * H)
+        side = self._side = getattr(self, "_side", None) or _SideStream()
         pre = "encoder.rnn.network."
         for l in reversed(range(nl)):
             g = sv["gru"][l]
+            # two sets of the recurrence's gradient buffers: layer l's weight gradients (side stream) read set l % 2 while layer
+            # l - 1's backward through time fills the other one
+            k_ = l & 1
+            dgx, dgh, hprev = ws.f(f"dgx{k_}", rows_g, 6 * H), ws.f(f"dgh{k_}", rows_g, 6 * H), ws.f(f"hprev{k_}", rows_g, 2 * H)
+            if l + 2 < nl:
+                side.join()   # this set was read by layer l + 2's weight gradients
             if l < nl - 1 and p_rnn > 0:
                 check(lib.ac_dropout(dout, dout, rows_g * A, p_rnn, OP_GRU_LAYER + l, self._seed_ptr, 0, s), "ac_dropout")
             check(lib.ac_gru_layer_bwd(dout, g["out"], ws.f(f"gru_save{l}", rows_g, 8 * H), fp.p(f"{pre}weight_hh_l{l}"),
                                        lens_p, dgx, dgh, hprev, B, Tq, H, s), "ac_gru_layer_bwd")
-            self._lin_dw(s, dgx, 6 * H, g["x"], g["in_dim"], fp.g(f"{pre}weight_ih_l{l}"), rows_g, 6 * H, g["in_dim"])
-            self._colsum(s, dgx, 6 * H, fp.g(f"{pre}bias_ih_l{l}"), rows_g, 6 * H)
-            self._colsum(s, dgh, 6 * H, fp.g(f"{pre}bias_hh_l{l}"), rows_g, 6 * H)
+            s2 = side.fork()
+            self._lin_dw(s2, dgx, 6 * H, g["x"], g["in_dim"], fp.g(f"{pre}weight_ih_l{l}"), rows_g, 6 * H, g["in_dim"])
+            self._colsum(s2, dgx, 6 * H, fp.g(f"{pre}bias_ih_l{l}"), rows_g, 6 * H)
+            self._colsum(s2, dgh, 6 * H, fp.g(f"{pre}bias_hh_l{l}"), rows_g, 6 * H)
             for d_ in range(2):
                 # dW_hh[dir] (3H, H) += dgh[:, dir]^T hprev[:, dir]
                 sk = self._splitk(3 * H, H, rows_g)
-                self._gemm(s, dgh + 4 * d_ * 3 * H, 1, 6 * H, hprev + 4 * d_ * H, 2 * H, 1,
+                self._gemm(s2, dgh + 4 * d_ * 3 * H, 1, 6 * H, hprev + 4 * d_ * H, 2 * H, 1,
                            fp.g(f"{pre}weight_hh_l{l}") + 4 * d_ * 3 * H * H, H, 3 * H, H, rows_g, None, 0, 1.0, sk)
             if l > 0:
                 self._lin_dx(s, dgx, fp.p(f"{pre}weight_ih_l{l}"), dout, rows_g, 6 * H, g["in_dim"])
+        side.join()
 
     # ---- fast path: forward + loss + backward (+ gradient all-reduce) + clip + Adam -----------------------
     def _launch_part(self, st, smoothing, part):
