@@ -1,61 +1,54 @@
-"""Token ids <-> text.  Plugin-compatible with the reference's ``DictTokenizer``
-(captioning/datasets/text_tokenizer.py:8-79: ``<pad>`` 0, ``<start>`` 1, ``<end>`` 2, ``<unk>`` 3, then the corpus words;
-pickled word->index dict) and the prediction file the runners write (python_scripts/train_eval/base.py:212-224,
-295-305).  Pure host code: it consumes the (B, max_length) int64 CPU tensor the models return."""
+"""Token ids <-> text: the step right after the hot path.
+
+Plugin-compatible with the reference's ``DictTokenizer`` (captioning/datasets/text_tokenizer.py:8-79) - same class and
+method names, the same pickled ``word -> index`` dict as checkpoint format, ``<pad>`` 0, ``<start>`` 1, ``<end>`` 2, ``<unk>``
+3 ahead of the corpus words - and with the prediction file the runners write (python_scripts/train_eval/base.py:212-224,
+295-305).  Host code, written around what the accelerated path hands over: ONE (B, max_length) int64 CPU array per batch,
+so ``decode`` works on the whole array (first end token per row found with array operations, one vocabulary lookup table)
+and ``__call__`` fills one padded int64 matrix."""
 import json
 import os
 import pickle
 
 import numpy as np
 
+SPECIALS = ("<pad>", "<start>", "<end>", "<unk>")
+
 
 class DictTokenizer:
 
     def __init__(self, tokenizer_path=None, max_length=20):
-        self.word2idx, self.idx2word, self.idx = {}, {}, 0
-        for w in ("<pad>", "<start>", "<end>", "<unk>"):
-            self.add_word(w)
+        self.max_length = max_length
         self.loaded = False
+        self._adopt({w: i for i, w in enumerate(SPECIALS)})
         if tokenizer_path is not None and os.path.exists(tokenizer_path):
             with open(tokenizer_path, "rb") as f:
                 self.load_state_dict(pickle.load(f))
             self.loaded = True
-        self.bos, self.eos, self.pad = self.word2idx["<start>"], self.word2idx["<end>"], self.word2idx["<pad>"]
-        self.max_length = max_length
+
+    # ---- vocabulary ---------------------------------------------------------------------------------------------------
+    def _adopt(self, word2idx):
+        """Take a word -> index dict as THE vocabulary and derive what the other methods use from it."""
+        self.word2idx = word2idx
+        self.idx = len(word2idx)
+        size = max(word2idx.values(), default=-1) + 1
+        table = np.full(size, "<unk>", dtype=object)           # index -> word, for decode
+        for w, i in word2idx.items():
+            table[i] = w
+        self._table = table
+        self.bos, self.eos, self.pad = (word2idx[w] for w in ("<start>", "<end>", "<pad>"))
+        self._unk = word2idx["<unk>"]
+
+    @property
+    def idx2word(self):
+        return {i: w for w, i in self.word2idx.items()}
 
     def add_word(self, word):
         if word not in self.word2idx:
-            self.word2idx[word] = self.idx
-            self.idx2word[self.idx] = word
-            self.idx += 1
+            self._adopt(dict(self.word2idx, **{word: self.idx}))
 
     def encode_word(self, word):
-        return self.word2idx.get(word, self.word2idx["<unk>"])
-
-    def __call__(self, texts):
-        assert isinstance(texts, list), "the input must be List[str]"
-        rows = []
-        for text in texts:
-            tokens = [self.encode_word(t) for t in text.split()][:self.max_length]
-            rows.append(np.array([self.bos] + tokens + [self.eos]))
-        lens = np.array([len(r) for r in rows])
-        caps = np.full((len(rows), int(lens.max())), self.pad, dtype=np.int64)
-        for i, r in enumerate(rows):
-            caps[i, :len(r)] = r
-        return {"cap": caps, "cap_len": lens}
-
-    def decode(self, batch_token_ids):
-        out = []
-        for ids in np.asarray(batch_token_ids):
-            words = []
-            for t in ids.tolist():
-                if t == self.eos:
-                    break
-                if t == self.bos:
-                    continue
-                words.append(self.idx2word[t])
-            out.append(" ".join(words))
-        return out
+        return self.word2idx.get(word, self._unk)
 
     def __len__(self):
         return len(self.word2idx)
@@ -64,14 +57,39 @@ class DictTokenizer:
         return self.word2idx
 
     def load_state_dict(self, state_dict):
-        self.word2idx = state_dict
-        self.idx2word = {i: w for w, i in state_dict.items()}
-        self.idx = len(state_dict)
+        self._adopt(dict(state_dict))
+
+    # ---- text -> ids (training captions) -------------------------------------------------------------------------------
+    def __call__(self, texts):
+        if not isinstance(texts, list):
+            raise TypeError("DictTokenizer expects a list of caption strings")
+        lookup, unk, keep = self.word2idx, self._unk, self.max_length
+        ids = [[lookup.get(w, unk) for w in t.split()[:keep]] for t in texts]
+        lens = np.fromiter((len(r) + 2 for r in ids), dtype=np.int64, count=len(ids))
+        caps = np.full((len(ids), int(lens.max()) if len(ids) else 0), self.pad, dtype=np.int64)
+        caps[:, 0] = self.bos
+        for r, (row, n) in enumerate(zip(ids, lens)):
+            caps[r, 1:n - 1] = row
+            caps[r, n - 1] = self.eos
+        return {"cap": caps, "cap_len": lens}
+
+    # ---- ids -> text (what the model returns) --------------------------------------------------------------------------
+    def decode(self, batch_token_ids):
+        ids = np.asarray(batch_token_ids)
+        if ids.ndim == 1:
+            ids = ids[None]
+        ended = ids == self.eos
+        stop = np.where(ended.any(axis=1), ended.argmax(axis=1), ids.shape[1])   # first end token of every row
+        words = self._table[np.clip(ids, 0, len(self._table) - 1)]
+        show = (np.arange(ids.shape[1])[None] < stop[:, None]) & (ids != self.bos)
+        return [" ".join(row[m]) for row, m in zip(words, show)]
 
 
 def write_predictions(key2pred, path):
     """The runners' prediction file: {"predictions": [{"filename": key, "tokens": caption}, ...]} (base.py:295-305)."""
-    data = [{"filename": k, "tokens": v[0] if isinstance(v, (list, tuple)) else v} for k, v in key2pred.items()]
+    rows = []
+    for key, pred in key2pred.items():
+        rows.append({"filename": key, "tokens": pred[0] if isinstance(pred, (list, tuple)) else pred})
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     with open(path, "w") as f:
-        json.dump({"predictions": data}, f, indent=4)
+        json.dump({"predictions": rows}, f, indent=4)

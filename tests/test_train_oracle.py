@@ -156,6 +156,27 @@ def test_dict_tokenizer_roundtrip_and_prediction_file(tmp_path):
                                                            {"filename": "y.wav", "tokens": "a dog"}]}
 
 
+def test_dict_tokenizer_vs_reference_fixture(golden_dir, tmp_path):
+    """audiocaption_amd.text.DictTokenizer against what the reference's tokenizer returned on the same seeded vocabulary,
+    captions (unknown words, truncation to max_length, ragged lengths) and id matrices (rows with / without <start>, an
+    <end> in the middle, <pad> / <unk> ids): tests/golden/make_tokenizer_golden.py."""
+    import json
+    import pickle
+    from audiocaption_amd.text import DictTokenizer
+    g = json.load(open(os.path.join(golden_dir, "g12_tokenizer.json")))
+    p = tmp_path / "vocab.pkl"
+    p.write_bytes(pickle.dumps(g["vocab"]))
+    tok = DictTokenizer(str(p), max_length=g["max_length"])
+    assert len(tok) == g["len"] and tok.state_dict() == g["vocab"]
+    enc = tok(g["texts"])
+    assert enc["cap"].tolist() == g["cap"] and np.asarray(enc["cap_len"]).tolist() == g["cap_len"]
+    assert tok.decode(np.array(g["seqs"])) == g["decoded"]
+    grown = DictTokenizer(max_length=g["max_length"])             # built word by word like the reference's vocabulary builder
+    for w, i in sorted(g["vocab"].items(), key=lambda kv: kv[1]):
+        grown.add_word(w)
+    assert grown.state_dict() == g["vocab"] and grown.decode(np.array(g["seqs"])) == g["decoded"]
+
+
 def test_swa_averager_on_cpu_tensors():
     from audiocaption_amd.trainer import SwaAverager
     m = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.BatchNorm1d(3))
