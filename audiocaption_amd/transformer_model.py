@@ -317,12 +317,13 @@ class TransformerModel(CaptionModel):
                 input_dict.get("temp", 1.0), bool(input_dict.get("n_best", False)), input_dict.get("n_best_size"))
 
     def _run_lazy(self, pending):
-        """The beam search of a submitted batch, on the decode stream.  AUDIOCAPTION_BEAM_GROUP=n (default 1) searches up to n
+        """The beam search of a submitted batch, on the decode stream.  AUDIOCAPTION_BEAM_GROUP=n (default 2) searches up to n
         consecutive submissions with the same search parameters as ONE batch and splits the results (clips are independent:
         the same token ids as separate searches; a clip that has its `beam` finished beams is retired whatever the other
-        clips do).  Unlike the 64-row greedy chain, the search over 384 rows is no pure latency chain: measured on
-        EffB2-Trm (128 clips, beam 3) two submissions as one search cost 8.8 ms per submission against 7.9 ms separately,
-        so grouping stays opt-in."""
+        clips do).  Beside running encoders a search is slowed by every one of its ~260 dependent launches waiting for
+        workgroup slots, so one search per two submissions wins: EffB2-Trm (128 clips, beam 3) 7.60 -> 7.08 ms per
+        submission (16.8 k -> 18.1 k clips/s); 3 / 4 submissions per search: 7.16 / 7.14 ms.  (In round 2, before the
+        decode-side changes of round 3, the grouped search measured slower: 8.8 vs 7.9 ms.)"""
         refs = getattr(self, "_lazy_queue", None) or []
         queue = [q for q in (r() for r in refs) if q is not None and q._lazy is not None]
         # AUDIOCAPTION_BEAM_CONCURRENT=n (default 1): the searches of n consecutive submissions run side by side, each on
@@ -330,7 +331,7 @@ class TransformerModel(CaptionModel):
         # (128 clips, beam 3): 9.4 ms per submission with two searches in flight, 8.9 with three, 7.7 one by one - the
         # search over 384 rows is not waiting for CU slots, it shares the device's throughput with the next encoders.
         conc = max(1, int(os.environ.get("AUDIOCAPTION_BEAM_CONCURRENT", "1")))
-        limit = max(1, int(os.environ.get("AUDIOCAPTION_BEAM_GROUP", "1")))
+        limit = max(1, int(os.environ.get("AUDIOCAPTION_BEAM_GROUP", "2")))
         merge = limit > 1
         if not merge:
             limit = conc
