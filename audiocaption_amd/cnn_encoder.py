@@ -63,21 +63,56 @@ def _conv_wino1d(x, w, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode
     return K.conv3x3_bn_relu_wino1d(x, w, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode, need=need, workspace=ws)
 
 
-def rows_needed(block, conv):
+WINO = ("wino43", "wino1d")   # the Winograd tiers: same layouts, epilogues, ragged-batch and dropout hooks
+W43_MIN_WORKGROUPS = int(os.environ.get("AUDIOCAPTION_W43_MIN_WG", "192"))
+
+
+def wino43_covers(W, cout):
+    """Layers the F(4,3) kernel runs (one 512-register wave per SIMD, csrc/conv3x3_wino43.hip): the full-width forms of
+    conv blocks 2-5.  Block 1 (64 channels) and block 6 (2 mel columns, mean over mel) stay on the F(2,3) kernel."""
+    return W in (32, 16, 8, 4) and cout % 128 == 0
+
+
+def _conv_wino43(x, w, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode=-1, need=None, splitk_buf=None,
+                 dropout=None):
+    """The "wino43" tier's launcher: ``w`` is (F(2,3) pack, F(4,3) pack or None).  F(4,3) when the kernel covers the layer
+    and the launch fills the chip (a workgroup owns a CU: single clips run the K-sliced F(2,3) form instead)."""
+    w23, w43 = w if isinstance(w, tuple) else (w, None)
+    if w43 is not None and mode != 2 and Hp % 4 == 0 and K.wino43_workgroups(B, Hp, W, Cout) >= W43_MIN_WORKGROUPS:
+        return K.conv3x3_bn_relu_wino43(x, w43, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode, need=need,
+                                        dropout=dropout)
+    return _conv_wino1d(x, w23, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode, need=need, splitk_buf=splitk_buf,
+                        dropout=dropout)
+
+
+def rows_needed(block, conv, quads=False):
     """(mul, add): output rows of conv ``conv`` (1 | 2) of conv block ``block`` (1..6) that can reach an output frame below a
     clip's own ``attn_emb_len`` = mul * attn_emb_len + add.  Block 6 is not pooled: its second conv needs exactly the
-    frames, its first one row more; every 3x3 conv upstream adds a row, every pooling doubles (cnn_encoder.py:431-441)."""
+    frames, its first one row more; every 3x3 conv upstream adds a row, every pooling doubles (cnn_encoder.py:431-441).
+    ``quads`` (the "wino43" tier): the F(4,3) kernel forms every output row of a QUAD from all six input rows of the quad
+    (the rows a given output does not depend on cancel in exact arithmetic, not bit for bit), so a conv of blocks 2-5 that
+    needs N rows wants its input valid up to the end of the last quad + 1 <= N + 4 rows instead of N + 1: results below
+    ``attn_emb_len`` then stay bit-identical to the full convolution."""
     if block == 6:
         return (1, 0) if conv == 2 else (1, 1)
-    mul, add = 1 << (6 - block), (1 << (8 - block)) - 4
-    return (mul, add) if conv == 2 else (mul, add + 1)
+    if not quads:
+        mul, add = 1 << (6 - block), (1 << (8 - block)) - 4
+        return (mul, add) if conv == 2 else (mul, add + 1)
+    need = 2 * 2                      # conv2 of block 5 = 2 * (frames + 2): tracked as mul * frames + add
+    mul = 2
+    for b in range(5, block, -1):     # walk up: conv1 of block b (+4), pooled output of block b - 1 (+4), doubled
+        need = 2 * (need + 8)
+        mul *= 2
+    if block == 1:                    # conv2 of block 1 runs the F(2,3) kernel; what it feeds (conv1 of block 2) is F(4,3)
+        return (mul, need) if conv == 2 else (mul, need + 1)
+    return (mul, need) if conv == 2 else (mul, need + 4)
 
 
 def conv_kernel(algo):
     """The launcher of a conv tier (``Cnn14.conv_algo``)."""
     return {"winograd": K.conv3x3_bn_relu_winograd, "direct": K.conv3x3_bn_relu,
             "bf16x3": K.conv3x3_bn_relu_bf16x3_gw, "bf16x3_lds": K.conv3x3_bn_relu_bf16x3,
-            "f16x2": K.conv3x3_bn_relu_f16x2_gw, "wino1d": _conv_wino1d}[algo]
+            "f16x2": K.conv3x3_bn_relu_f16x2_gw, "wino1d": _conv_wino1d, "wino43": _conv_wino43}[algo]
 
 
 class Cnn14Encoder(nn.Module):
@@ -100,14 +135,14 @@ class Cnn14Encoder(nn.Module):
         nn.init.zeros_(self.fc1.bias)
         self.fc_emb_size = 2048
         self.freeze = freeze
-        # Conv tiers.  "wino1d" (default): F(2,3) Winograd along time on split-bf16 operands, f32 activations - f32-grade
-        # parity with the fp32 reference (logits within 1e-4, identical token ids) at two bf16 MFMA products per f32
-        # product.  "bf16x3": the direct form on split-bf16 operands, three products (same accuracy).  "f16x2" (opt-in,
+        # Conv tiers.  "wino43" (default): Winograd along time on split-bf16 operands, f32 activations - f32-grade parity
+        # with the fp32 reference (logits within 1e-4, identical token ids): F(4,3) (1.5 bf16 MFMA products per f32 product)
+        # on conv blocks 2-5 when the launch fills the chip, F(2,3) (two products) elsewhere.  "wino1d": F(2,3) everywhere.  "bf16x3": the direct form on split-bf16 operands, three products (same accuracy).  "f16x2" (opt-in,
         # half-precision gate): fp16 activations (kept as fp16 in HBM), fp16 hi + lo weights, two fp16 MFMA products -
         # identical token ids, logits within 1e-3 (BASELINE.json's half-precision bar), NOT reference precision.
         # "winograd": F(2x2,3x3) on the f32 MFMA, exact f32.  "direct": 9-tap f32 implicit GEMM.  "bf16x3_lds": bf16x3
         # with an LDS weight ring (kept for ablations).  The train-mode forward never uses "f16x2".
-        self.conv_algo = os.environ.get("AUDIOCAPTION_CONV_ALGO", "wino1d")
+        self.conv_algo = os.environ.get("AUDIOCAPTION_CONV_ALGO", "wino43")
         self.f16x2_min_frames = int(os.environ.get("AUDIOCAPTION_F16X2_MIN_FRAMES", "10"))
         # The "f16x2" tier is MIXED: conv_block6 (K = 9216 / 18432, two pixels per frame to average over - half of the
         # tier's logit error by the per-layer breakdown of DESIGN.md section 4) runs on the split-bf16 kernel with f32
@@ -170,10 +205,13 @@ class Cnn14Encoder(nn.Module):
                         wp = K.pack_conv_weight_winograd(w)
                     elif algo == "direct":
                         wp = K.pack_conv_weight(w)
-                    elif algo == "bf16x3" or (algo == "wino1d" and not wino1d_covers(w.shape[0])):
+                    elif algo == "bf16x3" or (algo in WINO and not wino1d_covers(w.shape[0])):
                         wp = K.pack_conv_weight_bf16x3_frag(w)
                     elif algo == "wino1d":
                         wp = K.pack_conv_weight_wino1d_frag(w)
+                    elif algo == "wino43":   # both packs: small launches (single clips) take the K-sliced F(2,3) form
+                        wp = (K.pack_conv_weight_wino1d_frag(w),
+                              K.pack_conv_weight_wino43_frag(w) if wino43_covers(64 >> b, w.shape[0]) else None)
                     elif algo == "bf16x3_lds":
                         wp = K.pack_conv_weight_bf16x3(w)
                     elif algo == "f16x2" and mixed and b == 5:
@@ -269,7 +307,7 @@ class Cnn14Encoder(nn.Module):
         if specaug is not None:
             K.specaug_(x0, specaug, pk["bn0"][1], B, Hp[0], T)
         return self.conv_stack(x0, B, H, Hp, pk, algo, dropout, overflow=overflow,
-                               clip_frames=clip_frames if algo == "wino1d" else None)
+                               clip_frames=clip_frames if algo in WINO else None)
 
     def effective_algo(self, algo=None, train=False, min_frames=None):
         """The conv tier a call runs on: the fp16-activation tier is left for the train-mode forward and for batches
@@ -294,12 +332,13 @@ class Cnn14Encoder(nn.Module):
             import functools
             conv = functools.partial(conv, overflow=overflow)
         fuse1 = algo == "f16x2" and os.environ.get("AUDIOCAPTION_FUSE_BLOCK1", "1") != "0"
-        if algo == "wino1d" and dropout is None and os.environ.get("AUDIOCAPTION_W1_SPLITK", "1") != "0":
+        if algo in WINO and dropout is None and os.environ.get("AUDIOCAPTION_W1_SPLITK", "1") != "0":
             import functools   # single clips: layers of a few workgroups run K-sliced over a shared workspace
             conv = functools.partial(conv, splitk_buf=lambda n: self._buf("w1_splitk", n, dev))
 
         def need(block, j):   # ragged batches: the rows of this layer a clip's own length can bring to an output frame
-            return {"need": (clip_frames,) + rows_needed(block, j)} if clip_frames is not None and algo == "wino1d" else {}
+            return {"need": (clip_frames,) + rows_needed(block, j, quads=algo == "wino43")} \
+                if clip_frames is not None and algo in WINO else {}
 
         mixed = algo == "f16x2" and pk.get("mixed", False)
         for b in range(6):
@@ -319,9 +358,9 @@ class Cnn14Encoder(nn.Module):
             else:
                 conv(pooled, w1, s1, t1, full, B, Hp[b], H[b], W, cin, cout, 0, **need(b + 1, 1))
             if b < 5:
-                fused_drop = dropout is not None and algo == "wino1d" and not (b == 0 and fuse1)
+                fused_drop = dropout is not None and algo in WINO and not (b == 0 and fuse1)
                 if not (b == 0 and fuse1):
-                    kw = need(b + 1, 2) if algo != "wino1d" or wino1d_covers(cout) else {}
+                    kw = need(b + 1, 2) if algo not in WINO or wino1d_covers(cout) else {}
                     if fused_drop:   # the block's F.dropout in the conv kernel's epilogue
                         kw = {"dropout": (dropout[0], dropout[1] + b, dropout[2])}
                     conv(full, w2, s2, t2, pool_out, B, Hp[b], H[b], W, cout, cout, 1, **kw)
@@ -338,7 +377,7 @@ class Cnn14Encoder(nn.Module):
                     conv(full, w2, s2, t2, attn, B, Hp[b], H[b], W, cout, cout, 2, **need(6, 2))
                 else:  # dropout sits between the last block and the mean over mel bins
                     last = self._buf("last", B * Hp[5] * W * cout, dev)
-                    if algo == "wino1d":
+                    if algo in WINO:
                         conv(full, w2, s2, t2, last, B, Hp[b], H[b], W, cout, cout, 0,
                              dropout=(dropout[0], dropout[1] + b, dropout[2]))
                     else:
@@ -362,7 +401,7 @@ class Cnn14Encoder(nn.Module):
         flag = torch.zeros(1, device=wav.device, dtype=torch.int32) if algo == "f16x2" else None
         # inside a composite encoder (skip_fc: CrnnEncoder / Cnn14TransformerEncoder mask by length) the rows a clip's own
         # length cannot bring to an output frame are not convolved; stand-alone, attn_emb is the reference's everywhere
-        ragged = skip_fc and algo == "wino1d" and os.environ.get("AUDIOCAPTION_SKIP_DEAD_ROWS", "1") != "0" \
+        ragged = skip_fc and algo in WINO and os.environ.get("AUDIOCAPTION_SKIP_DEAD_ROWS", "1") != "0" \
             and int(feat_length.min()) < int(feat_length.max())
         frames = K.upload(feat_length, wav.device, torch.int32) if ragged else None
         attn_emb = self.encode(wav, min_frames=min_frames, algo=algo, overflow=flag, clip_frames=frames,

@@ -1,0 +1,582 @@
+// Cnn14 conv stack, f32-grade tier, second generation: 3x3 convolution + eval BatchNorm + ReLU (+ 2x2 average pooling) as a
+// 1-D Winograd F(4,3) along the TIME axis on split-bf16 operands, ONE 512-register wave per SIMD.
+//
+// Same contract, layouts and epilogue modes 0 / 1 as csrc/conv3x3_wino1d.hip (reference ConvBlock.forward,
+// cnn_encoder.py:59-75; pooling glue of Cnn14Encoder.forward, cnn_encoder.py:431-444).  f32 activations [B*Hp][W][C] in and
+// out, Hp % 4 == 0.
+//
+// Arithmetic.  For an output row QUAD (4j .. 4j+3) of one mel column w the six input rows d0..d5 = rows 4j-1 .. 4j+4 give
+//     V0 = 4 d0 - 5 d2 + d4          V1 = (d4 - 4 d2) + (d3 - 4 d1)      V2 = (d4 - 4 d2) - (d3 - 4 d1)
+//     V3 = (d4 - d2) + 2 (d3 - d1)   V4 = (d4 - d2) - 2 (d3 - d1)        V5 = 4 d1 - 5 d3 + d5          (f32)
+//     U_p = sum_ky G[p][ky] g_ky,  G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]]
+//     M_p[quad, w, cout] = sum_kx sum_cin V_p[quad, w + kx - 1, cin] U_p,kx[cout, cin]            (6 positions x 3 mel taps)
+//     y0 = M0+M1+M2+M3+M4   y1 = (M1-M2) + 2 (M3-M4)   y2 = (M1+M2) + 4 (M3+M4)   y3 = (M1-M2) + 8 (M3-M4) + M5
+// i.e. 18 products per (cin, cout) and row quad instead of 36: HALF the multiplications of the direct form (F(2,3): 2/3).
+// Every product runs on split-bf16 operands (x = hi + lo, hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, f32
+// accumulation), so a f32 product costs 3 / 2 = 1.5 bf16 MFMA products.  V is transformed in f32 BEFORE the split and U in
+// f64 before the split, so the larger transform constants of F(4,3) do not amplify the 2^-17 operand error: greedy logits
+// within 3e-5 of the fp32 CPU reference, the same as F(2,3) and the direct split form (tests/wino_split_emulation.py).
+//
+// Work decomposition.  Six accumulator sets per (pixel tile, channel tile) do not fit two waves per SIMD, so a workgroup is
+// FOUR waves, one per SIMD, each with up to 512 registers: a wave owns 32 output channels x MW = 3 (2) MFMA tiles of 32
+// (quad, column) pixels x 6 positions = 288 (192) accumulator registers, and every weight fragment pair it fetches from L2
+// feeds 9 (6) MFMAs (the F(2,3) kernel: 6) - per output a third of the weight bytes through the L1.  A workgroup covers
+// the FULL image width (W = 32, 16, 8, 4 = blocks 2 .. 5) x PQ = MW * 32 / W quads x 128 channels; the two halo columns
+// beside the image are LDS columns that stay zero.  The K loop runs in 16-channel steps over double-buffered V planes in
+// LDS ([position][hi | lo][k-half][column][quad] items of 8 channels = 16 bytes, column pitch chosen so that the 16 lanes
+// of every ds_read_b128 group land in 16 different bank slots).  One wave per SIMD means nothing hides a stall but the
+// wave's own instruction stream, so the step is one straight-line block: the raw rows of step s + 2 are requested in the
+// middle of step s (a whole step of latency, the registers are free by then), the rows of step s + 1 are transformed,
+// split and stored a piece per MFMA group (waves 0-1 / 2-3 share the 128 odd items position-wise so that every lane has
+// work in every piece), the A fragments of a group are read one group ahead, the weight fragments two groups ahead, and
+// the single barrier of a step sits one group before its end so that the first fragments of the next step are read
+// under the last group's MFMAs.
+#include <stdlib.h>
+#include <string.h>
+#include <type_traits>
+
+#include "ac_common.h"
+#include "ac_drop.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+#ifndef W4_KO   // development (tools/conv_bench.py): 1 no weight loads, 2 no A reads, 4 no plane stores, 8 no row loads, 32 no MFMAs
+#define W4_KO 0
+#endif
+
+#ifndef W4_RING     // weight fragment ring: a group's pair is requested W4_RING - 1 groups ahead (18 % W4_RING == 0)
+#define W4_RING 9
+#endif
+#ifndef W4_ADEPTH   // A fragments are read this many groups ahead (1 or 2)
+#define W4_ADEPTH 2
+#endif
+
+#ifdef W4_CLK   // development: shader-clock cycles of the prologue / K loop / epilogue, 100 MHz ticks of the whole block, count
+__device__ unsigned long long w4_clk[8];
+#define W4_STAMP(var) const unsigned long long var = __builtin_readcyclecounter()
+#else
+#define W4_STAMP(var)
+#endif
+
+constexpr int KS = 16;   // input channels per K step = one MFMA k-step
+
+struct W4Params {
+  const float* in;
+  const void* wpk;    // [Cin/16][18 = 3 kx x 6 p][Cout/32][2 (hi, lo)][64 lanes][8] bf16
+  const float* scale;
+  const float* shift;
+  float* out;
+  int rows_total, Hp, H, W, Cin, Cout;
+  int MT, NT;
+  int Hp_out, H_out, W_out;
+  int map_mode;
+  const int* clip_frames;   // ragged batches: see csrc/conv3x3_wino1d.hip
+  int need_mul, need_add;
+  Drop drop;
+};
+
+enum { MODE_FULL = 0, MODE_POOL = 1 };
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+// x (4 floats) -> packed hi (2 dwords) and lo (2 dwords) bf16 quadruples: hi = RNE(x), lo = RNE(x - hi)
+__device__ __forceinline__ void split_bf16x4(const f32x4 x, u32x2& hi, u32x2& lo) {
+  hi.x = cvt_pk_bf16(x[0], x[1]);
+  hi.y = cvt_pk_bf16(x[2], x[3]);
+  const float h0 = __builtin_bit_cast(float, hi.x << 16), h1 = __builtin_bit_cast(float, hi.x & 0xffff0000u);
+  const float h2 = __builtin_bit_cast(float, hi.y << 16), h3 = __builtin_bit_cast(float, hi.y & 0xffff0000u);
+  lo.x = cvt_pk_bf16(x[0] - h0, x[1] - h1);
+  lo.y = cvt_pk_bf16(x[2] - h2, x[3] - h3);
+}
+
+__device__ __forceinline__ f32x4 vfma(float a, const f32x4 x, const f32x4 y) {   // a * x + y, one rounding per element
+  f32x4 r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) r[j] = __builtin_fmaf(a, x[j], y[j]);
+  return r;
+}
+
+struct FastDiv4 {   // x mod d / x div d for 0 <= x < 2^23 with one reciprocal
+  int d;
+  float inv;
+  __device__ __forceinline__ explicit FastDiv4(int d_) : d(d_), inv(1.0f / (float)d_) {}
+  __device__ __forceinline__ int mod(int x) const {
+    int q = (int)((float)x * inv);
+    int r = x - q * d;
+    if (r < 0) r += d;
+    if (r >= d) r -= d;
+    return r;
+  }
+};
+
+// block -> (row block, channel tile); block b runs on XCD b % 8 (speed only).  1: an XCD streams one weight column slab
+// (NT % 8 == 0); 3: NT in {1, 2, 4, 8}: the channel tiles of a row block sit on 8 / NT ... XCDs each owning one slab;
+// 2: the channel tiles of a row block back to back on one XCD
+__device__ __forceinline__ bool w4_block_map(const W4Params& p, int& m_tile, int& n_tile) {
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, seq = bid >> 3;
+  if (p.map_mode == 1) {
+    n_tile = xcd + 8 * (seq / p.MT);
+    m_tile = seq % p.MT;
+  } else if (p.map_mode == 2) {
+    n_tile = seq % p.NT;
+    m_tile = (seq / p.NT) * 8 + xcd;
+    if (m_tile >= p.MT) return false;
+  } else if (p.map_mode == 3) {
+    const int per = 8 / p.NT;
+    n_tile = xcd % p.NT;
+    m_tile = seq * per + xcd / p.NT;
+    if (m_tile >= p.MT) return false;
+  } else {
+    n_tile = bid % p.NT;
+    m_tile = bid / p.NT;
+  }
+  return true;
+}
+
+// Dead block (as in csrc/conv3x3_wino1d.hip): every row lies in the padding of its clip(s), or beyond what the clip's own
+// length can bring to an output frame
+__device__ __forceinline__ bool w4_block_live(const W4Params& p, int row0, int nrows) {
+  bool live = false;
+  if (row0 < p.rows_total) {
+    const int r_end = row0 + nrows < p.rows_total ? row0 + nrows : p.rows_total;
+    int b = row0 / p.Hp;
+    for (int base = b * p.Hp; base < r_end; base += p.Hp, ++b) {
+      const int lo = (row0 > base ? row0 : base) - base;
+      int lim = p.H;
+      if (p.clip_frames) {
+        const int need = p.need_mul * p.clip_frames[b] + p.need_add;
+        lim = need < lim ? need : lim;
+      }
+      live = live || lo < lim;
+    }
+  }
+  return live;
+}
+
+template <int TC, int MW>
+struct W4Geom {
+  static_assert(TC == 32 || TC == 16 || TC == 8 || TC == 4, "full-width blocks of 32, 16, 8 or 4 mel columns");
+  static_assert(MW == 2 || MW == 3, "two or three MFMA tiles per wave");
+  static constexpr int QT = 32 / TC;          // quads of an MFMA tile: row i = (quad i / TC, column i % TC)
+  static constexpr int PQ = MW * QT;          // quads of a block
+  // column pitch in 16-byte slots: the 16 lanes of a ds_read_b128 group ({0-3, 12-15, 20-27} ...) read column i % TC,
+  // quad i / TC: TC = 32 any odd pitch, 16: pitch % 4 == 2, 8 and 4: pitch % 8 == 4 put them in 16 different slots
+  static constexpr int COLP = TC == 32 ? (PQ | 1) : TC == 16 ? (PQ % 4 == 2 ? PQ : PQ + 2) : (PQ % 8 == 4 ? PQ : PQ + 4);
+  static constexpr int HALF = (((TC + 2) * COLP * 16 + 127) / 128) * 128 + 64;   // bytes of one k-half of a plane (= 64 mod 128:
+  static constexpr int PLANE = 2 * HALF;      //   the 8-byte stores of channels 0-7 / 8-15 of four items hit different banks)
+  static constexpr int VBUF = 12 * PLANE;     // 6 positions x (hi, lo)
+  static constexpr int NITEM = PQ * TC * 4;   // staging items (quad, column, channel quad) of a step: 384 (MW 3) or 256
+  static_assert(NITEM == 256 || NITEM == 384, "one item per thread, plus half of a shared one for MW = 3");
+  static constexpr int NPIECE = MW == 3 ? 9 : 6;
+};
+
+template <int MODE, int TC, int MW>
+__global__ __launch_bounds__(256, 1) void conv3x3_w4_kernel(W4Params p) {
+  using G = W4Geom<TC, MW>;
+  constexpr int QT = G::QT, PQ = G::PQ, COLP = G::COLP, HALF = G::HALF, PLANE = G::PLANE, VBUF = G::VBUF;
+  constexpr int NPIECE = G::NPIECE;
+  extern __shared__ __attribute__((aligned(128))) unsigned char dsm_raw[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+
+  int m_tile, n_tile;
+  if (!w4_block_map(p, m_tile, n_tile)) return;
+  W4_STAMP(clk_t0);
+#ifdef W4_CLK
+  const unsigned long long clk_rt0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long clk_t1 = clk_t0;
+#endif
+  const int quad0 = m_tile * PQ;
+  unsigned char* sV = dsm_raw;   // two buffers of VBUF bytes
+
+  // A fragment of tile m, tap kx, plane (p, hl): lane (i, half) reads item (column i % TC + kx, quad m QT + i / TC), k-half
+  // `half`
+  unsigned pb[MW];
+  {
+    const int i = lane & 31;
+#pragma unroll
+    for (int m = 0; m < MW; ++m) pb[m] = (unsigned)(half * HALF + ((i % TC) * COLP + m * QT + i / TC) * 16);
+  }
+
+  f32x16 acc[6][MW];
+#pragma unroll
+  for (int q = 0; q < 6; ++q)
+#pragma unroll
+    for (int m = 0; m < MW; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q][m][r] = 0.f;
+
+  const int row0 = 4 * quad0;
+  const bool live = w4_block_live(p, row0, 4 * PQ);
+  const bool all_pad = !live;
+  const int nstep = p.Cin / KS;
+  if (!all_pad) {
+    // Input window of this block: rows 4 quad0 - 1 .. 4 (quad0 + PQ), through a buffer descriptor REBASED to the block's
+    // first row (offsets stay small whatever the batch; bytes beyond the tensor, the row above the batch and lanes
+    // parked on 0x80000000 read as zero)
+    const int R0 = row0 > 0 ? row0 - 1 : 0;
+    const int first = row0 > 0 ? 0 : 1;   // rows to subtract: relative row of (quad, r) = 4 quad + r - first
+    const size_t row_elems = (size_t)p.W * p.Cin;
+    const size_t left = ((size_t)p.rows_total - R0) * row_elems * 4;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.in + (size_t)R0 * row_elems), 0, (int)(left < 0x7fffffffull ? left : 0x7fffffffull), 0x00020000);
+    const int NT32 = p.Cout >> 5;
+    const unsigned g_bytes = (unsigned)NT32 * 2048u;   // one (step, kx, p) group: NT32 x (hi, lo) x 1 KiB
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.wpk, 0, (int)((unsigned)nstep * 18u * g_bytes), 0x00020000);
+    const unsigned wvoff = (unsigned)((n_tile * 4 + wave) * 2048 + lane * 16);
+    auto w_load = [&](int s, int gi, bf16x8 (&w)[2]) {
+      if (W4_KO & 1) { if (s | gi) return; }
+      const unsigned soff = (unsigned)(s * 18 + gi) * g_bytes;
+      w[0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff, soff, 0));
+      w[1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff + 1024u, soff, 0));
+    };
+
+    // Staging items.  Item it = (channel quad it & 3, quad (it >> 2) % PQ, column (it >> 2) / PQ).  Thread t owns item t
+    // whole; MW = 3: items 256 + (t & 127) are shared by threads t and t + 128 position-wise (waves 0-1: V0..V2 from rows
+    // d0..d4, waves 2-3: V3..V5 from rows d1..d5).
+    const unsigned row_bytes = (unsigned)row_elems * 4u;
+    unsigned vbA, lofsA, vbB = 0, lofsB = 0;
+    {
+      auto item = [&](int it, unsigned& vb, unsigned& lofs) {
+        const int cq = it & 3, rest = it >> 2, quad = rest % PQ, c = rest / PQ;
+        vb = (unsigned)(((4 * quad - first) * p.W + c) * p.Cin * 4 + cq * 16);
+        lofs = (unsigned)((cq >> 1) * HALF + ((c + 1) * COLP + quad) * 16 + (cq & 1) * 8);
+      };
+      item(tid, vbA, lofsA);
+      if (MW == 3) item(256 + (tid & 127), vbB, lofsB);
+    }
+
+    // HPB (MW = 3): first position of this wave's share of the shared item, 0 or 3
+    auto run = [&](auto HPB_) {
+      constexpr int HPB = decltype(HPB_)::value;
+      constexpr int RB = HPB ? 1 : 0;      // first row of the shared item this wave needs
+      f32x4 preA[6], preB[5];
+      auto rows_request = [&](int s) {
+        if (W4_KO & 8) { if (s) return; }
+        const unsigned cs = (unsigned)(s * KS * 4);
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+          preA[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, vbA + cs + (unsigned)r * row_bytes, 0, 0));
+        if (MW == 3) {
+#pragma unroll
+          for (int r = 0; r < 5; ++r)
+            preB[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, vbB + cs + (unsigned)(r + RB) * row_bytes, 0, 0));
+        }
+      };
+      // position pos of the rows d0..d5 (d[r] only touched where pos needs it)
+      auto transform = [&](int pos, const f32x4& d0, const f32x4& d1, const f32x4& d2, const f32x4& d3, const f32x4& d4,
+                           const f32x4& d5) -> f32x4 {
+        if (pos == 0) return vfma(4.f, d0, vfma(-5.f, d2, d4));
+        if (pos == 5) return vfma(4.f, d1, vfma(-5.f, d3, d5));
+        if (pos == 1 || pos == 2) {
+          const f32x4 t1 = vfma(-4.f, d2, d4), t2 = vfma(-4.f, d1, d3);
+          return pos == 1 ? t1 + t2 : t1 - t2;
+        }
+        const f32x4 t3 = d4 - d2, u = d3 - d1;
+        return pos == 3 ? vfma(2.f, u, t3) : vfma(-2.f, u, t3);
+      };
+      auto store_piece = [&](unsigned char* buf, unsigned lofs, int pos, const f32x4 v) {
+        u32x2 hi, lo;
+        split_bf16x4(v, hi, lo);
+        unsigned char* dst = buf + lofs + (2 * pos) * PLANE;
+        *(u32x2*)dst = hi;
+        *(u32x2*)(dst + PLANE) = lo;
+      };
+      // piece k of a step: 0..5 = positions of the own item, 6..8 = this wave's positions of the shared item
+      auto commit_piece = [&](unsigned char* buf, int k) {
+        if (W4_KO & 4) return;
+        if (k < 6) {
+          store_piece(buf, lofsA, k, transform(k, preA[0], preA[1], preA[2], preA[3], preA[4], preA[5]));
+        } else {
+          const int pos = HPB + (k - 6);
+          const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          if (HPB == 0) store_piece(buf, lofsB, pos, transform(pos, preB[0], preB[1], preB[2], preB[3], preB[4], z));
+          else store_piece(buf, lofsB, pos, transform(pos, z, preB[0], preB[1], preB[2], preB[3], preB[4]));
+        }
+      };
+      auto a_load = [&](const unsigned char* buf, int gi, bf16x8 (&a)[MW][2]) {
+        if (W4_KO & 2) { if (gi) return; }
+        const int kx = gi / 6, q = gi % 6;
+        const unsigned char* vh = buf + (2 * q) * PLANE + kx * COLP * 16;
+#pragma unroll
+        for (int m = 0; m < MW; ++m) {
+          a[m][0] = *(const bf16x8*)(vh + pb[m]);
+          a[m][1] = *(const bf16x8*)(vh + PLANE + pb[m]);
+        }
+      };
+
+      // ---- prologue: zero halo columns of both buffers, step 0 into buffer 0, rows of step 1 requested ----
+      {
+        constexpr int NZ = 2 * 12 * 2 * 2 * COLP;   // 16-byte slots: buffers x planes x k-halves x 2 columns x COLP
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        for (int i = tid; i < NZ; i += 256) {
+          const int slot = i % COLP, col = (i / COLP) & 1, hh = (i / (2 * COLP)) % 24, b = i / (48 * COLP);
+          *(f32x4*)(sV + b * VBUF + hh * HALF + ((col ? TC + 1 : 0) * COLP + slot) * 16) = z;
+        }
+      }
+      constexpr int RING = W4_RING, AH = RING - 1, NA = W4_ADEPTH + 1, LASTG = 17 - W4_ADEPTH;
+      static_assert(18 % RING == 0 && 18 % NA == 0 && NPIECE <= LASTG, "ring positions are static; staging ends before the barrier");
+      bf16x8 wr[RING][2];   // ring of weight fragments: group gi lives in wr[gi % RING], requested RING - 1 groups ahead
+#pragma unroll
+      for (int g0 = 0; g0 < AH; ++g0) w_load(0, g0, wr[g0]);
+      rows_request(0);
+#pragma unroll
+      for (int k = 0; k < NPIECE; ++k) commit_piece(sV, k);
+      rows_request(1);   // nstep >= 2
+      lds_barrier();     // LDS only: the rows just requested stay in flight
+      bf16x8 af[NA][MW][2];   // A fragments (tile, hi | lo) of the current group and the next W4_ADEPTH ones
+#pragma unroll
+      for (int g0 = 0; g0 < W4_ADEPTH; ++g0) a_load(sV, g0, af[g0]);
+
+      // ---- one K step.  MORE: a step follows (its planes are staged here; the one after it is requested) ----
+      auto step = [&](int s, auto MORE_) {
+        constexpr bool MORE = decltype(MORE_)::value;
+        const unsigned char* cur = sV + (s & 1) * VBUF;
+        unsigned char* nxt = sV + ((s + 1) & 1) * VBUF;
+#pragma unroll
+        for (int gi = 0; gi < 18; ++gi) {
+          const int q = gi % 6;
+          if (gi + W4_ADEPTH < 18) a_load(cur, gi + W4_ADEPTH, af[(gi + W4_ADEPTH) % NA]);
+          else if (MORE) a_load(nxt, gi + W4_ADEPTH - 18, af[(gi + W4_ADEPTH) % NA]);   // behind the barrier of group LASTG
+          if (gi + AH < 18) w_load(s, gi + AH, wr[(gi + AH) % RING]);
+          else if (MORE) w_load(s + 1, gi + AH - 18, wr[(gi + AH) % RING]);
+          if (!(W4_KO & 32)) {
+            // operand order (weights, pixels): D rows = channels, columns = pixels, so that a lane ends up with four
+            // CONSECUTIVE channels of one pixel per register quad (16-byte stores in the epilogue)
+#pragma unroll
+            for (int m = 0; m < MW; ++m)
+              acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[gi % RING][0], af[gi % NA][m][1], acc[q][m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MW; ++m)
+              acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[gi % RING][1], af[gi % NA][m][0], acc[q][m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MW; ++m)
+              acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[gi % RING][0], af[gi % NA][m][0], acc[q][m], 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int m = 0; m < MW; ++m)
+              asm volatile("" :: "v"(af[gi % NA][m][0]), "v"(af[gi % NA][m][1]), "v"(wr[gi % RING][0]), "v"(wr[gi % RING][1]));
+          }
+          if (MORE) {
+            if (gi < NPIECE) commit_piece(nxt, gi);
+            if (gi == NPIECE) rows_request(s + 2);   // past the last step: lands in registers nobody reads
+          }
+          if (gi == LASTG && !(W4_KO & 16)) lds_barrier();   // step s + 1 is complete in `nxt`; the fragments of the groups left are in registers
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+#ifdef W4_CLK
+      clk_t1 = __builtin_readcyclecounter();
+#endif
+#pragma unroll 1
+      for (int s = 0; s + 1 < nstep; ++s) step(s, std::true_type{});
+      step(nstep - 1, std::false_type{});
+    };
+    if (MW == 3 && wave >= 2) run(std::integral_constant<int, 3>{});
+    else run(std::integral_constant<int, 0>{});
+  }
+
+  W4_STAMP(clk_t2);
+  // ---- epilogue: output transform, BN, ReLU, pooling, zero rows.  Lane l owns PIXEL l % 32 of each tile (column i % TC,
+  // quad i / TC) and, in register quad g, the four consecutive channels 8 g + 4 (l / 32) .. + 3 of the wave's 32: one
+  // 16-byte store per (tile, g, row).  The two columns of a pooling window sit in lanes l, l ^ 1. ----
+  const int chw = n_tile * 128 + wave * 32 + 4 * half;
+  const FastDiv4 by_hp(p.Hp), by_hp_out(MODE == MODE_POOL ? p.Hp_out : 1);
+  const int pi = lane & 31, col = pi % TC;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 sc4[4], sh4[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    sc4[g] = all_pad ? zero4 : *(const f32x4*)(p.scale + chw + 8 * g);   // dead blocks store zeros
+    sh4[g] = all_pad ? zero4 : *(const f32x4*)(p.shift + chw + 8 * g);
+  }
+#pragma unroll
+  for (int m = 0; m < MW; ++m) {
+    const int qg = quad0 + m * QT + pi / TC;
+    const int gr = 4 * qg;
+    const bool inside = gr < p.rows_total;
+    f32x4 y[4][4];   // y[g][j][e]: channel quad g, output row j, channel chw + 8 g + e
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        const float m0 = acc[0][m][r], m1 = acc[1][m][r], m2 = acc[2][m][r], m3 = acc[3][m][r], m4 = acc[4][m][r],
+                    m5 = acc[5][m][r];
+        const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+        const float sc = sc4[g][e], sh = sh4[g][e];
+        y[g][0][e] = fmaxf(fmaf((m0 + s12) + s34, sc, sh), 0.f);
+        y[g][1][e] = fmaxf(fmaf(__builtin_fmaf(2.f, d34, d12), sc, sh), 0.f);
+        y[g][2][e] = fmaxf(fmaf(__builtin_fmaf(4.f, s34, s12), sc, sh), 0.f);
+        y[g][3][e] = fmaxf(fmaf(__builtin_fmaf(8.f, d34, d12) + m5, sc, sh), 0.f);
+      }
+    if (MODE == MODE_FULL) {
+      const int h = by_hp.mod(gr);   // Hp % 4 == 0: the four rows of a quad belong to one clip
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {   // the four stores that complete a pixel's 128-byte line of this wave back to back
+          const size_t oi = ((size_t)(gr + j) * p.W + col) * p.Cout + chw + 8 * g;
+          f32x4 v = h + j < p.H ? y[g][j] : zero4;
+          if (p.drop.thresh != 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= p.drop.mask(oi + e);
+          }
+          if (inside && !(W4_KO & 64)) *(f32x4*)(p.out + oi) = v;
+        }
+    } else {   // a row quad is two pooled rows: the even lane of a column pair stores the first, the odd lane the second
+      const int pr = 2 * qg + (col & 1);
+      const bool valid = by_hp_out.mod(2 * qg) + (col & 1) < p.H_out;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 t0 = y[g][0] + y[g][1], t1 = y[g][2] + y[g][3];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a = t0[e] + dpp_mov<DPP_QUAD_XOR1>(t0[e]), b = t1[e] + dpp_mov<DPP_QUAD_XOR1>(t1[e]);
+          o[e] = 0.25f * ((col & 1) ? b : a);
+        }
+        const size_t oi = ((size_t)pr * p.W_out + (col >> 1)) * p.Cout + chw + 8 * g;
+        if (!valid) o = zero4;
+        if (p.drop.thresh != 0) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] *= p.drop.mask(oi + e);
+        }
+        if (inside && !(W4_KO & 64)) *(f32x4*)(p.out + oi) = o;
+      }
+    }
+  }
+#ifdef W4_CLK
+  __builtin_amdgcn_s_waitcnt(0);
+  if (tid == 0) {
+    const unsigned long long t3 = __builtin_readcyclecounter();
+    atomicAdd(&w4_clk[0], clk_t1 - clk_t0);
+    atomicAdd(&w4_clk[1], clk_t2 - clk_t1);
+    atomicAdd(&w4_clk[2], t3 - clk_t2);
+    atomicAdd(&w4_clk[3], __builtin_amdgcn_s_memrealtime() - clk_rt0);
+    atomicAdd(&w4_clk[4], 1ull);
+  }
+#endif
+}
+
+template <int MODE, int TC, int MW>
+int launch_w4(W4Params p, hipStream_t s) {
+  using G = W4Geom<TC, MW>;
+  const int quads = p.rows_total / 4;
+  p.MT = (quads + G::PQ - 1) / G::PQ;
+  unsigned grid;
+  if (p.map_mode == 2) grid = (unsigned)(((p.MT + 7) / 8) * 8 * p.NT);
+  else if (p.map_mode == 3) grid = (unsigned)(((p.MT + 8 / p.NT - 1) / (8 / p.NT)) * 8);
+  else grid = (unsigned)(p.MT * p.NT);
+  constexpr size_t lds = (size_t)2 * G::VBUF;
+  static_assert(lds <= 160 * 1024, "V planes exceed the LDS");
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)conv3x3_w4_kernel<MODE, TC, MW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      return AC_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3x3_w4_kernel<MODE, TC, MW>), dim3(grid), dim3(256), lds, s, p);
+  return ac_check_launch();
+}
+
+#ifndef W4_MW3   // development: the three-tile form (288 accumulators exceed the 256 AGPRs: hipcc shuffles them through VGPRs)
+#define W4_MW3 0
+#endif
+template <int MODE, int TC>
+int launch_w4_mw(const W4Params& p, int mw, hipStream_t s) {
+#if W4_MW3
+  if (mw == 3) return launch_w4<MODE, TC, 3>(p, s);
+#endif
+  return launch_w4<MODE, TC, 2>(p, s);
+}
+
+}  // namespace
+
+// workgroups of a launch with MW tiles per wave
+static long w4_grid(int rows_total, int W, int Cout, int mw) {
+  const int pq = mw * (32 / W);
+  return (long)((rows_total / 4 + pq - 1) / pq) * (Cout / 128);
+}
+
+static int w4_dispatch(const float* in, const void* wfrag, const float* scale, const float* shift, float* out, int B, int Hp,
+                       int H, int W, int Cin, int Cout, int mode, int map_mode, int mw, const int* clip_frames, int need_mul,
+                       int need_add, void* stream, Drop drop) {
+  if (!in || !wfrag || !scale || !shift || !out) return AC_ERR_ARG;
+  if (B <= 0 || Hp <= H || (Hp & 3) || !(W == 32 || W == 16 || W == 8 || W == 4) || Cin % 16 || Cin < 32 || Cout % 128)
+    return AC_ERR_ARG;
+  if (mode != MODE_FULL && mode != MODE_POOL) return AC_ERR_ARG;
+  if ((unsigned long long)B * Hp >= (1ull << 29)) return AC_ERR_ARG;          // row indices are ints (x 4 in the epilogue)
+  if ((unsigned long long)(Cin / 16) * 18 * (Cout / 32) * 2048 >= (1ull << 31)) return AC_ERR_ARG;   // packed weights: one descriptor
+  W4Params p;
+  p.in = in; p.wpk = wfrag; p.scale = scale; p.shift = shift; p.out = out;
+  p.rows_total = B * Hp; p.Hp = Hp; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+  p.MT = 0;
+  p.NT = Cout / 128;
+  p.Hp_out = Hp / 2; p.H_out = H / 2; p.W_out = W / 2;
+  if (map_mode < 0) map_mode = (p.NT % 8 == 0) ? 1 : ((p.NT == 1 || p.NT == 2 || p.NT == 4) ? 3 : 2);
+  if (map_mode == 1 && p.NT % 8 != 0) return AC_ERR_ARG;
+  if (map_mode == 3 && !(p.NT == 1 || p.NT == 2 || p.NT == 4 || p.NT == 8)) return AC_ERR_ARG;
+  if (map_mode > 3) return AC_ERR_ARG;
+  p.map_mode = map_mode;
+  p.clip_frames = clip_frames; p.need_mul = need_mul; p.need_add = need_add;
+  p.drop = drop;
+  if (mw != 2 && mw != 3) {
+    // three tiles per wave (9 MFMAs per weight fragment pair) unless two leave fewer idle CUs in the last round of workgroups
+    auto waste = [&](int m) {
+      const long g = w4_grid(p.rows_total, W, Cout, m);
+      const long rounds = (g + 255) / 256;
+      return (double)(rounds * 256 - g) / (double)(rounds * 256);
+    };
+    mw = (waste(3) > waste(2) + 0.12) ? 2 : 3;
+  }
+  hipStream_t s = (hipStream_t)stream;
+#define W4_CASE(TCV)                                                                     \
+  if (W == TCV) return mode == MODE_FULL ? launch_w4_mw<MODE_FULL, TCV>(p, mw, s) : launch_w4_mw<MODE_POOL, TCV>(p, mw, s);
+  W4_CASE(32) W4_CASE(16) W4_CASE(8) W4_CASE(4)
+#undef W4_CASE
+  return AC_ERR_ARG;
+}
+
+#ifdef W4_CLK
+extern "C" int ac_w4_clk_read(unsigned long long* out5, int reset) {
+  if (hipMemcpyFromSymbol(out5, HIP_SYMBOL(w4_clk), 40) != hipSuccess) return -2;
+  if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(w4_clk), z, 64) != hipSuccess) return -2; }
+  return 0;
+}
+#endif
+
+// C ABI: see include/audiocaption_hip.h
+extern "C" int ac_conv3x3_bn_relu_wino43(const float* in, const void* wfrag, const float* scale, const float* shift,
+                                         float* out, int B, int Hp, int H, int W, int Cin, int Cout, int mode,
+                                         int map_mode, int tiles_per_wave, const int* clip_frames, int need_mul,
+                                         int need_add, void* stream) {
+  return w4_dispatch(in, wfrag, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode, tiles_per_wave, clip_frames,
+                     need_mul, need_add, stream, make_drop(0.f, 0, nullptr));
+}
+
+extern "C" int ac_conv3x3_bn_relu_wino43_drop(const float* in, const void* wfrag, const float* scale, const float* shift,
+                                              float* out, int B, int Hp, int H, int W, int Cin, int Cout, int mode,
+                                              int map_mode, float drop_p, unsigned long long drop_seed,
+                                              const unsigned long long* seed_dev, void* stream) {
+  if (!(drop_p >= 0.f) || drop_p >= 1.f) return AC_ERR_ARG;
+  return w4_dispatch(in, wfrag, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode, 0, nullptr, 0, 0, stream,
+                     make_drop(drop_p, drop_seed, seed_dev));
+}
+
+extern "C" long ac_conv3x3_wino43_workgroups(int B, int Hp, int W, int Cout) {
+  if (B <= 0 || Hp <= 0 || (Hp & 3) || !(W == 32 || W == 16 || W == 8 || W == 4) || Cout % 128) return 0;
+  return w4_grid(B * Hp, W, Cout, 2);
+}

@@ -189,6 +189,37 @@ def conv3x3_bn_relu_wino1d(x, wfrag, scale, shift, out, B, Hp, H, W, Cin, Cout, 
     return out
 
 
+def wino43_workgroups(B, Hp, W, Cout):
+    """Workgroups of ``conv3x3_bn_relu_wino43`` on this geometry (0: the F(4,3) kernel does not cover it)."""
+    return int(_lib.load().ac_conv3x3_wino43_workgroups(B, Hp, W, Cout))
+
+
+def conv3x3_bn_relu_wino43(x, wfrag, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode=-1, need=None, dropout=None,
+                           tiles_per_wave=0):
+    """F(4,3) Winograd along time on split-bf16 operands, one wave per SIMD (csrc/conv3x3_wino43.hip); ``wfrag`` from
+    ``pack_conv_weight_wino43_frag``.  Covers W in (32, 16, 8, 4), Cout % 128 == 0, Hp % 4 == 0, modes 0 / 1; ``need`` and
+    ``dropout`` as for ``conv3x3_bn_relu_wino1d``."""
+    lib = _lib.load()
+    hook = CONV_LAUNCH_HOOK
+    if hook is not None:
+        info = {"B": B, "H": H, "Hp": Hp, "W": W, "Cin": Cin, "Cout": Cout, "mode": mode, "algo": "wino43"}
+        hook("pre", info)
+    cf, mul, add = need if need is not None else (None, 0, 0)
+    if dropout is not None:
+        if cf is not None:
+            raise ValueError("conv3x3_bn_relu_wino43: dropout and dead-row skipping are not combined")
+        check(lib.ac_conv3x3_bn_relu_wino43_drop(ptr(x), ptr(wfrag), ptr(scale), ptr(shift), ptr(out), B, Hp, H, W, Cin, Cout,
+                                                 mode, map_mode, float(dropout[0]), int(dropout[1]), dropout[2], stream()),
+              "ac_conv3x3_bn_relu_wino43_drop")
+    else:
+        check(lib.ac_conv3x3_bn_relu_wino43(ptr(x), ptr(wfrag), ptr(scale), ptr(shift), ptr(out), B, Hp, H, W, Cin, Cout,
+                                            mode, map_mode, int(tiles_per_wave), ptr(cf), int(mul), int(add), stream()),
+              "ac_conv3x3_bn_relu_wino43")
+    if hook is not None:
+        hook("post", info)
+    return out
+
+
 def conv3x3_bn_relu_f16x2_gw(x, wfrag, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode=-1, overflow=None):
     """``out``: fp16 for modes 0 / 1 (an f32 ``out`` with mode 1 selects the f32 pooled output that feeds a split-bf16
     block), f32 for mode 2.  ``overflow``: a uint32 / int32 device word OR-ed with 1 when a value stored as fp16
@@ -262,6 +293,26 @@ def pack_conv_weight_wino1d_frag(w):
         return t.permute(0, 4, 1, 5, 2, 6, 3).reshape(cin // 32, 12, 2, cout // 32, 64, 8)
 
     return torch.stack([lay(hi), lay(lo)], dim=4).contiguous()
+
+
+def pack_conv_weight_wino43_frag(w):
+    """OIHW f32 -> U = G g (F(4,3) filter transform over the time taps ky, evaluated in float64), split into bf16
+    hi + lo, in MFMA fragment order [Cin/16][18 = 3 kx x 6 positions][Cout/32][2 (hi, lo)][64 lanes][8]: lane
+    (cout % 32) + 32 * ((cin % 16) // 8), element cin % 8 (csrc/conv3x3_wino43.hip).  Elementwise torch ops only."""
+    cout, cin = w.shape[0], w.shape[1]
+    g = w.double()                                                   # (o, c, ky, kx)
+    G = ((1 / 4, 0, 0), (-1 / 6, -1 / 6, -1 / 6), (-1 / 6, 1 / 6, -1 / 6), (1 / 24, 1 / 12, 1 / 6), (1 / 24, -1 / 12, 1 / 6),
+         (0, 0, 1))
+    u = torch.stack([G[p][0] * g[:, :, 0] + G[p][1] * g[:, :, 1] + G[p][2] * g[:, :, 2] for p in range(6)], dim=3)   # (o, c, kx, p)
+    u = u.reshape(cout, cin, 18)                                     # tap = kx * 6 + position
+    hi = u.to(torch.bfloat16)
+    lo = (u - hi.double()).to(torch.bfloat16)
+
+    def lay(t):
+        t = t.permute(1, 2, 0).reshape(cin // 16, 2, 8, 18, cout // 32, 32)     # (step, k-half, j, tap, channel tile, n)
+        return t.permute(0, 3, 4, 1, 5, 2).reshape(cin // 16, 18, cout // 32, 64, 8)
+
+    return torch.stack([lay(hi), lay(lo)], dim=3).contiguous()
 
 
 def pack_conv_weight_winograd(w):

@@ -109,6 +109,27 @@ int ac_conv3x3_bn_relu_wino1d_splitk(const float* in, const void* wfrag, const f
                                      int map_mode, const int* clip_frames, int need_mul, int need_add,
                                      float* workspace, long workspace_floats, void* stream);
 
+/* Second generation of the f32-grade tier: the same layer as a 1-D Winograd F(4,3) along time (row QUADS: 6 transformed
+ * positions per 4 output rows, 18 instead of 36 products per (cin, cout)) on split-bf16 operands - 1.5 bf16 MFMA products
+ * per f32 product (F(2,3): 2) - with ONE 512-register wave per SIMD (csrc/conv3x3_wino43.hip).  Same layouts, epilogue
+ * modes 0 / 1 and ragged-batch arguments as ac_conv3x3_bn_relu_wino1d; replaces the same reference code: ConvBlock.forward,
+ * cnn_encoder.py:59-75 (+ the pooling of Cnn14Encoder.forward, :431-441).  Covers the full-width layers W = 32, 16, 8, 4
+ * (conv blocks 2-5) with Cout % 128 == 0, Cin % 16 == 0, Cin >= 32, Hp % 4 == 0; wfrag
+ * [Cin/16][3 kx x 6 positions][Cout/32][hi, lo][64 lanes][8] bf16 (U = G g in f64, then split).  tiles_per_wave: 3 (288
+ * accumulators, 9 MFMAs per weight fragment pair), 2, or 0 = chosen by the launch's last-round occupancy.  The input is
+ * addressed through a buffer descriptor rebased per workgroup, so any B * Hp * W * Cin is accepted (B * Hp < 2^29).
+ * AC_ERR_ARG for shapes outside this list. */
+int ac_conv3x3_bn_relu_wino43(const float* in, const void* wfrag, const float* scale, const float* shift, float* out,
+                              int B, int Hp, int H, int W, int Cin, int Cout, int mode, int map_mode, int tiles_per_wave,
+                              const int* clip_frames, int need_mul, int need_add, void* stream);
+/* ... followed by F.dropout in the epilogue (see ac_conv3x3_bn_relu_wino1d_drop). */
+int ac_conv3x3_bn_relu_wino43_drop(const float* in, const void* wfrag, const float* scale, const float* shift, float* out,
+                                   int B, int Hp, int H, int W, int Cin, int Cout, int mode, int map_mode, float drop_p,
+                                   unsigned long long drop_seed, const unsigned long long* seed_dev, void* stream);
+/* Workgroups ac_conv3x3_bn_relu_wino43 launches for a geometry at two tiles per wave (0: not covered): callers route
+ * launches of a few workgroups (single clips) to the K-sliced F(2,3) form instead. */
+long ac_conv3x3_wino43_workgroups(int B, int Hp, int W, int Cout);
+
 /* "f16x2" tier of the same kernel.  Activations live in HBM as fp16 (in: [B*Hp][W][Cin] fp16; out: fp16 for modes 0
  * and 1, f32 for mode 2 = the attn_emb the rest of the path consumes), weights as fp16 hi + lo (2^-22) in the same
  * fragment order, two fp16 MFMA products per f32 product, f32 accumulation, fp16 rounding (RNE, 2^-12 relative) once

@@ -1,5 +1,6 @@
 """GPU parity tests of the assembled path against the golden fixtures (reference outputs) and the
 oracle: Cnn14 from log-mel, decoder forward, greedy and beam token ids, and the wav -> tokens path."""
+import contextlib
 import os
 
 import numpy as np
@@ -36,27 +37,39 @@ def _cnn_from_logmel(cnn, lms):
     return attn, blocks
 
 
-# Absolute tolerances per conv tier on O(1) activations / logits.  The f32-grade tiers - "wino1d" (the default: F(2,3)
-# Winograd on split-bf16 operands), "bf16x3" (direct, split bf16; 2^-16 operand error) and the exact-f32 "winograd" - are
+# Absolute tolerances per conv tier on O(1) activations / logits.  The f32-grade tiers - "wino43" (the default: F(4,3) /
+# F(2,3) Winograd on split-bf16 operands; run here with the F(4,3) kernel forced onto these few-clip batches, which the
+# default routes to the K-sliced F(2,3) form), "wino1d" (F(2,3) everywhere), "bf16x3" (direct, split bf16; 2^-16 operand error) and the exact-f32 "winograd" - are
 # held to SURVEY 8(d)'s fp32 gate end to end: identical token ids, logits within 1e-4; the opt-in "f16x2" tier (fp16
 # activations) to BASELINE.json's half-precision bar: identical token ids, logits within 1e-3 (measured: 4e-4).
 _F32_GRADE = {"block": 1e-4, "attn_golden": 2e-4, "attn_e2e": 5e-4, "logit_e2e": 1e-4, "block_sum_rtol": 2e-5}
-TIER_TOL = {"wino1d": _F32_GRADE, "bf16x3": _F32_GRADE, "winograd": _F32_GRADE,
+TIER_TOL = {"wino43": _F32_GRADE, "wino1d": _F32_GRADE, "bf16x3": _F32_GRADE, "winograd": _F32_GRADE,
             "f16x2": {"block": 1.5e-3, "attn_golden": 1e-3, "attn_e2e": 1e-3, "logit_e2e": 1e-3, "block_sum_rtol": 1e-4}}
 
 
-@pytest.fixture(params=["wino1d", "bf16x3", "winograd", "f16x2"])
+@contextlib.contextmanager
+def _tier(cnn, algo):
+    """Run with conv tier ``algo``; "wino43" with its F(4,3) kernel on every layer it covers, whatever the batch size."""
+    from audiocaption_amd import cnn_encoder as CE
+    saved, saved_min = cnn.conv_algo, CE.W43_MIN_WORKGROUPS
+    cnn.conv_algo = algo
+    if algo == "wino43":
+        CE.W43_MIN_WORKGROUPS = 1
+    try:
+        yield
+    finally:
+        cnn.conv_algo, CE.W43_MIN_WORKGROUPS = saved, saved_min
+
+
+@pytest.fixture(params=["wino43", "wino1d", "bf16x3", "winograd", "f16x2"])
 def conv_tier(request, hip_model):
-    """Run the test once per conv tier of the Cnn14: the default, the other two f32-grade ones and the fp16 one."""
-    cnn = hip_model.encoder.cnn
-    saved = cnn.conv_algo
-    cnn.conv_algo = request.param
-    yield request.param
-    cnn.conv_algo = saved
+    """Run the test once per conv tier of the Cnn14: the default, the other f32-grade ones and the fp16 one."""
+    with _tier(hip_model.encoder.cnn, request.param):
+        yield request.param
 
 
 def test_default_conv_tier(hip_model):
-    assert hip_model.encoder.cnn.conv_algo == os.environ.get("AUDIOCAPTION_CONV_ALGO", "wino1d")
+    assert hip_model.encoder.cnn.conv_algo == os.environ.get("AUDIOCAPTION_CONV_ALGO", "wino43")
 
 
 def test_g1_cnn14_vs_reference_golden(hip_model, golden_dir, conv_tier):
@@ -119,7 +132,7 @@ def test_f16x2_tier_odd_geometries(hip_model, monkeypatch, B, T):
     assert _maxdiff(f"attn_emb f16x2 vs f32 B={B} T={T}", got, want) < 1e-3 * max(1.0, float(want.abs().max()))
 
 
-@pytest.mark.parametrize("algo", ["direct", "winograd", "bf16x3", "bf16x3_lds", "wino1d", "f16x2"])
+@pytest.mark.parametrize("algo", ["direct", "winograd", "bf16x3", "bf16x3_lds", "wino1d", "wino43", "f16x2"])
 def test_g1_cnn14_every_conv_algorithm(hip_model, golden_dir, algo):
     """Every conv kernel family against the reference's attn_emb (bar 2e-4 abs; f32 kernels land at ~5e-6,
     the split-bf16 ones at ~2e-5; the fp16-activation tier "f16x2" has its own bar, 1e-3 = BASELINE.json's
@@ -127,14 +140,10 @@ def test_g1_cnn14_every_conv_algorithm(hip_model, golden_dir, algo):
     from audiocaption_amd import procedural as P
     g = _load(golden_dir, "g1_cnn14.npz")
     cnn = hip_model.encoder.cnn
-    saved = cnn.conv_algo
-    try:
-        cnn.conv_algo = algo
+    with _tier(cnn, algo):
         lms = torch.from_numpy(P.synthetic_logmel(2, 1001)).cuda()
         attn, _ = _cnn_from_logmel(cnn, lms)
         assert _maxdiff(f"attn_emb[{algo}]", attn, g["attn_emb"]) < (1e-3 if algo == "f16x2" else 2e-4)
-    finally:
-        cnn.conv_algo = saved
 
 
 def test_g2_gru_vs_reference_golden(hip_model, golden_dir):
@@ -290,7 +299,7 @@ def test_wav_to_tokens_vs_oracle(hip_model, state4981, conv_tier):
     assert _maxdiff("e2e logit", out["logit"][:, :st], want["logit"][:, :st]) < tol["logit_e2e"]
 
 
-@pytest.mark.parametrize("algo", ["wino1d", "bf16x3", "winograd", "direct"])
+@pytest.mark.parametrize("algo", ["wino43", "wino1d", "bf16x3", "winograd", "direct"])
 def test_fp32_gate_from_the_oracles_logmel(hip_model, state4981, algo):
     """SURVEY 8(d)'s fp32 gate end to end on the reference-pinned part of the path: the ORACLE's log-mel through the HIP
     conv stack -> bi-GRU -> greedy decoding against the oracle from the same log-mel - logits within 1e-4, ids identical
@@ -306,12 +315,8 @@ def test_fp32_gate_from_the_oracles_logmel(hip_model, state4981, algo):
     enc_o = O.gru_forward(state4981, O.cnn14_from_logmel(state4981, lms), flen)
     want = O.greedy_decode(state4981, enc_o["attn_emb"], enc_o["attn_emb_len"], 20)
     cnn = hip_model.encoder.cnn
-    saved = cnn.conv_algo
-    try:
-        cnn.conv_algo = algo
+    with _tier(cnn, algo):
         attn, _ = _cnn_from_logmel(cnn, lms.cuda())
-    finally:
-        cnn.conv_algo = saved
     enc = hip_model.encoder.rnn({"attn": attn, "attn_len": flen})
     assert _maxdiff(f"attn_emb after the GRU [{algo}]", enc["attn_emb"], enc_o["attn_emb"]) < 1e-4
     out = hip_model.decoder.greedy(enc["attn_emb"], flen, 20, hip_model.start_idx, hip_model.end_idx, hip_model.pad_idx)
@@ -436,7 +441,9 @@ def test_ragged_batch_skips_dead_rows_bit_identically(hip_model, monkeypatch):
         wav[i, n:] = 0.0
     wav = torch.from_numpy(wav).cuda()
     inp = {"mode": "inference", "wav": wav, "wav_len": wav_len, "specaug": False, "sample_method": "greedy", "max_length": 12}
-    assert hip_model.encoder.cnn.conv_algo == "wino1d"
+    assert hip_model.encoder.cnn.conv_algo == "wino43"
+    from audiocaption_amd import cnn_encoder as CE
+    monkeypatch.setattr(CE, "W43_MIN_WORKGROUPS", 1)   # the F(4,3) kernel's dead-row skipping on this small batch too
     monkeypatch.setenv("AUDIOCAPTION_SKIP_DEAD_ROWS", "0")
     full = hip_model(dict(inp))
     monkeypatch.setenv("AUDIOCAPTION_SKIP_DEAD_ROWS", "1")
@@ -657,21 +664,17 @@ def test_mixed_tier_hands_block6_f32_activations(hip_model, golden_dir):
 
 
 @pytest.mark.parametrize("seconds", [1.0, 2.0, 3.0, 4.0, 6.0, 10.0])
-@pytest.mark.parametrize("tier,bar", [("wino1d", 1e-4), ("f16x2", 5e-4)])
+@pytest.mark.parametrize("tier,bar", [("wino43", 1e-4), ("wino1d", 1e-4), ("f16x2", 5e-4)])
 def test_tier_logit_error_by_clip_length(hip_model, state4981, seconds, tier, bar):
     """Worst logit error against the CPU oracle over 5 seeds per clip length, token ids identical: the DEFAULT tier
-    ("wino1d") inside the fp32 gate (1e-4) at every length; the opt-in fp16 tier (block 6 on split-bf16; batches with a
+    ("wino43", F(4,3) forced onto these two-clip batches) and the F(2,3) tier inside the fp32 gate (1e-4) at every length; the opt-in fp16 tier (block 6 on split-bf16; batches with a
     clip under ``f16x2_min_frames`` frames re-routed to split-bf16) <= 5e-4, half of BASELINE.json's half-precision bar."""
     from audiocaption_amd import procedural as P
     from oracle import cpu_path as O
     cnn = hip_model.encoder.cnn
     assert cnn.f16x2_block6 == "bf16x3"
-    saved = cnn.conv_algo
-    cnn.conv_algo = tier
-    try:
+    with _tier(cnn, tier):
         worst = _worst_logit_error(hip_model, state4981, seconds)
-    finally:
-        cnn.conv_algo = saved
     assert worst <= bar
 
 
