@@ -37,11 +37,9 @@
 
 #include "ac_common.h"
 #include "ac_drop.h"
+#include "ac_wino43.h"
 
 namespace {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 #ifndef W4_KO   // development (tools/conv_bench.py): 1 no weight loads, 2 no A reads, 4 no plane stores, 8 no row loads, 32 no MFMAs
 #define W4_KO 0
@@ -80,42 +78,6 @@ struct W4Params {
 
 enum { MODE_FULL = 0, MODE_POOL = 1 };
 
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
-}
-
-// x (4 floats) -> packed hi (2 dwords) and lo (2 dwords) bf16 quadruples: hi = RNE(x), lo = RNE(x - hi)
-__device__ __forceinline__ void split_bf16x4(const f32x4 x, u32x2& hi, u32x2& lo) {
-  hi.x = cvt_pk_bf16(x[0], x[1]);
-  hi.y = cvt_pk_bf16(x[2], x[3]);
-  const float h0 = __builtin_bit_cast(float, hi.x << 16), h1 = __builtin_bit_cast(float, hi.x & 0xffff0000u);
-  const float h2 = __builtin_bit_cast(float, hi.y << 16), h3 = __builtin_bit_cast(float, hi.y & 0xffff0000u);
-  lo.x = cvt_pk_bf16(x[0] - h0, x[1] - h1);
-  lo.y = cvt_pk_bf16(x[2] - h2, x[3] - h3);
-}
-
-__device__ __forceinline__ f32x4 vfma(float a, const f32x4 x, const f32x4 y) {   // a * x + y, one rounding per element
-  f32x4 r;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) r[j] = __builtin_fmaf(a, x[j], y[j]);
-  return r;
-}
-
-struct FastDiv4 {   // x mod d / x div d for 0 <= x < 2^23 with one reciprocal
-  int d;
-  float inv;
-  __device__ __forceinline__ explicit FastDiv4(int d_) : d(d_), inv(1.0f / (float)d_) {}
-  __device__ __forceinline__ int mod(int x) const {
-    int q = (int)((float)x * inv);
-    int r = x - q * d;
-    if (r < 0) r += d;
-    if (r >= d) r -= d;
-    return r;
-  }
-};
-
 // block -> (row block, channel tile); block b runs on XCD b % 8 (speed only).  1: an XCD streams one weight column slab
 // (NT % 8 == 0); 3: NT in {1, 2, 4, 8}: the channel tiles of a row block sit on 8 / NT ... XCDs each owning one slab;
 // 2: the channel tiles of a row block back to back on one XCD
@@ -139,26 +101,6 @@ __device__ __forceinline__ bool w4_block_map(const W4Params& p, int& m_tile, int
     m_tile = bid / p.NT;
   }
   return true;
-}
-
-// Dead block (as in csrc/conv3x3_wino1d.hip): every row lies in the padding of its clip(s), or beyond what the clip's own
-// length can bring to an output frame
-__device__ __forceinline__ bool w4_block_live(const W4Params& p, int row0, int nrows) {
-  bool live = false;
-  if (row0 < p.rows_total) {
-    const int r_end = row0 + nrows < p.rows_total ? row0 + nrows : p.rows_total;
-    int b = row0 / p.Hp;
-    for (int base = b * p.Hp; base < r_end; base += p.Hp, ++b) {
-      const int lo = (row0 > base ? row0 : base) - base;
-      int lim = p.H;
-      if (p.clip_frames) {
-        const int need = p.need_mul * p.clip_frames[b] + p.need_add;
-        lim = need < lim ? need : lim;
-      }
-      live = live || lo < lim;
-    }
-  }
-  return live;
 }
 
 template <int TC, int MW>
@@ -217,7 +159,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_w4_kernel(W4Params p) {
       for (int r = 0; r < 16; ++r) acc[q][m][r] = 0.f;
 
   const int row0 = 4 * quad0;
-  const bool live = w4_block_live(p, row0, 4 * PQ);
+  const bool live = w4_rows_live(row0, 4 * PQ, p.rows_total, p.Hp, p.H, p.clip_frames, p.need_mul, p.need_add);
   const bool all_pad = !live;
   const int nstep = p.Cin / KS;
   if (!all_pad) {
@@ -274,18 +216,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_w4_kernel(W4Params p) {
             preB[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, vbB + cs + (unsigned)(r + RB) * row_bytes, 0, 0));
         }
       };
-      // position pos of the rows d0..d5 (d[r] only touched where pos needs it)
-      auto transform = [&](int pos, const f32x4& d0, const f32x4& d1, const f32x4& d2, const f32x4& d3, const f32x4& d4,
-                           const f32x4& d5) -> f32x4 {
-        if (pos == 0) return vfma(4.f, d0, vfma(-5.f, d2, d4));
-        if (pos == 5) return vfma(4.f, d1, vfma(-5.f, d3, d5));
-        if (pos == 1 || pos == 2) {
-          const f32x4 t1 = vfma(-4.f, d2, d4), t2 = vfma(-4.f, d1, d3);
-          return pos == 1 ? t1 + t2 : t1 - t2;
-        }
-        const f32x4 t3 = d4 - d2, u = d3 - d1;
-        return pos == 3 ? vfma(2.f, u, t3) : vfma(-2.f, u, t3);
-      };
       auto store_piece = [&](unsigned char* buf, unsigned lofs, int pos, const f32x4 v) {
         u32x2 hi, lo;
         split_bf16x4(v, hi, lo);
@@ -297,12 +227,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_w4_kernel(W4Params p) {
       auto commit_piece = [&](unsigned char* buf, int k) {
         if (W4_KO & 4) return;
         if (k < 6) {
-          store_piece(buf, lofsA, k, transform(k, preA[0], preA[1], preA[2], preA[3], preA[4], preA[5]));
+          store_piece(buf, lofsA, k, w4_transform(k, preA[0], preA[1], preA[2], preA[3], preA[4], preA[5]));
         } else {
           const int pos = HPB + (k - 6);
           const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-          if (HPB == 0) store_piece(buf, lofsB, pos, transform(pos, preB[0], preB[1], preB[2], preB[3], preB[4], z));
-          else store_piece(buf, lofsB, pos, transform(pos, z, preB[0], preB[1], preB[2], preB[3], preB[4]));
+          if (HPB == 0) store_piece(buf, lofsB, pos, w4_transform(pos, preB[0], preB[1], preB[2], preB[3], preB[4], z));
+          else store_piece(buf, lofsB, pos, w4_transform(pos, z, preB[0], preB[1], preB[2], preB[3], preB[4]));
         }
       };
       auto a_load = [&](const unsigned char* buf, int gi, bf16x8 (&a)[MW][2]) {
@@ -412,14 +342,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_w4_kernel(W4Params p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int r = 4 * g + e;
-        const float m0 = acc[0][m][r], m1 = acc[1][m][r], m2 = acc[2][m][r], m3 = acc[3][m][r], m4 = acc[4][m][r],
-                    m5 = acc[5][m][r];
-        const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
-        const float sc = sc4[g][e], sh = sh4[g][e];
-        y[g][0][e] = fmaxf(fmaf((m0 + s12) + s34, sc, sh), 0.f);
-        y[g][1][e] = fmaxf(fmaf(__builtin_fmaf(2.f, d34, d12), sc, sh), 0.f);
-        y[g][2][e] = fmaxf(fmaf(__builtin_fmaf(4.f, s34, s12), sc, sh), 0.f);
-        y[g][3][e] = fmaxf(fmaf(__builtin_fmaf(8.f, d34, d12) + m5, sc, sh), 0.f);
+        float yy[4];
+        w4_outputs(acc[0][m][r], acc[1][m][r], acc[2][m][r], acc[3][m][r], acc[4][m][r], acc[5][m][r], sc4[g][e], sh4[g][e], yy);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[g][j][e] = yy[j];
       }
     if (MODE == MODE_FULL) {
       const int h = by_hp.mod(gr);   // Hp % 4 == 0: the four rows of a quad belong to one clip

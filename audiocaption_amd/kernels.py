@@ -189,6 +189,25 @@ def conv3x3_bn_relu_wino1d(x, wfrag, scale, shift, out, B, Hp, H, W, Cin, Cout, 
     return out
 
 
+def conv3x3_block1_wino43(x0, w1, scale1, shift1, wfrag2, scale2, shift2, out, B, Hp, H, need=None, dropout=None):
+    """Conv block 1 in one kernel at f32 grade: conv1 computed into conv2's staging, conv2 + pool as F(4,3) on split-bf16
+    operands (csrc/conv3x3_block1_w4.hip).  x0 [B*Hp][64] f32, out [B*Hp/2][32][64] f32; ``wfrag2`` from
+    ``pack_conv_weight_wino43_frag``; ``need`` / ``dropout`` as for ``conv3x3_bn_relu_wino1d``."""
+    cf, mul, add = need if need is not None else (None, 0, 0)
+    dp, dseed, ddev = dropout if dropout is not None else (0.0, 0, None)
+    check(_lib.load().ac_conv3x3_block1_wino43(ptr(x0), ptr(w1), ptr(scale1), ptr(shift1), ptr(wfrag2), ptr(scale2),
+                                               ptr(shift2), ptr(out), B, Hp, H, ptr(cf), int(mul), int(add), float(dp),
+                                               int(dseed), ddev, stream()), "ac_conv3x3_block1_wino43")
+    return out
+
+
+def conv3x3_block1_conv2_wino43(x64, wfrag2, scale2, shift2, out, B, Hp, H):
+    """The conv2 + pool half of ``conv3x3_block1_wino43`` on a 64-channel input in HBM (tests: the unfused form)."""
+    check(_lib.load().ac_conv3x3_block1_conv2_wino43(ptr(x64), ptr(wfrag2), ptr(scale2), ptr(shift2), ptr(out), B, Hp, H,
+                                                     stream()), "ac_conv3x3_block1_conv2_wino43")
+    return out
+
+
 def wino43_workgroups(B, Hp, W, Cout):
     """Workgroups of ``conv3x3_bn_relu_wino43`` on this geometry (0: the F(4,3) kernel does not cover it)."""
     return int(_lib.load().ac_conv3x3_wino43_workgroups(B, Hp, W, Cout))

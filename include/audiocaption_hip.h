@@ -130,6 +130,23 @@ int ac_conv3x3_bn_relu_wino43_drop(const float* in, const void* wfrag, const flo
  * launches of a few workgroups (single clips) to the K-sliced F(2,3) form instead. */
 long ac_conv3x3_wino43_workgroups(int B, int Hp, int W, int Cout);
 
+/* Conv block 1 at f32 grade in ONE kernel (csrc/conv3x3_block1_w4.hip): conv1 (Cin = 1) + BN + ReLU is computed straight
+ * into the staging of conv2, conv2 + BN + ReLU + 2x2 average pool runs as F(4,3) on split-bf16 operands; persistent
+ * workgroups (one per CU) walk tiles of 8 rows x 64 columns.  The 64-channel intermediate never exists in HBM.
+ * in1 [B*Hp][64] f32 (log-mel after bn0), w1 [64][9], wfrag2 = the F(4,3) pack of conv2 ([4][18][2][hi, lo][64][8] bf16),
+ * out [B*Hp/2][32][64] f32.  Hp % 8 == 0.  Replaces ConvBlock.forward of conv_block1 + F.avg_pool2d, cnn_encoder.py:59-75 /
+ * :431-432: bit-identical to ac_conv3x3_first followed by ac_conv3x3_block1_conv2_wino43.  clip_frames / need_mul /
+ * need_add: ragged batches (see ac_conv3x3_bn_relu_wino1d); drop_p > 0: F.dropout on the pooled output in the epilogue
+ * (see ac_conv3x3_bn_relu_wino1d_drop). */
+int ac_conv3x3_block1_wino43(const float* in1, const float* w1, const float* scale1, const float* shift1,
+                             const void* wfrag2, const float* scale2, const float* shift2, float* out, int B, int Hp,
+                             int H, const int* clip_frames, int need_mul, int need_add, float drop_p,
+                             unsigned long long drop_seed, const unsigned long long* seed_dev, void* stream);
+/* The conv2 half of the same kernel on a 64-channel input in HBM ([B*Hp][64][64] f32, B*Hp*64*64*4 < 2^31): the unfused
+ * form the fused kernel is tested against. */
+int ac_conv3x3_block1_conv2_wino43(const float* in64, const void* wfrag2, const float* scale2, const float* shift2,
+                                   float* out, int B, int Hp, int H, void* stream);
+
 /* "f16x2" tier of the same kernel.  Activations live in HBM as fp16 (in: [B*Hp][W][Cin] fp16; out: fp16 for modes 0
  * and 1, f32 for mode 2 = the attn_emb the rest of the path consumes), weights as fp16 hi + lo (2^-22) in the same
  * fragment order, two fp16 MFMA products per f32 product, f32 accumulation, fp16 rounding (RNE, 2^-12 relative) once

@@ -170,3 +170,101 @@ def test_conv3x3_wino43_rejects_what_it_does_not_cover(K):
     with pytest.raises(HipLibraryError):
         K.conv3x3_bn_relu_wino43(x, wp, sc, sc, out, 2, 6, 5, 4, 64, 128, 0)      # Hp % 4 != 0
     assert K.wino43_workgroups(64, 256, 16, 256) == (64 * 64 + 3) // 4 * 2 and K.wino43_workgroups(1, 32, 2, 2048) == 0
+
+
+# ---- conv block 1 in one kernel (csrc/conv3x3_block1_w4.hip) ----------------------------------------------------------
+def _block1_case(B, H, seed):
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(seed)
+    Hp = (H + 8) & ~7
+    x = torch.randn(B, 1, H, 64, generator=g)
+    w1 = torch.randn(64, 1, 3, 3, generator=g) * 0.5
+    s1, t1 = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    w2 = torch.randn(64, 64, 3, 3, generator=g) * math.sqrt(2.0 / (9 * 64))
+    s2, t2 = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    y1 = F.relu(F.conv2d(x, w1, padding=1) * s1[None, :, None, None] + t1[None, :, None, None])
+    y2 = F.relu(F.conv2d(y1, w2, padding=1) * s2[None, :, None, None] + t2[None, :, None, None])
+    want = _to_rows(F.avg_pool2d(y2, 2), Hp // 2)
+    x0 = torch.zeros(B, Hp, 64)
+    x0[:, :H] = x[:, 0]
+    return x0.reshape(B * Hp, 64), w1.reshape(64, 9), s1, t1, w2, s2, t2, Hp, want
+
+
+@pytest.mark.parametrize("B,H", [(1, 13), (3, 37), (2, 250), (5, 1001)])
+def test_block1_wino43_vs_conv2d_and_vs_the_two_kernel_form(K, B, H):
+    """conv_block1 + avg_pool2d of the reference (cnn_encoder.py:59-75, :431-432) in ONE kernel against F.conv2d in fp32 on the
+    CPU (bar of the split-bf16 tiers), and bit for bit against conv1 (ac_conv3x3_first) followed by the unfused form of the
+    same kernel reading the 64-channel intermediate from HBM."""
+    x0, w1, s1, t1, w2, s2, t2, Hp, want = _block1_case(B, H, 100 * B + H)
+    dev = "cuda"
+    x0, w1, s1, t1, s2, t2 = (t.to(dev) for t in (x0, w1, s1, t1, s2, t2))
+    wp = K.pack_conv_weight_wino43_frag(w2.to(dev))
+    fused = torch.full((B * Hp // 2, 32, 64), 7.0, device=dev)
+    K.conv3x3_block1_wino43(x0, w1, s1, t1, wp, s2, t2, fused, B, Hp, H)
+    assert _report(f"block1 fused {B}x{H}", fused.reshape(want.shape), want) < 1e-3
+    mid = torch.full((B * Hp, 64, 64), 7.0, device=dev)
+    K.conv3x3_first(x0, w1, s1, t1, mid, B, Hp, H)
+    two = torch.full((B * Hp // 2, 32, 64), 7.0, device=dev)
+    K.conv3x3_block1_conv2_wino43(mid, wp, s2, t2, two, B, Hp, H)
+    assert torch.equal(fused, two)
+    again = torch.full_like(fused, 7.0)
+    K.conv3x3_block1_wino43(x0, w1, s1, t1, wp, s2, t2, again, B, Hp, H)
+    assert torch.equal(fused, again)
+
+
+def test_block1_wino43_many_tiles_per_workgroup(K):
+    """More tiles than CUs (persistent workgroups walk several tiles each; the staging of a tile's first K step runs under
+    the previous tile's last): 40 clips x 500 rows = 2560 tiles, every clip equal to the same clip convolved alone."""
+    B, H = 40, 500
+    x0, w1, s1, t1, w2, s2, t2, Hp, _ = _block1_case(1, H, 7)
+    dev = "cuda"
+    g = torch.Generator().manual_seed(3)
+    xs = torch.zeros(B, Hp, 64)
+    xs[:, :H] = torch.randn(B, H, 64, generator=g)
+    xs = xs.reshape(B * Hp, 64).to(dev)
+    w1, s1, t1, s2, t2 = (t.to(dev) for t in (w1, s1, t1, s2, t2))
+    wp = K.pack_conv_weight_wino43_frag(w2.to(dev))
+    out = torch.full((B * Hp // 2, 32, 64), 7.0, device=dev)
+    K.conv3x3_block1_wino43(xs, w1, s1, t1, wp, s2, t2, out, B, Hp, H)
+    for b in (0, 17, 39):
+        one = torch.full((Hp // 2, 32, 64), 7.0, device=dev)
+        K.conv3x3_block1_wino43(xs[b * Hp:(b + 1) * Hp].contiguous(), w1, s1, t1, wp, s2, t2, one, 1, Hp, H)
+        assert torch.equal(one, out[b * Hp // 2:(b + 1) * Hp // 2])
+
+
+def test_block1_wino43_dead_rows_and_dropout(K):
+    """Ragged batches: rows below a clip's need are bit-identical to the full convolution, tiles beyond it are zeros (and
+    some are skipped); F.dropout in the epilogue equals the separate counter-hash pass bit for bit."""
+    from audiocaption_amd.cnn_encoder import rows_needed
+    B, H = 5, 2900
+    x0, w1, s1, t1, w2, s2, t2, Hp, _ = _block1_case(1, 16, 11)
+    dev = "cuda"
+    g = torch.Generator().manual_seed(5)
+    xs = torch.zeros(B, (H + 8) & ~7, 64)
+    Hp = xs.shape[1]
+    xs[:, :H] = torch.randn(B, H, 64, generator=g)
+    xs = xs.reshape(B * Hp, 64).to(dev)
+    w1, s1, t1, s2, t2 = (t.to(dev) for t in (w1, s1, t1, s2, t2))
+    wp = K.pack_conv_weight_wino43_frag(w2.to(dev))
+    frames = torch.tensor([80, 4, 50, 2, 30], dtype=torch.int32)
+    mul, add = rows_needed(1, 2, quads=True)
+    full, skip = (torch.full((B * Hp // 2, 32, 64), 7.0, device=dev) for _ in range(2))
+    K.conv3x3_block1_wino43(xs, w1, s1, t1, wp, s2, t2, full, B, Hp, H)
+    K.conv3x3_block1_wino43(xs, w1, s1, t1, wp, s2, t2, skip, B, Hp, H, need=(frames.to(dev), mul, add))
+    f, s_ = full.reshape(B, Hp // 2, -1).cpu(), skip.reshape(B, Hp // 2, -1).cpu()
+    zeroed = 0
+    for b in range(B):
+        n = min(int(mul * frames[b] + add), H) // 2
+        assert torch.equal(f[b, :n], s_[b, :n]), (b, n)
+        tail = s_[b, n:]
+        same, zero = (tail == f[b, n:]).all(dim=1), (tail == 0).all(dim=1)
+        assert bool((same | zero).all())
+        zeroed += int((zero & ~same).sum())
+    assert zeroed > 0
+    step = torch.tensor([5], dtype=torch.int64, device=dev)
+    for seed_dev in (None, step.data_ptr()):
+        two = full.clone()
+        K.dropout_(two, two.numel(), 0.2, 77, seed_dev)
+        one = torch.full_like(full, 7.0)
+        K.conv3x3_block1_wino43(xs, w1, s1, t1, wp, s2, t2, one, B, Hp, H, dropout=(0.2, 77, seed_dev))
+        assert torch.equal(one, two)

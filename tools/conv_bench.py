@@ -29,7 +29,7 @@ def main():
     build.build()
     B = args.batch
     dev = "cuda:0"
-    tot = {a: 0.0 for a in args.algos.split(",")}
+    tot = {a: 0.0 for a in args.algos.split(",") if a != "block1"}
     for name, H, Hp, W, Cin, Cout, mode in LAYERS:
         if args.layers and name not in args.layers.split(","):
             continue
@@ -48,6 +48,8 @@ def main():
         gflop = 2.0 * 9 * Cin * Cout * H * W * B / 1e9
         line = f"{name} {Cin:4d}->{Cout:4d} {H}x{W} mode{mode} {gflop:7.1f} GF"
         for algo in args.algos.split(","):
+            if algo == "block1":
+                continue
             if algo == "direct":
                 wp = K.pack_conv_weight(w)
                 fn = lambda: K.conv3x3_bn_relu(x, wp, sc, sh, out, B, Hp, H, W, Cin, Cout, mode)
@@ -95,6 +97,33 @@ def main():
             tot[algo] += ms
             line += f" | {algo} {ms * 1000:8.1f} us {gflop / ms:7.1f} TF"
         print(line, flush=True)
+    if "block1" in args.algos.split(","):   # conv block 1: conv_first + F(2,3) conv2 against the one-kernel F(4,3) form
+        H, Hp = 1001, 1024
+        x0 = torch.randn(B * Hp, 64, device=dev)
+        x0.view(B, Hp, 64)[:, H:] = 0
+        w1 = torch.randn(64, 9, device=dev) * 0.3
+        w2 = torch.randn(64, 64, 3, 3, device=dev) * (2.0 / (9 * 64)) ** 0.5
+        s1, t1, s2, t2 = (torch.rand(64, device=dev) + 0.5 for _ in range(4))
+        mid = torch.empty(B * Hp, 64, 64, device=dev)
+        o1, o2 = torch.empty(B * Hp // 2, 32, 64, device=dev), torch.empty(B * Hp // 2, 32, 64, device=dev)
+        wp23, wp43 = K.pack_conv_weight_wino1d_frag(w2), K.pack_conv_weight_wino43_frag(w2)
+
+        def two():
+            K.conv3x3_first(x0, w1, s1, t1, mid, B, Hp, H)
+            K.conv3x3_bn_relu_wino1d(mid, wp23, s2, t2, o1, B, Hp, H, 64, 64, 64, 1)
+
+        for name, fn in (("conv_first + wino1d", two),
+                         ("block1 fused F(4,3)", lambda: K.conv3x3_block1_wino43(x0, w1, s1, t1, wp43, s2, t2, o2, B, Hp, H)),
+                         ("conv2 alone, unfused F(4,3)", lambda: K.conv3x3_block1_conv2_wino43(mid, wp43, s2, t2, o2, B, Hp, H))):
+            fn()
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(args.iters):
+                fn()
+            e.record()
+            torch.cuda.synchronize()
+            print(f"block 1, {name}: {s.elapsed_time(e) / args.iters * 1000:8.1f} us  (maxdiff vs two-kernel F(2,3) {float((o1 - o2).abs().max()):.1e})")
     print("total ms:", {a: round(v, 3) for a, v in tot.items()})
 
 
