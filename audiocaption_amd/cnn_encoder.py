@@ -226,6 +226,8 @@ class Cnn14Encoder(nn.Module):
                         sc = (sc * inv).contiguous()
                     pk["convs"].append((wp, sc, sh))
             pk["mixed"] = mixed
+            if algo == "wino43":
+                pk["b1c2_f43"] = K.pack_conv_weight_wino43_frag(self.conv_block1.conv2.weight.detach().float())
         self._packed[algo] = (key, pk)
         return pk
 
@@ -332,6 +334,10 @@ class Cnn14Encoder(nn.Module):
             import functools
             conv = functools.partial(conv, overflow=overflow)
         fuse1 = algo == "f16x2" and os.environ.get("AUDIOCAPTION_FUSE_BLOCK1", "1") != "0"
+        # "wino43": conv block 1 in one kernel (conv1 computed into the F(4,3) staging of conv2) when the launch gives every
+        # CU a persistent workgroup; single clips keep conv_first + the K-sliced F(2,3) form
+        fuse1_w4 = algo == "wino43" and os.environ.get("AUDIOCAPTION_FUSE_BLOCK1", "1") != "0" and Hp[0] % 8 == 0 \
+            and B * Hp[0] // 8 >= W43_MIN_WORKGROUPS and pk.get("b1c2_f43") is not None
         if algo in WINO and dropout is None and os.environ.get("AUDIOCAPTION_W1_SPLITK", "1") != "0":
             import functools   # single clips: layers of a few workgroups run K-sliced over a shared workspace
             conv = functools.partial(conv, splitk_buf=lambda n: self._buf("w1_splitk", n, dev))
@@ -351,7 +357,11 @@ class Cnn14Encoder(nn.Module):
             if mixed and b == 5:
                 conv = K.conv3x3_bn_relu_bf16x3_gw
                 full = self._buf("full32", B * Hp[5] * 2 * CHANNELS[6], dev, torch.float32)
-            if b == 0 and fuse1:   # conv1 is computed inside conv2's kernel: its 64-channel output never reaches HBM
+            if b == 0 and fuse1_w4:
+                K.conv3x3_block1_wino43(x0, w1, s1, t1, pk["b1c2_f43"], s2, t2, pooled, B, Hp[0], H[0],
+                                        dropout=(dropout[0], dropout[1], dropout[2]) if dropout is not None else None,
+                                        **need(1, 2))
+            elif b == 0 and fuse1:   # conv1 is computed inside conv2's kernel: its 64-channel output never reaches HBM
                 K.conv3x3_block1_f16x2(x0, w1, s1, t1, w2, s2, t2, pooled, B, Hp[0], H[0], W, overflow=overflow)
             elif b == 0:
                 K.conv3x3_first(x0, w1, s1, t1, full, B, Hp[0], H[0], W, overflow=overflow)
@@ -359,7 +369,7 @@ class Cnn14Encoder(nn.Module):
                 conv(pooled, w1, s1, t1, full, B, Hp[b], H[b], W, cin, cout, 0, **need(b + 1, 1))
             if b < 5:
                 fused_drop = dropout is not None and algo in WINO and not (b == 0 and fuse1)
-                if not (b == 0 and fuse1):
+                if not (b == 0 and (fuse1 or fuse1_w4)):
                     kw = need(b + 1, 2) if algo not in WINO or wino1d_covers(cout) else {}
                     if fused_drop:   # the block's F.dropout in the conv kernel's epilogue
                         kw = {"dropout": (dropout[0], dropout[1] + b, dropout[2])}

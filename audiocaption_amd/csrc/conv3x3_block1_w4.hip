@@ -26,7 +26,14 @@
 namespace {
 
 #ifndef B1_RING
-#define B1_RING 6     // conv2 weight fragment ring (18 % B1_RING == 0): a group's pair is requested B1_RING - 1 groups ahead
+#define B1_RING 3     // conv2 weight fragment ring (18 % B1_RING == 0): a group's pair is requested B1_RING - 1 groups ahead
+#endif
+
+#ifndef B1_KO    // development: 1 no staging (conv1 / transform / split / plane stores), 2 no MFMAs, 4 no epilogue stores
+#define B1_KO 0
+#endif
+#ifdef B1_CLK
+__device__ unsigned long long b1_clk[8];
 #endif
 
 struct B1Params {
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(256, 1) void block1_w4_kernel(B1Params p) {
     // rows 0..4, two pieces, two pieces, row 5, two pieces, rows 6..8, two, two, row 9, two
     constexpr int ROW_AT[16] = {0, 1, 2, 3, 4, -1, -1, 5, -1, 6, 7, 8, -1, -1, 9, -1};
     constexpr int PIECE_AT[16] = {-1, -1, -1, -1, -1, 0, 2, -1, 4, -1, -1, -1, 6, 8, -1, 10};   // first of two pieces (j * 6 + pos)
-    if (gi >= 16) return;
+    if (gi >= 16 || (B1_KO & 1)) return;
     if (FUSED && gi == 0) taps_load(S);
     if (FUSED && ROW_AT[gi] >= 0) d[ROW_AT[gi]] = conv1_row(x, mask, ROW_AT[gi]);
     if (PIECE_AT[gi] >= 0) {
@@ -253,8 +260,15 @@ __global__ __launch_bounds__(256, 1) void block1_w4_kernel(B1Params p) {
   const int chw = cg * 32 + 4 * half;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
+#ifdef B1_CLK
+  unsigned long long clk_loop = 0, clk_epi = 0, clk_n = 0;
+  const unsigned long long clk_t0 = __builtin_readcyclecounter(), clk_rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll 1
   while (tile < p.tiles) {
+#ifdef B1_CLK
+    const unsigned long long clk_a = __builtin_readcyclecounter();
+#endif
     const int next = next_live(tile);   // >= p.tiles: none (its staging below then works on zeros nobody reads)
     // ---- four K steps; step s stages step s + 1 (step 3: step 0 of the next tile) ----
     auto step = [&](auto S_) {
@@ -270,6 +284,7 @@ __global__ __launch_bounds__(256, 1) void block1_w4_kernel(B1Params p) {
         else w_load(s + 1, gi + AH - 18, wr[(gi + AH) % RING]);
         // operand order (weights, pixels): D rows = channels, columns = pixels (16-byte stores in the epilogue); the first
         // products of a tile start from zero instead of the previous tile's sums
+        if (!(B1_KO & 2)) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
           if (s == 0 && gi < 6) {
@@ -287,6 +302,17 @@ __global__ __launch_bounds__(256, 1) void block1_w4_kernel(B1Params p) {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
           acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[gi % RING][0], af[gi & 1][m][0], acc[q][m], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+            asm volatile("" :: "v"(af[gi & 1][m][0]), "v"(af[gi & 1][m][1]), "v"(wr[gi % RING][0]), "v"(wr[gi % RING][1]));
+          if (s == 0 && gi < 6) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[q][m][r] = 0.f;
+          }
+        }
         // staging of the next step: steps 0-2 from this tile's inputs, step 3 from the next tile's
         if (FUSED) {
           // steps 0-2 stage this tile's next step, step 3 the first step of the next tile: its log-mel values replace this
@@ -317,6 +343,9 @@ __global__ __launch_bounds__(256, 1) void block1_w4_kernel(B1Params p) {
     step(std::integral_constant<int, 2>{});
     step(std::integral_constant<int, 3>{});
 
+#ifdef B1_CLK
+    const unsigned long long clk_b = __builtin_readcyclecounter();
+#endif
     // ---- epilogue: output transform, BN, ReLU, 2x2 pool.  Lane l owns PIXEL column 32 m + l % 32 of quad wq and, in
     // register quad g, channels chw + 8 g .. + 3; the two columns of a pooling window sit in lanes l, l ^ 1 ----
     {
@@ -357,13 +386,27 @@ __global__ __launch_bounds__(256, 1) void block1_w4_kernel(B1Params p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] *= p.drop.mask(oi + e);
           }
-          if (inside) *(f32x4*)(p.out + oi) = o;
+          if (inside && !(B1_KO & 4)) *(f32x4*)(p.out + oi) = o;
         }
       }
     }
     asm volatile("" :: "v"(touch));
+#ifdef B1_CLK
+    clk_loop += clk_b - clk_a;
+    clk_epi += __builtin_readcyclecounter() - clk_b;
+    ++clk_n;
+#endif
     tile = next;
   }
+#ifdef B1_CLK
+  if (tid == 0) {
+    atomicAdd(&b1_clk[0], clk_loop);
+    atomicAdd(&b1_clk[1], clk_epi);
+    atomicAdd(&b1_clk[2], __builtin_readcyclecounter() - clk_t0);
+    atomicAdd(&b1_clk[3], __builtin_amdgcn_s_memrealtime() - clk_rt0);
+    atomicAdd(&b1_clk[4], clk_n);
+  }
+#endif
 }
 
 template <bool FUSED>
@@ -404,6 +447,14 @@ static int b1_dispatch(bool fused, const float* in, const float* w1, const float
   p.drop = drop;
   return fused ? launch_b1<true>(p, (hipStream_t)stream) : launch_b1<false>(p, (hipStream_t)stream);
 }
+
+#ifdef B1_CLK
+extern "C" int ac_b1_clk_read(unsigned long long* out5, int reset) {
+  if (hipMemcpyFromSymbol(out5, HIP_SYMBOL(b1_clk), 40) != hipSuccess) return -2;
+  if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(b1_clk), z, 64) != hipSuccess) return -2; }
+  return 0;
+}
+#endif
 
 // C ABI: see include/audiocaption_hip.h
 extern "C" int ac_conv3x3_block1_wino43(const float* in1, const float* w1, const float* scale1, const float* shift1,
