@@ -119,7 +119,7 @@ SIGNATURES = {
     "ac_effnet_se_gate_t": (_I, [_P, _F, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ac_effnet_expand_depthwise": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     # waveform ingest (csrc/ingest.hip)
-    "ac_ingest_resample": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "ac_ingest_resample": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ac_mfma_bf16_probe": (_I, [_P, _I, _I, _P]),
 }
 

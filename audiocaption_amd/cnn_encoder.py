@@ -45,14 +45,35 @@ def wino1d_covers(cout):
     return cout % 128 == 0 or (cout == 64 and os.environ.get("AUDIOCAPTION_W1_C64", "1") != "0")
 
 
+def _wino1d_clip_chunk(B, Hp, W, Cin):
+    """Clips one F(2,3) launch may take: the kernel addresses its input with 32-bit BYTE offsets through one buffer descriptor
+    ((B * Hp + 16) * W * Cin * 4 < 2^31, csrc/conv3x3_wino1d.hip) - 127 ten-second clips at conv2 of block 1."""
+    return max(1, min(B, ((1 << 31) - 1) // (W * Cin * 4 * Hp) - 1))
+
+
 def _conv_wino1d(x, w, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode=-1, need=None, splitk_buf=None,
                  dropout=None):
     """The "wino1d" tier's launcher (``_pack`` packs a layer's weights for the kernel ``wino1d_covers`` names).
-    ``splitk_buf(floats) -> tensor``: workspace provider for the K-sliced launches of single clips."""
+    ``splitk_buf(floats) -> tensor``: workspace provider for the K-sliced launches of single clips.  A batch whose input
+    exceeds the kernel's 2 GiB addressing range is convolved in clip chunks (clips do not interact; rows are per clip)."""
     if not wino1d_covers(Cout):
         K.conv3x3_bn_relu_bf16x3_gw(x, w, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode)
         if dropout is not None:
             K.dropout_(out, out.numel() if mode != 1 else B * (Hp // 2) * (W // 2) * Cout, *dropout)
+        return out
+    chunk = _wino1d_clip_chunk(B, Hp, W, Cin)
+    if chunk < B:
+        if dropout is not None:
+            raise ValueError("F(2,3) conv: the dropout epilogue indexes the whole output buffer; batches beyond 2 GiB of input "
+                             "are not supported in train mode")
+        in_clip = Hp * W * Cin
+        out_clip = {0: Hp * W * Cout, 1: (Hp // 2) * (W // 2) * Cout, 2: H * Cout}[mode]
+        xf, of = x.reshape(-1), out.reshape(-1)
+        for b0 in range(0, B, chunk):
+            nb = min(chunk, B - b0)
+            nd = (need[0][b0:b0 + nb], need[1], need[2]) if need is not None else None
+            _conv_wino1d(xf[b0 * in_clip:(b0 + nb) * in_clip], w, scale, shift, of[b0 * out_clip:(b0 + nb) * out_clip], nb, Hp, H, W,
+                         Cin, Cout, mode, map_mode, need=nd, splitk_buf=splitk_buf)
         return out
     if dropout is not None:   # F.dropout on the block's output in the kernel's epilogue (no extra pass over the buffer)
         return K.conv3x3_bn_relu_wino1d(x, w, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode, dropout=dropout)

@@ -672,7 +672,9 @@ static int w1_dispatch(const float* in, const void* wfrag, const float* scale, c
   if (c64 && (W % 16 || mode == MODE_MEANW)) return AC_ERR_ARG;
   if (mode < 0 || mode > 2) return AC_ERR_ARG;
   if (mode == MODE_MEANW && W != 2) return AC_ERR_ARG;
-  if ((unsigned long long)(B * (unsigned long long)Hp + 2) * W * Cin >= (1ull << 31)) return AC_ERR_ARG;   // 32-bit offsets
+  // 32-bit BYTE offsets into the input: the staging addresses are (row, column, channel) * 4 through one buffer descriptor,
+  // and lanes without an item are parked on 0x80000000 + their row / step offsets, which must stay out of range
+  if (((unsigned long long)B * Hp + 16) * W * Cin * 4 >= (1ull << 31)) return AC_ERR_ARG;
   W1Params p;
   p.in = in; p.wpk = wfrag; p.scale = scale; p.shift = shift; p.out = out;
   p.rows_total = B * Hp; p.Hp = Hp; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;

@@ -2,8 +2,9 @@
 // lengths -> one zero-padded float32 batch at the model's sample rate, in ONE pass over the samples.
 //
 // Replaces, per clip, np.float32(h5 float16) (caption_dataset.py:131-145), torchaudio.functional.resample
-// (caption_dataset.py:110-120; the windowed-sinc polyphase filter of torchaudio==0.13.1, un-vendored: PARITY UNPINNED)
-// and the padding collate (inference.py:81-111).  torchaudio evaluates the filter as a dense strided conv1d over
+// (caption_dataset.py:110-120; the windowed-sinc polyphase filter of torchaudio==0.13.1, un-vendored: pinned by the
+// independent float64 witness of tests/golden/g13_resample.npz),
+// the random crop / zero pad to audio_duration (caption_dataset.py:121-129) and the padding collate (inference.py:81-111).  torchaudio evaluates the filter as a dense strided conv1d over
 // 2*width + orig taps per output sample; all but ~2*6*orig/(0.99*min(orig,new)) of them are exactly zero (the Hann
 // window is clamped), so each output sample here only walks the non-zero tap range of its phase.
 #include <hip/hip_fp16.h>
@@ -19,7 +20,8 @@ struct IngestP {
   const int* tap_lo;       // [new] first non-zero tap of each phase
   const int* tap_hi;       // [new] one past the last non-zero tap
   float* out;              // [B][lmax]
-  const int* out_len;      // [B] resampled lengths
+  const int* out_len;      // [B] samples of the resampled clip that exist (rows are zero beyond out_len[b] - out_start[b])
+  const int* out_start;    // [B] first resampled sample kept (random crop to audio_duration), may be null = 0
   int B, lmax, orig, new_, width, kw;
 };
 
@@ -27,8 +29,10 @@ __global__ void ingest_kernel(IngestP p) {
   const int b = blockIdx.y;
   const long len = p.src_off[b + 1] - p.src_off[b];
   const int olen = p.out_len[b];
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < p.lmax; i += gridDim.x * blockDim.x) {
+  const int start = p.out_start ? p.out_start[b] : 0;
+  for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < p.lmax; o += gridDim.x * blockDim.x) {
     float acc = 0.f;
+    const int i = o + start;     // index in the resampled clip
     if (i < olen) {
       if (p.new_ == p.orig) {
         const long s = p.src_off[b] + i;
@@ -46,20 +50,20 @@ __global__ void ingest_kernel(IngestP p) {
         }
       }
     }
-    p.out[(long)b * p.lmax + i] = acc;
+    p.out[(long)b * p.lmax + o] = acc;
   }
 }
 
 }  // namespace
 
 extern "C" int ac_ingest_resample(const void* src, int src_half, const long* src_off, const float* kernel, const int* tap_lo,
-                                  const int* tap_hi, float* out, const int* out_len, int B, int lmax, int orig, int new_,
-                                  int width, void* stream) {
+                                  const int* tap_hi, float* out, const int* out_len, const int* out_start, int B, int lmax,
+                                  int orig, int new_, int width, void* stream) {
   if (!src || !src_off || !out || !out_len || B <= 0 || lmax <= 0 || orig <= 0 || new_ <= 0 || width < 0) return AC_ERR_ARG;
   if (orig != new_ && (!kernel || !tap_lo || !tap_hi)) return AC_ERR_ARG;
   IngestP p;
   p.src = src; p.src_half = src_half; p.src_off = src_off; p.kernel = kernel; p.tap_lo = tap_lo; p.tap_hi = tap_hi;
-  p.out = out; p.out_len = out_len; p.B = B; p.lmax = lmax; p.orig = orig; p.new_ = new_; p.width = width;
+  p.out = out; p.out_len = out_len; p.out_start = out_start; p.B = B; p.lmax = lmax; p.orig = orig; p.new_ = new_; p.width = width;
   p.kw = 2 * width + orig;
   int gx = (lmax + 255) / 256;
   if (gx > 4096) gx = 4096;

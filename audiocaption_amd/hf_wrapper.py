@@ -67,7 +67,13 @@ class ContraEncoderKdWrapper(nn.Module, CaptionMetaMixin):
     """hf_wrapper.py:1071-1112.  Holds the captioner plus the contrastive knowledge-distillation heads that exist in the
     published state dict.  Inference passes straight through to the captioner (HIP path); with ``tchr_output`` in the input
     dict the symmetric contrastive loss between the projected clip embedding and the teacher's embedding is added as
-    ``enc_kd_loss`` (hf_wrapper.py:1095-1111) - a few torch ops on ``fc_emb``, outside the accelerated path."""
+    ``enc_kd_loss`` (hf_wrapper.py:1095-1111) - a few torch ops on ``fc_emb``, outside the accelerated path.
+
+    The loss is HEAD-ONLY here: ``fc_emb`` comes out of the HIP encoder detached, so ``enc_kd_loss`` trains
+    ``stdnt_proj`` / ``tchr_proj`` / ``logit_scale`` and sends no gradient into the encoder.  Distilling INTO the encoder
+    (the reference's recipe: mode "train", encoder_output_dict merged into the training output, base.py:133) needs the
+    encoder's backward, which this path does not build (SURVEY section 8 scope): mode "train" with ``tchr_output`` raises
+    ``NotImplementedError`` instead of returning a loss that silently trains nothing but the heads."""
 
     def __init__(self, model, shared_dim, tchr_dim):
         super().__init__()
@@ -79,6 +85,12 @@ class ContraEncoderKdWrapper(nn.Module, CaptionMetaMixin):
         self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
 
     def forward(self, input_dict):
+        if "tchr_output" in input_dict and input_dict.get("mode") == "train" and not input_dict.get("unsup", False):
+            raise NotImplementedError(
+                "ContraEncoderKdWrapper: encoder knowledge distillation in mode='train' needs the gradient of enc_kd_loss "
+                "with respect to the encoder (hf_wrapper.py:1095-1111 on top of base.py:133); the accelerated training "
+                "step returns no fc_emb and the HIP encoder has no backward.  Use mode='inference' (or unsup=True) for a "
+                "head-only loss")
         out = self.model.encoder(input_dict) if input_dict.get("unsup", False) else self.model(input_dict)
         if "tchr_output" in input_dict:
             # CLIP-style loss: cosine similarities of every (student clip, teacher clip) pair, scaled, matched on the diagonal

@@ -30,22 +30,27 @@ class DictTokenizer:
     def _adopt(self, word2idx):
         """Take a word -> index dict as THE vocabulary and derive what the other methods use from it."""
         self.word2idx = word2idx
+        self.idx2word = {i: w for w, i in word2idx.items()}
         self.idx = len(word2idx)
-        size = max(word2idx.values(), default=-1) + 1
-        table = np.full(size, "<unk>", dtype=object)           # index -> word, for decode
-        for w, i in word2idx.items():
-            table[i] = w
-        self._table = table
+        self._table = None                                         # index -> word array of ``decode``: built on first use
         self.bos, self.eos, self.pad = (word2idx[w] for w in ("<start>", "<end>", "<pad>"))
         self._unk = word2idx["<unk>"]
 
-    @property
-    def idx2word(self):
-        return {i: w for w, i in self.word2idx.items()}
+    def _lookup_table(self):
+        """index -> word as an object array (None where the vocabulary has no word); rebuilt after the vocabulary changed."""
+        if self._table is None:
+            table = np.full(max(self.idx2word, default=-1) + 1, None, dtype=object)
+            for i, w in self.idx2word.items():
+                table[i] = w
+            self._table = table
+        return self._table
 
     def add_word(self, word):
-        if word not in self.word2idx:
-            self._adopt(dict(self.word2idx, **{word: self.idx}))
+        if word not in self.word2idx:          # O(1), like the reference (text_tokenizer.py:30-34)
+            self.word2idx[word] = self.idx
+            self.idx2word[self.idx] = word
+            self.idx += 1
+            self._table = None
 
     def encode_word(self, word):
         return self.word2idx.get(word, self._unk)
@@ -65,8 +70,10 @@ class DictTokenizer:
             raise TypeError("DictTokenizer expects a list of caption strings")
         lookup, unk, keep = self.word2idx, self._unk, self.max_length
         ids = [[lookup.get(w, unk) for w in t.split()[:keep]] for t in texts]
+        if not ids:
+            return {"cap": np.zeros((0, 0), dtype=np.int64), "cap_len": np.zeros(0, dtype=np.int64)}
         lens = np.fromiter((len(r) + 2 for r in ids), dtype=np.int64, count=len(ids))
-        caps = np.full((len(ids), int(lens.max()) if len(ids) else 0), self.pad, dtype=np.int64)
+        caps = np.full((len(ids), int(lens.max())), self.pad, dtype=np.int64)
         caps[:, 0] = self.bos
         for r, (row, n) in enumerate(zip(ids, lens)):
             caps[r, 1:n - 1] = row
@@ -80,8 +87,13 @@ class DictTokenizer:
             ids = ids[None]
         ended = ids == self.eos
         stop = np.where(ended.any(axis=1), ended.argmax(axis=1), ids.shape[1])   # first end token of every row
-        words = self._table[np.clip(ids, 0, len(self._table) - 1)]
+        table = self._lookup_table()
         show = (np.arange(ids.shape[1])[None] < stop[:, None]) & (ids != self.bos)
+        inside = (ids >= 0) & (ids < len(table))
+        words = table[np.where(inside, ids, 0)]
+        bad = show & (~inside | np.equal(words, None))
+        if bad.any():                          # the reference's idx2word[token_id] raises for an id outside the vocabulary
+            raise KeyError(int(ids[bad][0]))
         return [" ".join(row[m]) for row, m in zip(words, show)]
 
 

@@ -147,13 +147,21 @@ class _RsAgWork:
 _RS_SHARDS = {}
 
 
+def default_grad_sync(world, backend):
+    """Gradient exchange when AUDIOCAPTION_GRAD_SYNC is not set: on RCCL with four or more ranks the sum goes as a direct
+    reduce-scatter + all-gather ("rs_ag": on a fully connected xGMI node every peer receives its shard over its own link,
+    and the two halves are separate collectives later work can sit between); a ring all-reduce otherwise (two ranks share
+    one link either way; gloo has no reduce_scatter_tensor fast path)."""
+    return "rs_ag" if backend == "nccl" and world >= 4 else "all_reduce"
+
+
 def allreduce_flat_gradients(flat_grad, process_group=None, async_op=False, algo=None):
     """Sum (a slice of) the flat gradient buffer over the ranks - the reference's DDP gradient all-reduce
     (run_ddp.py:98-108) as ONE collective per slice instead of per-parameter buckets - and return the world size (or,
     with ``async_op``, the work handle, None for a single rank); the division by the world size is folded into the clip
     coefficient (``clip_grad_norm_(..., grad_div=world)``).  No-op without an initialised process group.
 
-    ``algo`` (default AUDIOCAPTION_GRAD_SYNC, "all_reduce"): "rs_ag" spells the sum out as ``reduce_scatter_tensor`` into
+    ``algo`` (default AUDIOCAPTION_GRAD_SYNC, else ``default_grad_sync``): "rs_ag" spells the sum out as ``reduce_scatter_tensor`` into
     this rank's 1/N shard followed by ``all_gather_into_tensor`` back into the slice (the < N trailing elements that do not
     divide go through a tiny all-reduce).  Same sums, same bytes per link as a ring all-reduce; it exists so that the two
     halves are separate collectives on the wire of a fully connected xGMI node (7 links per GPU: each of the N - 1 peers
@@ -163,7 +171,7 @@ def allreduce_flat_gradients(flat_grad, process_group=None, async_op=False, algo
     world = dist_world_size(process_group)
     work = None
     if world > 1:
-        algo = algo or os.environ.get("AUDIOCAPTION_GRAD_SYNC", "all_reduce")
+        algo = algo or os.environ.get("AUDIOCAPTION_GRAD_SYNC") or default_grad_sync(world, dist.get_backend(process_group))
         if algo == "all_reduce":
             work = dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=process_group, async_op=async_op)
         elif algo == "rs_ag":
@@ -1029,7 +1037,19 @@ class TrainEngine:
         # synchronisation; ``gru_timeout()`` reads it for callers that want to raise.
         err = self._gru_error_word(st)
         if err is not None:
-            clip.state[3:4].add_((err != 0).to(clip.state.dtype))
+            hit = (err != 0).to(clip.state.dtype)
+            err.zero_()           # in stream order: the word judges ONE iteration, the next one starts clean
+            if world > 1:
+                # every rank must skip together: this rank's gradients are already in the others' all-reduced sums
+                import torch.distributed as dist
+                dist.all_reduce(hit, op=dist.ReduceOp.MAX, group=process_group)
+            clip.state[3:4].add_(hit)
+            if getattr(self, "_gru_timeouts", None) is None or self._gru_timeouts.device != hit.device:
+                self._gru_timeouts = torch.zeros(1, device=hit.device, dtype=torch.float32)
+            self._gru_timeouts.add_(hit.to(torch.float32))
+        if getattr(self, "_skipped", None) is None or self._skipped.device != clip.state.device:
+            self._skipped = torch.zeros(1, device=clip.state.device, dtype=torch.float32)
+        self._skipped.add_((clip.state[3:4] != 0).to(torch.float32))   # updates skipped so far (non-finite gradients, GRU timeouts)
         if isinstance(optimizer, FusedAdam):
             optimizer.step(clip=clip)
         else:
@@ -1046,7 +1066,7 @@ class TrainEngine:
                 _lib.bump_param_generation(self.flat.params)
         out = self._outputs(st)
         return {"loss": st["ws"].tensor("loss")[0], "total_norm": clip.total_norm, "logit": out["logit"],
-                "seq": out.get("seq")}
+                "seq": out.get("seq"), "skipped_updates": self._skipped[0]}
 
 
 def _gru_error_word(self, st):
@@ -1057,9 +1077,15 @@ def _gru_error_word(self, st):
 
 
 def gru_timeout(self):
-    """True if a split-GRU launch of any shape state of this engine timed out waiting for a partner workgroup (reads the
-    device: synchronises).  The affected iterations' updates were skipped on the device; clears the word."""
+    """True if a split-GRU launch of this engine timed out waiting for a partner workgroup since the last call (reads the
+    device: synchronises).  ``step`` folds the kernel's error word into that iteration's skip flag and clears it, counting
+    the hits; a word raised by a forward that no ``step`` followed is picked up here.  The affected iterations' updates
+    were skipped on the device (on every rank under DDP)."""
     hit = False
+    cnt = getattr(self, "_gru_timeouts", None)
+    if cnt is not None and float(cnt.item()) != 0.0:
+        hit = True
+        cnt.zero_()
     for st in self._states.values():
         err = _gru_error_word(self, st)
         if err is not None and int(err.item()) != 0:
@@ -1068,8 +1094,16 @@ def gru_timeout(self):
     return hit
 
 
+def skipped_updates(self):
+    """Optimiser updates ``step`` has skipped on the device so far (non-finite gradient norm, run.py:123, or a split-GRU
+    partner timeout); reads the device."""
+    c = getattr(self, "_skipped", None)
+    return int(c.item()) if c is not None else 0
+
+
 TrainEngine._gru_error_word = _gru_error_word
 TrainEngine.gru_timeout = gru_timeout
+TrainEngine.skipped_updates = skipped_updates
 
 
 class _TrainBridge(torch.autograd.Function):

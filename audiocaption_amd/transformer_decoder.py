@@ -198,14 +198,16 @@ class TransformerDecoder(BaseDecoder):
               "ac_trm_greedy")
 
     def greedy(self, attn_emb, attn_emb_len, max_length, start_idx, end_idx, pad_idx):
-        """On-device greedy search.  Returns device tensors seq (int64), logit, logprob, embed, cnt.
+        """On-device greedy search.  Returns device tensors seq (int64), logit, logprob, embed, cnt.  ``attn_emb`` /
+        ``attn_emb_len``: one batch, or lists of batches of the same (frames, width) decoded as one chain.
 
         The ~370 short launches of a decode are latency-bound, so the fixed launch sequence (memory
         preparation + max_length decoder steps) is captured once per shape (on its second use) into a HIP graph over
         static buffers and replayed; inputs are copied in, outputs are cloned out (fresh tensors per call, as the
         reference returns).  Set AUDIOCAPTION_DECODE_GRAPH=0 to launch eagerly."""
-        dev = attn_emb.device
-        B, Tm, A = attn_emb.shape
+        parts = list(attn_emb) if isinstance(attn_emb, (list, tuple)) else [attn_emb]   # several batches, one chain: each is
+        dev = parts[0].device                                                           # copied into its rows of the static buffer
+        B, (Tm, A) = sum(p_.shape[0] for p_ in parts), parts[0].shape[1:]
         use_graph = os.environ.get("AUDIOCAPTION_DECODE_GRAPH", "1") != "0"
         key = (dev, B, Tm, max_length, start_idx, end_idx, pad_idx, self._weights_key())
         if self._greedy_state is None:
@@ -230,7 +232,12 @@ class TransformerDecoder(BaseDecoder):
         while len(states) > 8:
             states.pop(next(iter(states)))
         st["uses"] += 1
-        st["attn_emb"].copy_(attn_emb)
+        r0 = 0
+        for p_ in parts:
+            st["attn_emb"][r0:r0 + p_.shape[0]].copy_(p_)
+            r0 += p_.shape[0]
+        if isinstance(attn_emb_len, (list, tuple)):
+            attn_emb_len = torch.cat([torch.as_tensor(l_).cpu().reshape(-1) for l_ in attn_emb_len])   # host side
         st["mem_len"].copy_(K.upload(attn_emb_len, dev, torch.int32))
         if not use_graph or st["uses"] < 2:
             # first batch of this shape: plain launches (also the warm-up a capture needs); a shape that never comes

@@ -79,10 +79,24 @@ class CaptionModel(nn.Module, CaptionMetaMixin):
     def _check_flags(self, host_flags, input_dict):
         """host_flags = [fp16 overflow of the conv tier, split-GRU partner timeout] read back with the results."""
         if int(host_flags[1]) != 0:
+            algos = []
             for m in self.encoder.modules():   # the word is sticky on the device: clear it so that the NEXT batch is judged on its own
                 ws = getattr(m, "_split_ws", None)
                 if ws is not None:
                     ws.view(torch.int32)[:1].zero_()
+                if getattr(m, "gru_algo", None) == "split":
+                    algos.append(m)
+            # The split kernel needs its four workgroups per (clip, direction) co-resident; on a GPU shared with another
+            # process (or over-subscribed by other streams) a partner may never start.  Once that has happened the
+            # encoder moves to the single-workgroup kernel for good and the batch is run again (AUDIOCAPTION_GRU_FALLBACK=0:
+            # raise instead).
+            if algos and os.environ.get("AUDIOCAPTION_GRU_FALLBACK", "1") != "0" and not input_dict.get("_gru_retry"):
+                import warnings
+                for m in algos:
+                    m.gru_algo = "single"
+                warnings.warn("split GRU kernel: a workgroup's partner never started (GPU shared with another process?); this "
+                              "encoder now uses the single-workgroup kernel (AUDIOCAPTION_GRU_ALGO=single)")
+                return self.forward(dict(input_dict, _gru_retry=True))
             raise _lib.HipLibraryError("split GRU kernel: a workgroup's partner never started (GPU shared with another "
                                        "process?); set AUDIOCAPTION_GRU_ALGO=single")
         if int(host_flags[0]) != 0:
@@ -254,6 +268,9 @@ class TransformerModel(CaptionModel):
             enc = self.encoder.forward_front(input_dict) if split_enc else self.encoder(input_dict)
             enc_done = torch.cuda.Event()
             enc_done.record(enc_s)
+        # "auto" pairing asks whether the decode stream is idle: asked BEFORE this batch's own GRU is queued on it (afterwards
+        # the stream is never idle, and "auto" would hold every lone submission until result())
+        dec_was_idle = dec_s.query()
         if split_enc:
             with torch.cuda.stream(dec_s):
                 dec_s.wait_event(enc_done)
@@ -280,7 +297,7 @@ class TransformerModel(CaptionModel):
                 held = []
         held = held + [item]
         # "auto": a lone batch waits only while the decode stream is still busy; held batches go as soon as it is idle
-        if len(held) >= gmax or (pair == "auto" and dec_s.query()):
+        if len(held) >= gmax or (pair == "auto" and dec_was_idle):
             self._held = None
             self._decode_group(held)
         else:
@@ -429,10 +446,12 @@ class TransformerModel(CaptionModel):
                         t.record_stream(dec_s)
             if len(items) == 1:
                 attn, lens = items[0][1]["attn_emb"], items[0][1]["attn_emb_len"]
-            else:
-                attn = torch.cat([it[1]["attn_emb"] for it in items], 0)
-                lens = torch.cat([torch.as_tensor(it[1]["attn_emb_len"]).cpu() for it in items], 0)
+            else:   # the decoder copies every batch into its rows of the chain's static buffer: no concatenation launch
+                attn, lens = [it[1]["attn_emb"] for it in items], [it[1]["attn_emb_len"] for it in items]
             res = self.decoder.greedy(attn, lens, max_length, self.start_idx, self.end_idx, self.pad_idx)
+            same_b = len({it[1]["attn_emb"].shape[0] for it in items}) == 1
+            if len(items) > 1 and same_b:   # rows still unfinished after step t, per batch: one reduction for the whole chain
+                cnts = (res["seq"].view(len(items), -1, max_length) != self.end_idx).sum(1).to(torch.int32)
             r0 = 0
             staged = []
             for pending, enc, _, _ in items:
@@ -454,6 +473,8 @@ class TransformerModel(CaptionModel):
                     host_flag.zero_()
                 if len(items) == 1:
                     cnt = res["unfinished_cnt"]
+                elif same_b:
+                    cnt = cnts[len(staged)]
                 else:   # rows still unfinished after step t: finished rows hold end_idx (csrc/decoder.hip greedy_pick)
                     cnt = (res["seq"][rows] != self.end_idx).sum(0).to(torch.int32)
                 out = {"logit": res["logit"][rows], "embed": res["embed"][rows], "unfinished_cnt": cnt}

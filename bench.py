@@ -209,6 +209,40 @@ def timed_steps(ranks, run, steps):
     return ranks.max_seconds(ranks.last_own), out
 
 
+def collective_record(ranks, dev, nccl_floats=10_700_000):
+    """What makes an N > 1 line self-describing about the node's collectives: on RCCL the all-reduce / reduce-scatter +
+    all-gather rates on a buffer of the training step's gradient size; on gloo (CPU ranks, tests) the same two spellings of
+    the sum on a small buffer, checked against each other.  ``grad_sync_default``: what the training step picks when
+    AUDIOCAPTION_GRAD_SYNC is not set (audiocaption_amd/train.py default_grad_sync)."""
+    from audiocaption_amd.train import allreduce_flat_gradients, default_grad_sync
+    world = ranks.world
+    if ranks.backend == "nccl":
+        rec = time_allreduce(ranks, torch.zeros(nccl_floats, device=dev))
+    else:
+        rec = {"backend": ranks.backend, "world_size": world}
+        if world > 1:
+            a = torch.arange(1003, dtype=torch.float32) * (ranks.rank + 1)
+            b = a.clone()
+            t0 = time.perf_counter()
+            allreduce_flat_gradients(a, algo="all_reduce")
+            t1 = time.perf_counter()
+            allreduce_flat_gradients(b, algo="rs_ag")
+            t2 = time.perf_counter()
+            rec.update({"all_reduce_ms": (t1 - t0) * 1e3, "rs_ag_ms": (t2 - t1) * 1e3, "bytes": a.numel() * 4,
+                        "rs_ag_equals_all_reduce": bool(torch.equal(a, b))})
+    rec["grad_sync_default"] = default_grad_sync(world, ranks.backend)
+    return rec
+
+
+def seconds_per_rank(ranks, own_seconds, dev):
+    own = torch.tensor([own_seconds], dtype=torch.float64, device=dev if ranks.backend == "nccl" else "cpu")
+    if ranks.world == 1:
+        return [float(own)]
+    every = [torch.zeros_like(own) for _ in range(ranks.world)]
+    ranks.dist.all_gather(every, own)
+    return [float(t) for t in every]
+
+
 def bench_stub(args, ranks):
     """Launch-plumbing check without the HIP path (tests/test_bench_launch.py): the "step" is a small CPU matmul, everything
     else - ranks from the environment or self-spawned, barrier, MAX-over-ranks timing, rank 0 printing one line with
@@ -224,7 +258,9 @@ def bench_stub(args, ranks):
     run(args.warmup)
     elapsed, _ = timed_steps(ranks, run, args.steps)
     who = ranks.describe()      # collective: every rank calls it
-    return {"ranks": who, "metric": "stub steps/sec (launch plumbing only)", "value": ranks.world * args.steps / elapsed, "unit": "steps/s",
+    per_rank = seconds_per_rank(ranks, ranks.last_own, "cpu")
+    rccl = collective_record(ranks, "cpu")
+    return {"ranks": who, "seconds_per_rank": per_rank, "rccl": rccl, "metric": "stub steps/sec (launch plumbing only)", "value": ranks.world * args.steps / elapsed, "unit": "steps/s",
             "n_gpus": ranks.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "stub (no HIP path): one 128x128 CPU matmul per step", "backend": ranks.backend,
@@ -407,7 +443,7 @@ def time_allreduce(ranks, flat_grad):
         bus = lambda t: (2.0 * (world - 1) / world) * nbytes / (t * 1e-3) / 1e9 if world > 1 and t else None
         return {"world_size": world, "backend": dist.get_backend(), "all_reduce_ms": ms, "bytes": nbytes,
                 "bus_gbs": bus(ms), "rs_ag_ms": rs_ms, "rs_ag_bus_gbs": bus(rs_ms),
-                "grad_sync": os.environ.get("AUDIOCAPTION_GRAD_SYNC", "all_reduce"),
+                "grad_sync": os.environ.get("AUDIOCAPTION_GRAD_SYNC") or "default (see grad_sync_default)",
                 "xgmi_note": "8 GPUs fully connected, 7 links x ~153 GB/s per GPU: a ring is bound by ONE link per hop, "
                              "direct reduce-scatter / all-gather can use all 7"}
     except Exception as e:  # noqa: BLE001
@@ -676,6 +712,7 @@ def main():
     ap.add_argument("--effb2-batch", type=int, default=128, help="clips per GPU per step in the EffB2 measurement")
     ap.add_argument("--beam", type=int, default=3, help="beam size of the EffB2 measurement (0: greedy)")
     ap.add_argument("--no-effb2", action="store_true", help="skip the secondary EffB2-Trm measurement")
+    ap.add_argument("--no-ingest", action="store_true", help="skip the host-to-device / ingest measurements")
     ap.add_argument("--no-ragged", action="store_true", help="skip the secondary Clotho-shape (ragged batch) measurement")
     ap.add_argument("--clotho-shape", action="store_true",
                     help="ragged Clotho-shape set (SURVEY 8(d)): durations ~ U[15 s, 30 s] zero-padded to the batch "
@@ -947,6 +984,78 @@ def main():
             extra["ragged"] = ragged
         except Exception as e:  # noqa: BLE001
             extra["ragged"] = {"error": f"{type(e).__name__}: {e}"}
+    if world == 1 and not args.no_ingest and not args.clotho_shape and not args.sync_steps:
+        # secondary: the pipeline the reference's runner actually drives (run.py:22-27: every batch arrives in host memory and
+        # goes to the device inside the step) and the ingest row in front of it (float16 44.1 kHz clips
+        # -> float32 32 kHz batch: caption_dataset.py:110-145 + inference.py:81-111).  NOT the headline: `value` is quoted
+        # with resident inputs as the contract asks.
+        try:
+            import collections
+            import numpy as np
+            host = [w_.cpu().pin_memory() for w_ in wavs]
+            keep = collections.deque(maxlen=6)   # the device copies of the steps in flight stay referenced
+
+            def h2d_steps(n):
+                pend = []
+                for i in range(n):
+                    w_dev = host[i % NROT].to(dev, non_blocking=True)   # PCIe inside the step, like run.py:22-27
+                    keep.append(w_dev)
+                    pend.append(model.forward_async(dict(inputs[i % NROT], wav=w_dev)))
+                last = None
+                for p_ in pend:
+                    last = p_.result()
+                return last
+
+            h2d_steps(5)
+            t_h, _ = timed_steps(ranks, h2d_steps, args.steps)
+            extra["with_h2d"] = {"value": B * args.steps / t_h, "unit": "clips/s", "ms_per_step": t_h / args.steps * 1e3,
+                                 "bytes_per_step": int(host[0].numel() * 4),
+                                 "note": "pinned host batch -> device inside every step (run.py:22-27), forward_async"}
+            keep.clear()
+            del host
+            from audiocaption_amd.ingest import WaveformIngest
+            rng = np.random.default_rng(P.BASE_SEED + 5)
+            clips = [(f"c{i}", (0.1 * rng.standard_normal(int(44100 * args.seconds))).astype(np.float16)) for i in range(B)]
+            ing = WaveformIngest(44100, 32000, device=dev)
+
+            def ingest_steps(n):
+                out_ = None
+                for _ in range(n):
+                    out_ = ing(clips)
+                torch.cuda.synchronize(dev)
+                return out_
+
+            ingest_steps(2)
+            t_i, o_i = timed_steps(ranks, ingest_steps, 5)
+            # the kernel alone (HIP events): what is left when the host-side packing of the float16 samples is taken out
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            src = torch.from_numpy(np.concatenate([c for _, c in clips])).to(dev)
+            offs = torch.arange(B + 1, device=dev, dtype=torch.int64) * len(clips[0][1])
+            olen = torch.full((B,), ing.out_length(len(clips[0][1])), dtype=torch.int32, device=dev)
+            dst = torch.empty(B, int(olen[0]), device=dev)
+            from audiocaption_amd import _lib as _L
+            lib_ = _L.load()
+
+            def kern():
+                _L.check(lib_.ac_ingest_resample(_L.ptr(src), 1, _L.ptr(offs), _L.ptr(ing.kernel), _L.ptr(ing.tap_lo), _L.ptr(ing.tap_hi),
+                                                 _L.ptr(dst), _L.ptr(olen), None, B, dst.shape[1], ing.orig, ing.new, ing.width,
+                                                 _L.stream()), "ac_ingest_resample")
+            kern()
+            e0.record()
+            for _ in range(10):
+                kern()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            k_ms = e0.elapsed_time(e1) / 10
+            extra["ingest"] = {"value": B * 5 / t_i, "unit": "clips/s", "ms_per_batch": t_i / 5 * 1e3,
+                               "kernel_clips_per_s": B / (k_ms * 1e-3), "kernel_ms": k_ms,
+                               "kernel_gbs": (src.numel() * 2 + dst.numel() * 4) / (k_ms * 1e-3) / 1e9,
+                               "note": f"{B} float16 clips x {args.seconds:g} s @ 44.1 kHz -> float32 @ 32 kHz (WaveformIngest: host packing "
+                                       "into one pinned buffer + H2D + one kernel); kernel_* = the kernel alone on resident samples"}
+            del src, dst
+        except Exception as e:  # noqa: BLE001
+            extra["with_h2d"] = extra.get("with_h2d") or {"error": f"{type(e).__name__}: {e}"}
+            extra["ingest"] = extra.get("ingest") or {"error": f"{type(e).__name__}: {e}"}
     if world == 1 and not args.no_effb2:
         # secondary: EffB2-Transformer inference (BASELINE configs[2])
         try:
@@ -960,12 +1069,8 @@ def main():
         # N > 1: the inference path has no collective (clips are sharded), so the line carries what makes the run
         # self-describing - where every rank sat, its own time, and the node's collective rates on a buffer of the
         # training step's gradient size (42.8 MB) - next to the max-over-ranks headline
-        own = torch.tensor([elapsed_own], dtype=torch.float64, device=dev if ranks.backend == "nccl" else "cpu")
-        every = [torch.zeros_like(own) for _ in range(world)]
-        ranks.dist.all_gather(every, own)
-        multi = {"ranks": ranks.describe(), "seconds_per_rank": [float(t) for t in every],
-                 "rccl": time_allreduce(ranks, torch.zeros(10_700_000, device=dev)) if ranks.backend == "nccl" else
-                         {"backend": ranks.backend, "world_size": world}}
+        multi = {"ranks": ranks.describe(), "seconds_per_rank": seconds_per_rank(ranks, elapsed_own, dev),
+                 "rccl": collective_record(ranks, dev)}
     sustained = {}
     if rank == 0 and TIERS[default_tier]["peak"] == BF16_MFMA_PEAK_TFLOPS:
         try:   # context for `frac` (denominator: the nominal dense peak): what a bare MFMA loop reaches on this part
@@ -1034,6 +1139,9 @@ def main():
             "train_ms_per_step": val(extra.get("train_step"), "ms_per_step"),
             "effb2_trm_clips_per_s": val(extra.get("effb2_trm")),
             "logmel_hbm_frac": extra["mel_roofline"]["frac"],
+            "value_with_h2d": val(extra.get("with_h2d")),
+            "ingest_clips_per_s": val(extra.get("ingest")),
+            "ingest_kernel_clips_per_s": val(extra.get("ingest"), "kernel_clips_per_s"),
             "clotho_shape_clips_per_s": val((extra.get("ragged") or {}).get("skip")),
             "clotho_shape_no_skip_clips_per_s": val((extra.get("ragged") or {}).get("no_skip")),
         }
@@ -1041,7 +1149,8 @@ def main():
             result.update({"ranks": multi["ranks"], "seconds_per_rank": multi["seconds_per_rank"], "rccl": multi["rccl"]})
         details = {"tiers": tiers, "steady_state": steady, "blocking_model_call": blocking, "latency_b1_ms": latency,
                    "rooflines_other": {"logmel": extra["mel_roofline"], "decoder": extra["decoder_roofline"]},
-                   "train_step": extra.get("train_step"), "effb2_trm": extra.get("effb2_trm"), "ragged": extra.get("ragged")}
+                   "train_step": extra.get("train_step"), "effb2_trm": extra.get("effb2_trm"), "ragged": extra.get("ragged"),
+                   "with_h2d": extra.get("with_h2d"), "ingest": extra.get("ingest")}
         if not args.no_cpu_baseline and world == 1:
             try:
                 from oracle import cpu_path as O  # the CPU restatement, timed as a reported baseline only

@@ -80,7 +80,9 @@ int ac_conv3x3_bn_relu_bf16x3_gw(const float* in, const void* wfrag, const float
  * in / out f32 with the layouts of ac_conv3x3_bn_relu.  wfrag = U split and packed in MFMA fragment order
  * [Cin/32][3 kx][4 positions][2 k-steps][Cout/32][2 (hi, lo)][64 lanes][8] bf16, lane = (cout % 32) + 32 * ((cin % 16) / 8),
  * element = cin % 8.  Requires Hp even, W = 2 or a multiple of 4, Cin % 32 == 0, and Cout % 128 == 0 or Cout == 64 with
- * W % 16 == 0 (conv2 of block 1) (AC_ERR_ARG otherwise; mode 1 needs W >= 4, mode 2 needs W == 2).
+ * W % 16 == 0 (conv2 of block 1) (AC_ERR_ARG otherwise; mode 1 needs W >= 4, mode 2 needs W == 2), and an input of less
+ * than 2 GiB, (B * Hp + 16) * W * Cin * 4 < 2^31 (32-bit byte offsets through one buffer descriptor; AC_ERR_ARG beyond:
+ * the caller convolves the batch in clip chunks - the clips of a batch do not interact).
  * Ragged batches (the reference pads every clip to the batch maximum and convolves the padding, collate_func.py:29-32,
  * cnn_encoder.py:446-450): clip_frames (device int32 [B], may be NULL) = every clip's own attn_emb_len; workgroups whose
  * output rows all lie at or beyond need_mul * clip_frames[b] + need_add of their clip(s) skip the convolution and store
@@ -502,11 +504,14 @@ int ac_effnet_expand_depthwise(const float* x, const float* we, const float* be,
  * -> out [B][lmax] float32: converted, resampled by the windowed-sinc polyphase filter of
  * torchaudio.functional.resample (call site caption_dataset.py:110-120; kernel [new][2*width + orig] with the non-zero
  * tap range [tap_lo, tap_hi) of each phase; orig / new are the gcd-reduced rates; orig == new: conversion only) and
- * zero-padded beyond out_len[b] (WavPadCollate, inference.py:81-111).  PARITY UNPINNED for the filter (torchaudio is
- * not vendored). */
+ * zero-padded (WavPadCollate, inference.py:81-111).  out_len[b] = samples of the RESAMPLED clip; out_start[b] (may be NULL
+ * = 0) = its first sample kept: output sample o is resampled sample o + out_start[b], zero where that is >= out_len[b] -
+ * the random crop / zero pad to audio_duration of caption_dataset.py:121-129 (the caller draws the offsets).  The filter
+ * bank is pinned by tests/golden/g13_resample.npz (an independent float64 evaluation of torchaudio 0.13.1's published
+ * windowed-sinc prototype on the fine grid; torchaudio itself is not vendored). */
 int ac_ingest_resample(const void* src, int src_half, const long* src_off, const float* kernel, const int* tap_lo,
-                       const int* tap_hi, float* out, const int* out_len, int B, int lmax, int orig, int new_, int width,
-                       void* stream);
+                       const int* tap_hi, float* out, const int* out_len, const int* out_start, int B, int lmax, int orig,
+                       int new_, int width, void* stream);
 
 /* Diagnostic (bench.py, not the hot path): `blocks` workgroups of 4 waves each issue iters x 32 dependent-free
  * v_mfma_f32_32x32x16_bf16 (8 accumulators per wave, no memory traffic); out[blocks * 256] receives the accumulator sums.

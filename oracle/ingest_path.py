@@ -6,11 +6,13 @@ collate with its ``min_duration`` blacklist (``WavPadCollate``, inference.py:81-
 The collate is the reference's own code (pinned by restating it).  The resampler's arithmetic is torchaudio==0.13.1's
 ``_get_sinc_resample_kernel`` / ``_apply_sinc_resample_kernel`` (not vendored, not installed here); restated from the
 published algorithm - windowed-sinc polyphase filter, ``lowpass_filter_width=6``, ``rolloff=0.99``, Hann window
-(``sinc_interpolation``), computed in float64 and cast like torchaudio does when no dtype is given.  Pinned in two
-parts (tests/test_ingest_oracle.py): the polyphase machinery (kernel bank, phase order, padding, block reshape, output
-length) against an independent engine, ``scipy.signal.upfirdn`` driven by the prototype filter on the fine grid (5e-7 on
-five rate pairs); the prototype's FORMULA itself only by closed-form properties (DC gain, tap count, sinusoid
-amplitudes) - **that part stays "restated", parity unpinned**: no implementation of it exists in this image.
+(``sinc_interpolation``), computed in float64 and cast like torchaudio does when no dtype is given.  Pinned by an
+independent witness (tests/test_ingest_oracle.py): the filter bank and resampled signals of the committed fixture
+tests/golden/g13_resample.npz - the published prototype evaluated in float64 on the fine grid with numpy and run through
+``scipy.signal.upfirdn`` by tests/golden/make_resample_golden.py, which imports neither this file nor the product's table
+builder - plus closed-form properties (DC gain, tap count, sinusoid amplitudes).  torchaudio itself is not installed in
+the build image, so no run of the LIBRARY backs the formula: **witness-pinned, not reference-pinned**.
+The crop / pad to ``audio_duration`` (caption_dataset.py:121-129) is the reference's own code, restated.
 """
 import math
 
@@ -70,13 +72,31 @@ def wav_pad_collate(data_list, min_duration=0.32, sample_rate=32000):
     return {"aid": np.array(aids), "wav": out, "wav_len": np.array(lens), "blacklist_aid": black}
 
 
-def ingest(data_list, orig_sr, target_sr, min_duration=0.32):
-    """float16/float32 clips at orig_sr -> what the model's input_dict needs: resample each clip, then collate."""
+def crop_or_pad(wav, num_audio_samples, rng):
+    """``process_waveform`` after the resampler (caption_dataset.py:121-129): a random window of num_audio_samples from a
+    longer clip (``random.randint`` is inclusive on both ends), zeros behind a shorter one."""
+    n = wav.shape[0]
+    if n > num_audio_samples:
+        start = rng.randint(0, n - num_audio_samples)
+        return wav[start:start + num_audio_samples]
+    if n < num_audio_samples:
+        return np.concatenate([wav, np.zeros(num_audio_samples - n, dtype=wav.dtype)])
+    return wav
+
+
+def ingest(data_list, orig_sr, target_sr, min_duration=0.32, audio_duration=None, rng=None):
+    """float16/float32 clips at orig_sr -> what the model's input_dict needs: resample each clip, crop / pad it to
+    ``audio_duration`` when that is set (one ``rng.randint`` per longer clip, in order), then collate."""
+    import random
+    rng = rng if rng is not None else random
     items = []
     for aid, wav in data_list:
         if wav is None:
             items.append((aid, None))
             continue
         w = torch.as_tensor(np.array(wav, dtype=np.float32))
-        items.append((aid, resample(w[None], orig_sr, target_sr)[0].numpy()))
+        y = resample(w[None], orig_sr, target_sr)[0].numpy()
+        if audio_duration is not None:
+            y = crop_or_pad(y, int(audio_duration * target_sr), rng)
+        items.append((aid, y))
     return wav_pad_collate(items, min_duration, target_sr)

@@ -47,6 +47,23 @@ def test_bench_under_a_launcher_reads_the_ranks_from_the_environment():
     assert json.loads(lines[0])["n_gpus"] == 2
 
 
+def test_bench_gpus_8_stub_describes_every_rank():
+    """The driver's 8-GPU command on CPU ranks (gloo): the line carries one record per rank, per-rank seconds and the
+    collective timing object, so that the first real 8-GPU run describes itself."""
+    res = _run(["--gpus", "8", "--steps", "3", "--warmup", "1", "--stub-workload"], timeout=600)
+    assert res["n_gpus"] == 8 and [r["rank"] for r in res["ranks"]] == list(range(8))
+    assert len({r["pid"] for r in res["ranks"]}) == 8 and len(res["seconds_per_rank"]) == 8
+    assert res["rccl"]["world_size"] == 8 and res["rccl"]["backend"] == "gloo"
+    assert res["rccl"]["grad_sync_default"] == "all_reduce"          # rs_ag only on RCCL with >= 4 ranks
+    assert res["ms_per_step"] * 1e-3 * res["steps"] >= max(res["seconds_per_rank"]) - 1e-9
+
+
+def test_default_gradient_sync_by_backend_and_world_size():
+    from audiocaption_amd.train import default_grad_sync
+    assert default_grad_sync(8, "nccl") == "rs_ag" and default_grad_sync(4, "nccl") == "rs_ag"
+    assert default_grad_sync(2, "nccl") == "all_reduce" and default_grad_sync(8, "gloo") == "all_reduce"
+
+
 def test_bench_single_rank_stub():
     res = _run(["--steps", "2", "--warmup", "0", "--stub-workload"])
     assert res["n_gpus"] == 1

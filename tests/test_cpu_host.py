@@ -282,3 +282,7 @@ def test_contrastive_kd_wrapper_loss():
     assert "enc_kd_loss" not in w({"feat": feat})
     out["enc_kd_loss"].backward()
     assert w.stdnt_proj.weight.grad is not None and w.logit_scale.grad is not None
+    # distilling INTO the encoder (mode "train") needs the encoder's backward, which the accelerated path does not have: a
+    # clear refusal instead of a KeyError on the training output or a loss that trains only the heads
+    with pytest.raises(NotImplementedError, match="head-only"):
+        w({"feat": feat, "mode": "train", "tchr_output": {"embedding": tchr}})

@@ -435,3 +435,29 @@ def test_gru_split_kernel_under_uneven_load(K):
         assert float((got - want).abs().max()) < 1e-5, rep
     for b in range(B):   # zeros at the padded steps
         assert float(got[b, int(lens[b]):].abs().max() if int(lens[b]) < T else 0.0) == 0.0
+
+
+def test_conv3x3_wino1d_beyond_2gib_runs_in_clip_chunks(K):
+    """The F(2,3) kernel addresses its input with 32-bit byte offsets (one buffer descriptor): an input of 2 GiB or more -
+    conv2 of block 1 from 128 ten-second clips - is REJECTED by the C ABI, and the tier's launcher convolves the batch in
+    clip chunks instead.  160 clips: the clips on both sides of the chunk boundary equal the same clips convolved alone."""
+    from audiocaption_amd import cnn_encoder as CE
+    from audiocaption_amd._lib import HipLibraryError
+    B, H, Hp, W, C = 160, 1001, 1024, 64, 64
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(B, Hp, W, C, device="cuda", generator=g)
+    x[:, H:] = 0
+    x = x.reshape(B * Hp, W, C)
+    wp = K.pack_conv_weight_wino1d_frag(torch.randn(C, C, 3, 3, device="cuda", generator=g) * math.sqrt(2.0 / (9 * C)))
+    sc, sh = torch.rand(C, device="cuda", generator=g) + 0.5, torch.randn(C, device="cuda", generator=g) * 0.1
+    out = torch.full((B * Hp // 2, W // 2, C), 7.0, device="cuda")
+    with pytest.raises(HipLibraryError):
+        K.conv3x3_bn_relu_wino1d(x, wp, sc, sh, out, B, Hp, H, W, C, C, 1)
+    chunk = CE._wino1d_clip_chunk(B, Hp, W, C)
+    assert 100 < chunk < 128
+    CE._conv_wino1d(x, wp, sc, sh, out, B, Hp, H, W, C, C, 1)
+    one = torch.empty(Hp // 2, W // 2, C, device="cuda")
+    for b in (0, chunk - 1, chunk, B - 1):
+        K.conv3x3_bn_relu_wino1d(x[b * Hp:(b + 1) * Hp], wp, sc, sh, one, 1, Hp, H, W, C, C, 1)
+        assert torch.equal(one, out[b * Hp // 2:(b + 1) * Hp // 2]), b
+    assert float(out.abs().max()) < 50 and float(out[:Hp // 2].abs().mean()) > 0.05

@@ -717,3 +717,32 @@ def test_dropped_beam_handles_do_not_pile_up(hip_model):
     assert len(hip_model._lazy_queue) == 1
     assert torch.equal(keep.result()["seq"], want["seq"])
     assert len(hip_model._lazy_queue) == 0
+
+
+def test_split_gru_timeout_falls_back_to_the_single_workgroup_kernel(hip_model, monkeypatch):
+    """A partner timeout of the split GRU kernel (its sticky error word, raised when one of the four workgroups of a (clip,
+    direction) never starts - a GPU shared with another process): the blocking call clears the word, moves the encoder to
+    the single-workgroup kernel for good, warns, and returns the re-run batch's result (same tokens: the two kernels agree
+    to ~2e-6); with AUDIOCAPTION_GRU_FALLBACK=0 it raises instead."""
+    from audiocaption_amd import procedural as P
+    from audiocaption_amd._lib import HipLibraryError
+    rnn = hip_model.encoder.rnn
+    if rnn.gru_algo != "split":
+        pytest.skip("single-workgroup GRU configured")
+    wav = torch.from_numpy(P.synthetic_wav(2, 160000, seed=3, varied=True)).cuda()
+    inp = {"mode": "inference", "wav": wav, "wav_len": [160000, 120000], "specaug": False, "sample_method": "greedy", "max_length": 8}
+    want = hip_model(dict(inp))
+    try:
+        rnn._split_ws.view(torch.int32)[:1].fill_(1)          # what a timed-out workgroup leaves behind
+        monkeypatch.setenv("AUDIOCAPTION_GRU_FALLBACK", "0")
+        with pytest.raises(HipLibraryError):
+            hip_model(dict(inp))
+        assert rnn.gru_algo == "split" and int(rnn._split_ws.view(torch.int32)[0]) == 0
+        rnn._split_ws.view(torch.int32)[:1].fill_(1)
+        monkeypatch.setenv("AUDIOCAPTION_GRU_FALLBACK", "1")
+        with pytest.warns(UserWarning, match="single-workgroup"):
+            got = hip_model(dict(inp))
+        assert rnn.gru_algo == "single"
+        assert torch.equal(got["seq"], want["seq"]) and float((got["logit"] - want["logit"]).abs().max()) < 1e-4
+    finally:
+        rnn.gru_algo = "split"

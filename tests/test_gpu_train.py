@@ -785,7 +785,8 @@ def test_changing_batch_shapes_share_one_workspace(train_model):
 def test_split_gru_timeout_skips_the_update_on_the_device(train_model):
     """A partner timeout of the split GRU kernel (sticky error word of its exchange area) must not reach the parameters:
     the word is folded into the clip state's non-finite flag on the device, the update is skipped like a NaN loss
-    (run.py:123), ``gru_timeout()`` reports and clears it, and training goes on."""
+    (run.py:123) and counted, the word is cleared in stream order so that the NEXT iteration updates again (a sticky word
+    used to skip every later update silently), ``gru_timeout()`` reports the hit once, and training goes on."""
     from audiocaption_amd import procedural as Pr
     from audiocaption_amd.optim import FusedAdam
     from audiocaption_amd.train import TrainEngine
@@ -809,6 +810,8 @@ def test_split_gru_timeout_skips_the_update_on_the_device(train_model):
     assert np.isfinite(float(r["loss"]))
     assert torch.equal(eng.flat.flat, before)
     assert all(int(v["step"]) == 3 for v in opt.state_dict()["state"].values())
+    assert int(r["skipped_updates"]) == 1 and eng.skipped_updates() == 1
+    # the word judged ONE iteration: the next one updates again without anybody having called gru_timeout() in between
+    r2 = eng.step(batch, opt)
+    assert not torch.equal(eng.flat.flat, before) and int(r2["skipped_updates"]) == 1
     assert eng.gru_timeout() is True and eng.gru_timeout() is False
-    eng.step(batch, opt)
-    assert not torch.equal(eng.flat.flat, before)

@@ -78,3 +78,44 @@ def test_resample_polyphase_machinery_vs_scipy_upfirdn(orig, new):
     err = float(np.abs(got - want).max())
     print(f"resample {orig}->{new}: oracle vs scipy.upfirdn max|diff| {err:.2e} (signal max {float(np.abs(want).max()):.2f})")
     assert err < 2e-5                                          # float32 kernel + float32 convolution vs float64
+
+
+@pytest.mark.parametrize("orig,new", [(44100, 32000), (48000, 16000), (16000, 32000)])
+def test_filter_bank_and_resampler_vs_committed_fixture(orig, new):
+    """tests/golden/g13_resample.npz (tests/golden/make_resample_golden.py: numpy / scipy only, the published windowed-sinc
+    prototype evaluated in float64 on the fine grid - neither the product's table builder nor the oracle is imported there):
+    the PRODUCT's filter bank (audiocaption_amd.ingest._sinc_kernel, what csrc/ingest.hip walks) and the oracle's equal the
+    fixture's to float32 rounding, and the oracle's resampled signals equal scipy.signal.upfirdn's."""
+    import os
+    from audiocaption_amd.ingest import _sinc_kernel
+    from oracle import ingest_path as I
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g13_resample.npz"))
+    bank, width = g[f"bank_{orig}_{new}"], int(g[f"width_{orig}_{new}"])
+    k, w, o, n = _sinc_kernel(orig, new)
+    assert (w, k.shape) == (width, bank.shape) and float(np.abs(k.numpy() - bank).max()) <= 1e-7
+    ko, wo, _, _ = I.sinc_resample_kernel(orig, new)
+    assert wo == width and float(np.abs(ko.numpy() - bank).max()) <= 1e-7
+    y = I.resample(torch.from_numpy(g[f"x_{orig}_{new}"]), orig, new).numpy()
+    assert y.shape == g[f"y_{orig}_{new}"].shape and float(np.abs(y - g[f"y_{orig}_{new}"]).max()) < 2e-6
+
+
+def test_crop_or_pad_to_audio_duration_follows_the_dataset():
+    """caption_dataset.py:121-129: a longer clip loses all but a random window (random.randint, inclusive bounds, one draw
+    per longer clip in order), a shorter one is zero-padded, an exact one passes; every kept clip then has
+    int(audio_duration * target_sr) samples for the collate."""
+    import random
+    from oracle import ingest_path as I
+    rng = np.random.default_rng(3)
+    clips = [("long", rng.standard_normal(52000).astype(np.float32)), ("short", rng.standard_normal(9000).astype(np.float32)),
+             ("none", None), ("exact", rng.standard_normal(32000).astype(np.float32)),
+             ("long2", rng.standard_normal(40001).astype(np.float32))]
+    out = I.ingest(clips, 32000, 32000, audio_duration=1.0, rng=random.Random(7))
+    assert out["aid"].tolist() == ["long", "short", "exact", "long2"] and out["blacklist_aid"] == ["none"]
+    assert out["wav"].shape == (4, 32000) and out["wav_len"].tolist() == [32000] * 4
+    r = random.Random(7)
+    s0 = r.randint(0, 52000 - 32000)
+    s1 = r.randint(0, 40001 - 32000)
+    assert np.array_equal(out["wav"][0], clips[0][1][s0:s0 + 32000].astype(np.float64))
+    assert np.array_equal(out["wav"][1][:9000], clips[1][1].astype(np.float64)) and not out["wav"][1][9000:].any()
+    assert np.array_equal(out["wav"][2], clips[3][1].astype(np.float64))
+    assert np.array_equal(out["wav"][3], clips[4][1][s1:s1 + 32000].astype(np.float64))

@@ -177,6 +177,30 @@ def test_dict_tokenizer_vs_reference_fixture(golden_dir, tmp_path):
     assert grown.state_dict() == g["vocab"] and grown.decode(np.array(g["seqs"])) == g["decoded"]
 
 
+def test_dict_tokenizer_keeps_the_references_costs_and_errors():
+    """text_tokenizer.py:30-34 / :56-68: ``add_word`` is O(1) (a vocabulary of 20 k words builds in well under a second),
+    ``idx2word`` is a plain dict kept in step with ``word2idx``, an id outside the vocabulary that ``decode`` has to look up
+    raises KeyError like ``idx2word[token_id]`` does (ids behind the first <end> are never looked up), an empty list encodes
+    to empty arrays."""
+    import time
+    from audiocaption_amd.text import DictTokenizer
+    tok = DictTokenizer()
+    t0 = time.perf_counter()
+    for i in range(20000):
+        tok.add_word(f"w{i}")
+    assert time.perf_counter() - t0 < 1.0 and len(tok) == 20004
+    assert tok.idx2word is tok.idx2word and tok.idx2word[4] == "w0" and tok.idx2word[20003] == "w19999"
+    assert tok.decode([[1, 4, 5, 2, 999999]]) == ["w0 w1"]
+    with pytest.raises(KeyError):
+        tok.decode([[1, 4, 999999, 2]])
+    with pytest.raises(KeyError):
+        tok.decode([[1, -7, 2]])
+    tok.add_word("late")                                  # the decode table follows later additions
+    assert tok.decode([[20004, 2]]) == ["late"]
+    empty = tok([])
+    assert empty["cap"].shape == (0, 0) and empty["cap_len"].shape == (0,)
+
+
 def test_swa_averager_on_cpu_tensors():
     from audiocaption_amd.trainer import SwaAverager
     m = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.BatchNorm1d(3))
