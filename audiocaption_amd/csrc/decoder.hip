@@ -278,6 +278,41 @@ __device__ __forceinline__ float row_gemv256(const float* WT, const float* bias,
   const int lane = tid & 63, wave = tid >> 6;
   const f32x4* wp = (const f32x4*)(WT + (size_t)(wave * 64) * ROW_D) + lane;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#if defined(DEC_PK_PROBE)
+  // Development (tools/pk_rootcause.py, packed-f32 builds only): the same product with every weight row of a 16-row batch
+  // LANDED before the first multiply-add touches it.  DEC_PK_PROBE >= 1: explicit s_waitcnt vmcnt(0) lgkmcnt(0) between the
+  // loads and the arithmetic (inline asm: invisible to the compiler's own wait-count pass, which keeps its partial
+  // vmcnt(N) waits as well); 2: a workgroup-scope fence on top.
+  for (int k0 = 0; k0 < 64; k0 += 16) {
+    f32x4 wv[16];
+    float xv[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      wv[k] = wp[(size_t)(k0 + k) * (ROW_D / 4)];
+      xv[k] = x[wave * 64 + k0 + k];
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#if DEC_PK_PROBE == 2
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+#endif
+#if DEC_PK_PROBE == 3   // 3: sixteen idle issue slots between the landed loads and the first packed multiply-add
+    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+#endif
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+#if DEC_PK_PROBE == 4   // 4: the packed instructions never read a register a LOAD wrote: every row goes through a plain v_mov first
+#pragma unroll
+      for (int e = 0; e < 4; ++e) asm volatile("v_mov_b32 %0, %1" : "=v"(wv[k][e]) : "v"(wv[k][e]));
+      asm volatile("v_mov_b32 %0, %1" : "=v"(xv[k]) : "v"(xv[k]));
+#endif
+      asm volatile("" : "+v"(wv[k]));   // the arithmetic below cannot be hoisted above the wait
+      acc[0] = fmaf(wv[k][0], xv[k], acc[0]);
+      acc[1] = fmaf(wv[k][1], xv[k], acc[1]);
+      acc[2] = fmaf(wv[k][2], xv[k], acc[2]);
+      acc[3] = fmaf(wv[k][3], xv[k], acc[3]);
+    }
+  }
+#else
 #pragma unroll 16
   for (int k = 0; k < 64; ++k) {
     const f32x4 wv = wp[(size_t)k * (ROW_D / 4)];
@@ -287,6 +322,7 @@ __device__ __forceinline__ float row_gemv256(const float* WT, const float* bias,
     acc[2] = fmaf(wv[2], xv, acc[2]);
     acc[3] = fmaf(wv[3], xv, acc[3]);
   }
+#endif
   *(f32x4*)(part + wave * ROW_D + 4 * lane) = acc;
   __syncthreads();
   const float y = ((part[tid] + part[ROW_D + tid]) + (part[2 * ROW_D + tid] + part[3 * ROW_D + tid])) + (bias ? bias[tid] : 0.f);
