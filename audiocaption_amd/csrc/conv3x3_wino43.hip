@@ -48,6 +48,9 @@ namespace {
 #ifndef W4_RING     // weight fragment ring: a group's pair is requested W4_RING - 1 groups ahead (18 % W4_RING == 0)
 #define W4_RING 9
 #endif
+#ifndef W4_PRO2     // prologue: request the rows of the first two steps together
+#define W4_PRO2 1
+#endif
 #ifndef W4_ADEPTH   // A fragments are read this many groups ahead (1 or 2)
 #define W4_ADEPTH 2
 #endif
@@ -258,12 +261,36 @@ __global__ __launch_bounds__(256, 1) void conv3x3_w4_kernel(W4Params p) {
       constexpr int RING = W4_RING, AH = RING - 1, NA = W4_ADEPTH + 1, LASTG = 17 - W4_ADEPTH;
       static_assert(18 % RING == 0 && 18 % NA == 0 && NPIECE <= LASTG, "ring positions are static; staging ends before the barrier");
       bf16x8 wr[RING][2];   // ring of weight fragments: group gi lives in wr[gi % RING], requested RING - 1 groups ahead
+#if W4_PRO2
+      // the rows of steps 0 AND 1 are requested back to back before anything else (one exposed HBM round trip instead of
+      // two: step 0's staging below waits for the first set, step 0 of the K loop finds the second one landed), the
+      // weight fragments behind them (L2 hits, and the vector-memory counter retires in order)
+      f32x4 pre2[6];
+      rows_request(0);
+      if (MW == 2) {
+        const unsigned cs = (unsigned)(KS * 4);
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+          pre2[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, vbA + cs + (unsigned)r * row_bytes, 0, 0));
+      }
+#pragma unroll
+      for (int g0 = 0; g0 < AH; ++g0) w_load(0, g0, wr[g0]);
+#pragma unroll
+      for (int k = 0; k < NPIECE; ++k) commit_piece(sV, k);
+      if (MW == 2) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) preA[r] = pre2[r];
+      } else {
+        rows_request(1);
+      }
+#else
 #pragma unroll
       for (int g0 = 0; g0 < AH; ++g0) w_load(0, g0, wr[g0]);
       rows_request(0);
 #pragma unroll
       for (int k = 0; k < NPIECE; ++k) commit_piece(sV, k);
       rows_request(1);   // nstep >= 2
+#endif
       lds_barrier();     // LDS only: the rows just requested stay in flight
       bf16x8 af[NA][MW][2];   // A fragments (tile, hi | lo) of the current group and the next W4_ADEPTH ones
 #pragma unroll

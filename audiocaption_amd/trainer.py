@@ -80,3 +80,19 @@ class SwaAverager:
 
     def state_dict(self):
         return {k: a.clone() for k, a in zip(self.keys, self.avg)}
+
+
+def with_next(batches):
+    """Iterate ``(batch, next_batch)`` over a data loader (``next_batch`` is None behind the last one): what
+    ``TrainEngine.step(batch, optimizer, next_batch=next_batch)`` wants in order to run the frozen Cnn14 forward of the
+    following iteration on a side stream under the current one (train.py ``prefetch_cnn``; run.py:77-148 hands its batches
+    over one at a time)."""
+    it = iter(batches)
+    try:
+        cur = next(it)
+    except StopIteration:
+        return
+    for nxt in it:
+        yield cur, nxt
+        cur = nxt
+    yield cur, None

@@ -270,7 +270,7 @@ def bench_stub(args, ranks):
 # ---------------------------------------------------------------------------------------------------------------------
 # training step (BASELINE configs[3])
 # ---------------------------------------------------------------------------------------------------------------------
-def bench_train(args, ranks, steps, warmup, with_rccl=False):
+def bench_train(args, ranks, steps, warmup, with_rccl=False, roofline=True):
     """Training iterations of the reference's recipe (run.py:77-148; cnn14rnn_trm.yaml): frozen Cnn14 with dropout,
     bi-GRU, scheduled-sampling decoder (ss_ratio 0.85), LabelSmoothingLoss(0.1), backward, gradient all-reduce
     (RCCL on the flat gradient buffer), clip_grad_norm_(1.0), Adam(5e-4, weight_decay 1e-6) - everything
@@ -302,13 +302,16 @@ def bench_train(args, ranks, steps, warmup, with_rccl=False):
     engine = T.TrainEngine(model, seed=rank * 1000003)
     opt = FusedAdam([p for p in model.parameters() if p.requires_grad], lr=5e-4, weight_decay=1e-6)
     random.seed(rank)
+    # the frozen Cnn14 forward of iteration i + 1 runs on a side stream under iteration i (TrainEngine.prefetch_cnn): a data
+    # loader that hands over the next batch early (AUDIOCAPTION_TRAIN_LOOKAHEAD=0: the plain loop)
+    look_ahead = os.environ.get("AUDIOCAPTION_TRAIN_LOOKAHEAD", "1") != "0"
 
     r = None
 
     def run(n):
         last = None
         for _ in range(n):
-            last = engine.step(batch, opt, smoothing=0.1, max_grad_norm=1.0)
+            last = engine.step(batch, opt, smoothing=0.1, max_grad_norm=1.0, next_batch=batch if look_ahead else None)
         return last
 
     run(warmup)
@@ -320,6 +323,8 @@ def bench_train(args, ranks, steps, warmup, with_rccl=False):
     # HIP events around every ac_gemm launch of the backward (the replayed graph cannot be instrumented)
     roof = None
     try:
+        if not roofline:
+            raise RuntimeError("roofline not requested")
         ev = []
 
         def hook(phase, info):
@@ -945,6 +950,14 @@ def main():
                                                        "roofline", "rccl") if k in tr}
         except Exception as e:  # noqa: BLE001
             extra["train_step"] = {"error": f"{type(e).__name__}: {e}"}
+        try:   # the reference recipe's per-GPU batch at 8 ranks (run_ddp.py:68-69: batch 32 over 8 GPUs = 4 clips per GPU)
+            import copy
+            a4 = copy.copy(args)
+            a4.train_batch = 4
+            t4 = bench_train(a4, ranks, max(5, args.steps // 2), 3, with_rccl=False, roofline=False)
+            extra["train_step_b4"] = {k: t4[k] for k in ("value", "unit", "ms_per_step", "steps") if k in t4}
+        except Exception as e:  # noqa: BLE001
+            extra["train_step_b4"] = {"error": f"{type(e).__name__}: {e}"}
     if world == 1 and not args.no_ragged and not args.clotho_shape and not args.sync_steps:
         # secondary: a Clotho-shaped ragged batch (durations ~ U[15 s, 30 s], zero-padded to the longest) with
         # and without dead-row skipping - 32 clips, two resident batches, forward_async like the headline
@@ -1137,6 +1150,8 @@ def main():
             "steady_state_value": val(steady),
             "train_clips_per_s": val(extra.get("train_step")),
             "train_ms_per_step": val(extra.get("train_step"), "ms_per_step"),
+            "train_ms_per_step_b4": val(extra.get("train_step_b4"), "ms_per_step"),
+            "train_clips_per_s_b4": val(extra.get("train_step_b4")),
             "effb2_trm_clips_per_s": val(extra.get("effb2_trm")),
             "logmel_hbm_frac": extra["mel_roofline"]["frac"],
             "value_with_h2d": val(extra.get("with_h2d")),
@@ -1149,7 +1164,7 @@ def main():
             result.update({"ranks": multi["ranks"], "seconds_per_rank": multi["seconds_per_rank"], "rccl": multi["rccl"]})
         details = {"tiers": tiers, "steady_state": steady, "blocking_model_call": blocking, "latency_b1_ms": latency,
                    "rooflines_other": {"logmel": extra["mel_roofline"], "decoder": extra["decoder_roofline"]},
-                   "train_step": extra.get("train_step"), "effb2_trm": extra.get("effb2_trm"), "ragged": extra.get("ragged"),
+                   "train_step": extra.get("train_step"), "train_step_b4": extra.get("train_step_b4"), "effb2_trm": extra.get("effb2_trm"), "ragged": extra.get("ragged"),
                    "with_h2d": extra.get("with_h2d"), "ingest": extra.get("ingest")}
         if not args.no_cpu_baseline and world == 1:
             try:

@@ -217,3 +217,9 @@ def test_swa_averager_on_cpu_tensors():
     for n in ("0.weight", "0.bias", "1.weight"):
         want = sum(s[n] for s in snaps) / 4
         assert torch.allclose(sd[n], want, atol=1e-6)
+
+
+def test_with_next_pairs_every_batch_with_its_successor():
+    from audiocaption_amd.trainer import with_next
+    assert list(with_next([])) == [] and list(with_next(["a"])) == [("a", None)]
+    assert list(with_next(iter("abc"))) == [("a", "b"), ("b", "c"), ("c", None)]
