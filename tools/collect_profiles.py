@@ -11,8 +11,8 @@ import re
 import shutil
 import sys
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r03"
-TIER = sys.argv[2] if len(sys.argv) > 2 else "wino1d"
+R = sys.argv[1] if len(sys.argv) > 1 else "r04"
+TIER = sys.argv[2] if len(sys.argv) > 2 else "wino43"
 src, dst = "gpurun_out", "profiles"
 names = {f"{R}_bench_final.json": f"{R}_bench.json", f"{R}_bench_details.json": None, f"{R}_kernel_stats.txt": None,
          f"{R}_train_kernel_stats.txt": None, f"{R}_train_bench.json": None, f"{R}_effb2_bench.json": None,
@@ -29,7 +29,7 @@ for d in (f"{R}_pmc_{TIER}", f"{R}_pmc_effb2"):
         shutil.copy(f, os.path.join(dst, d, os.path.basename(f)))
 
 # the dominant kernel of bench.py's roofline: conv2 + BN + ReLU + 2x2 pool of blocks 2-5 (MODE_POOL = 1), 4 launches per step
-INST = {"wino1d": r"conv3x3_w1_kernel<1, 4, ", "f16x2": r"conv3x3_gw_kernel<128, 1, 1, 1, 256, false, 9, (8|4)>"}[TIER]
+INST = {"wino43": r"conv3x3_w4_kernel<1, ", "wino1d": r"conv3x3_w1_kernel<1, 4, ", "f16x2": r"conv3x3_gw_kernel<128, 1, 1, 1, 256, false, 9, (8|4)>"}[TIER]
 
 
 def pmc(counter):
@@ -42,12 +42,12 @@ def pmc(counter):
     return tot / n
 
 
-def algorithmic_bytes(batch=64, frames=1001):
-    """Input once + pooled output once + packed weights once, mean over the four launches (f32 activations; the wino1d
-    weights are 12 transformed taps x (hi, lo) bf16 per (Cin, Cout) pair)."""
+def algorithmic_bytes(batch=64, frames=1001, taps=12):
+    """Input once + pooled output once + packed weights once, mean over the four launches (f32 activations; the Winograd
+    weights are 12 (F(2,3)) / 18 (F(4,3)) transformed taps x (hi, lo) bf16 per (Cin, Cout) pair)."""
     total, h, w, c = 0, frames // 2, 32, 128
     for _ in range(4):
-        total += batch * h * w * c * 4 + batch * (h // 2) * (w // 2) * c * 4 + c * c * 12 * 2 * 2
+        total += batch * h * w * c * 4 + batch * (h // 2) * (w // 2) * c * 4 + c * c * taps * 2 * 2
         h, w, c = h // 2, w // 2, c * 2
     return total // 4
 
@@ -62,7 +62,7 @@ for line in open(os.path.join(dst, f"{R}_kernel_stats.txt")):
 avg_us = total / calls
 hbm = (2 * fetch + write) * 1024   # FETCH_SIZE counts 32-byte requests in 64-byte units on gfx950 (MI355X_MICROARCH.md), KiB
 cycles = 1024 * gui / 8
-alg = algorithmic_bytes() if TIER == "wino1d" else 172000000
+alg = algorithmic_bytes(taps=18) if TIER == "wino43" else (algorithmic_bytes() if TIER == "wino1d" else 172000000)
 path = os.path.join(dst, f"{R}_traffic_{TIER}.json")
 t = {"kernel": INST, "launches_per_step": 4,
      "fetch_size_kib_per_launch": fetch, "write_size_kib_per_launch": write, "hbm_bytes_per_launch": int(hbm),

@@ -1,8 +1,8 @@
 # Development tool: the profile set committed under profiles/ each round (run on the GPU box from the repo root).
 set -x
 export TMPDIR=/tmp PYTHONPATH=$PWD
-R=${ROUND:-r03}
-T=${TIER:-wino1d}
+R=${ROUND:-r04}
+T=${TIER:-wino43}
 python bench.py > gpurun_out/${R}_bench_final.json 2> gpurun_out/${R}_bench_final.err
 cp gpurun_out/bench_details.json gpurun_out/${R}_bench_details.json
 rocprofv3 --kernel-trace --stats -d gpurun_out/p_head -- python bench.py --no-cpu-baseline > gpurun_out/${R}_prof_head.json 2>/dev/null
@@ -12,7 +12,7 @@ CMD="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-tiers --no-trai
 mkdir -p gpurun_out/${R}_pmc_${T}
 for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
   rocprofv3 --kernel-trace --pmc $c -d gpurun_out/p_$c -- $CMD > /dev/null 2>&1
-  for f in $(find gpurun_out/p_$c -name "*results.db"); do python profiles/pmc_summary.py $f conv3x3 logmel gru dec_ > gpurun_out/${R}_pmc_${T}/$c.txt; done
+  for f in $(find gpurun_out/p_$c -name "*results.db"); do python profiles/pmc_summary.py $f conv3x3 block1 logmel gru dec_ > gpurun_out/${R}_pmc_${T}/$c.txt; done
   rm -rf gpurun_out/p_$c
 done
 rocprofv3 --kernel-trace --stats -d gpurun_out/p_train -- python bench.py --mode train --steps 10 > /dev/null 2>&1
