@@ -90,8 +90,9 @@ W43_MIN_WORKGROUPS = int(os.environ.get("AUDIOCAPTION_W43_MIN_WG", "192"))
 
 def wino43_covers(W, cout):
     """Layers the F(4,3) kernel runs (one 512-register wave per SIMD, csrc/conv3x3_wino43.hip): the full-width forms of
-    conv blocks 2-5.  Block 1 (64 channels) and block 6 (2 mel columns, mean over mel) stay on the F(2,3) kernel."""
-    return W in (32, 16, 8, 4) and cout % 128 == 0
+    conv blocks 2-5 and the column-tile form of block 6 (2 mel columns).  Block 1 has its own kernel
+    (csrc/conv3x3_block1_w4.hip)."""
+    return W in (32, 16, 8, 4, 2) and cout % 128 == 0
 
 
 def _conv_wino43(x, w, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode=-1, need=None, splitk_buf=None,
@@ -99,7 +100,11 @@ def _conv_wino43(x, w, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode
     """The "wino43" tier's launcher: ``w`` is (F(2,3) pack, F(4,3) pack or None).  F(4,3) when the kernel covers the layer
     and the launch fills the chip (a workgroup owns a CU: single clips run the K-sliced F(2,3) form instead)."""
     w23, w43 = w if isinstance(w, tuple) else (w, None)
-    if w43 is not None and mode != 2 and Hp % 4 == 0 and K.wino43_workgroups(B, Hp, W, Cout) >= W43_MIN_WORKGROUPS:
+    # (batches of uneven lengths keep block 6 on F(2,3) - the caller passes it the F(2,3) pack only: its tiles are taller than a
+    # clip, nothing can be skipped there anyway, and the quad-wide input window of F(4,3) would cost every layer upstream
+    # four more valid rows per clip - ``rows_needed``)
+    if w43 is not None and (mode != 1 if W == 2 else mode != 2) and Hp % 4 == 0 \
+            and K.wino43_workgroups(B, Hp, W, Cout) >= W43_MIN_WORKGROUPS:
         return K.conv3x3_bn_relu_wino43(x, w43, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode, need=need,
                                         dropout=dropout)
     return _conv_wino1d(x, w23, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode, need=need, splitk_buf=splitk_buf,
@@ -274,7 +279,7 @@ class Cnn14Encoder(nn.Module):
         H = [T >> k for k in range(6)]
         if H[5] < 1:
             raise ValueError(f"clips of {n_samples} samples are shorter than one Cnn14 output frame")
-        hp6 = (H[5] + 2) & ~1  # >= H6 + 1 and even (a 2-row Winograd tile / pooling pair never straddles clips)
+        hp6 = (H[5] + 4) & ~3  # >= H6 + 1 and a multiple of 4 (a row quad of F(4,3) / a pooling pair never straddles clips)
         Hp = [hp6 << (5 - k) for k in range(6)]
         return T, H, Hp
 
@@ -296,7 +301,7 @@ class Cnn14Encoder(nn.Module):
             self._tables_key = mkey
 
     def encode(self, wav, dropout=None, specaug=None, train=False, min_frames=None, algo=None, overflow=None,
-               clip_frames=None, x0=None):
+               clip_frames=None, x0=None, block6_f23=False):
         """wav (B, L) on the ROCm device -> attn_emb (B, T // 32, 2048).
 
         ``dropout = (p, op_code, seed_dev_ptr)``: the train-mode forward of the frozen network, F.dropout(p) after
@@ -330,7 +335,7 @@ class Cnn14Encoder(nn.Module):
         if specaug is not None:
             K.specaug_(x0, specaug, pk["bn0"][1], B, Hp[0], T)
         return self.conv_stack(x0, B, H, Hp, pk, algo, dropout, overflow=overflow,
-                               clip_frames=clip_frames if algo in WINO else None)
+                               clip_frames=clip_frames if algo in WINO else None, block6_f23=block6_f23)
 
     def effective_algo(self, algo=None, train=False, min_frames=None):
         """The conv tier a call runs on: the fp16-activation tier is left for the train-mode forward and for batches
@@ -342,7 +347,8 @@ class Cnn14Encoder(nn.Module):
             return "bf16x3"
         return algo
 
-    def conv_stack(self, x0, B, H, Hp, pk, algo, dropout=None, blocks=None, overflow=None, clip_frames=None):
+    def conv_stack(self, x0, B, H, Hp, pk, algo, dropout=None, blocks=None, overflow=None, clip_frames=None,
+                   block6_f23=False):
         """The six conv blocks on a bn0-normalised log-mel x0 [B*Hp[0]][64] -> attn_emb (B, H[5], 2048).
         ``blocks``: a list that receives a float32 (B, C, H, W) copy of every pooled block output (tests)."""
         dev = x0.device
@@ -372,6 +378,8 @@ class Cnn14Encoder(nn.Module):
             cin, cout = CHANNELS[b], CHANNELS[b + 1]
             w1, s1, t1 = pk["convs"][2 * b]
             w2, s2, t2 = pk["convs"][2 * b + 1]
+            if b == 5 and block6_f23 and isinstance(w1, tuple):
+                w1, w2 = (w1[0], None), (w2[0], None)
             pool_out = pooled
             if mixed and b == 4:     # block 5 hands block 6 (split-bf16, f32 activations) an f32 pooled output
                 pool_out = self._buf("pooled32", B * Hp[5] * 2 * CHANNELS[5], dev, torch.float32)
@@ -435,8 +443,11 @@ class Cnn14Encoder(nn.Module):
         ragged = skip_fc and algo in WINO and os.environ.get("AUDIOCAPTION_SKIP_DEAD_ROWS", "1") != "0" \
             and int(feat_length.min()) < int(feat_length.max())
         frames = K.upload(feat_length, wav.device, torch.int32) if ragged else None
+        # a batch of uneven lengths keeps block 6 on the F(2,3) kernel whether or not rows are skipped (same kernels = same
+        # bits with AUDIOCAPTION_SKIP_DEAD_ROWS on and off; see _conv_wino43)
+        uneven = skip_fc and int(feat_length.min()) < int(feat_length.max())
         attn_emb = self.encode(wav, min_frames=min_frames, algo=algo, overflow=flag, clip_frames=frames,
-                               x0=input_dict.get("_logmel"))
+                               x0=input_dict.get("_logmel"), block6_f23=uneven)
         out = {"attn_emb": attn_emb, "attn_emb_len": feat_length}
         if flag is not None:
             # non-zero: an activation exceeded the fp16 range (65504) and this result must not be used -

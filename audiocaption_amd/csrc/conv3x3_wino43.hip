@@ -79,7 +79,7 @@ struct W4Params {
   Drop drop;
 };
 
-enum { MODE_FULL = 0, MODE_POOL = 1 };
+enum { MODE_FULL = 0, MODE_POOL = 1, MODE_MEANW = 2 };   // MEANW: mean over the two mel columns of block 6 (column tiles)
 
 // block -> (row block, channel tile); block b runs on XCD b % 8 (speed only).  1: an XCD streams one weight column slab
 // (NT % 8 == 0); 3: NT in {1, 2, 4, 8}: the channel tiles of a row block sit on 8 / NT ... XCDs each owning one slab;
@@ -108,14 +108,21 @@ __device__ __forceinline__ bool w4_block_map(const W4Params& p, int& m_tile, int
 
 template <int TC, int MW>
 struct W4Geom {
-  static_assert(TC == 32 || TC == 16 || TC == 8 || TC == 4, "full-width blocks of 32, 16, 8 or 4 mel columns");
+  static_assert(TC == 32 || TC == 16 || TC == 8 || TC == 4 || TC == 2, "full-width blocks of 32, 16, 8, 4 or 2 mel columns");
   static_assert(MW == 2 || MW == 3, "two or three MFMA tiles per wave");
-  static constexpr int QT = 32 / TC;          // quads of an MFMA tile: row i = (quad i / TC, column i % TC)
-  static constexpr int PQ = MW * QT;          // quads of a block
+  // TC = 2 (conv block 6): COLUMN tiles - tile m is column m of 32 quads, so the taps that read the zero padding beside the
+  // image (kx = 0 of column 0, kx = 2 of column 1: a third of the products) are skipped at compile time, and no halo
+  // column is staged
+  static constexpr bool COLT = TC == 2;
+  static_assert(!COLT || MW == 2, "column tiles: one tile per column");
+  static constexpr int QT = COLT ? 32 : 32 / TC;   // quads of an MFMA tile: row i = (quad i / TC, column i % TC); COLT: quad i
+  static constexpr int PQ = COLT ? 32 : MW * QT;   // quads of a block
+  static constexpr int LCOLS = COLT ? 2 : TC + 2;  // columns of a plane in LDS (with the two zero halo columns)
   // column pitch in 16-byte slots: the 16 lanes of a ds_read_b128 group ({0-3, 12-15, 20-27} ...) read column i % TC,
-  // quad i / TC: TC = 32 any odd pitch, 16: pitch % 4 == 2, 8 and 4: pitch % 8 == 4 put them in 16 different slots
-  static constexpr int COLP = TC == 32 ? (PQ | 1) : TC == 16 ? (PQ % 4 == 2 ? PQ : PQ + 2) : (PQ % 8 == 4 ? PQ : PQ + 4);
-  static constexpr int HALF = (((TC + 2) * COLP * 16 + 127) / 128) * 128 + 64;   // bytes of one k-half of a plane (= 64 mod 128:
+  // quad i / TC: TC = 32 any odd pitch, 16: pitch % 4 == 2, 8 and 4: pitch % 8 == 4 put them in 16 different slots; column
+  // tiles read 32 consecutive quads of one column: any pitch
+  static constexpr int COLP = COLT ? 32 : TC == 32 ? (PQ | 1) : TC == 16 ? (PQ % 4 == 2 ? PQ : PQ + 2) : (PQ % 8 == 4 ? PQ : PQ + 4);
+  static constexpr int HALF = ((LCOLS * COLP * 16 + 127) / 128) * 128 + 64;   // bytes of one k-half of a plane (= 64 mod 128:
   static constexpr int PLANE = 2 * HALF;      //   the 8-byte stores of channels 0-7 / 8-15 of four items hit different banks)
   static constexpr int VBUF = 12 * PLANE;     // 6 positions x (hi, lo)
   static constexpr int NITEM = PQ * TC * 4;   // staging items (quad, column, channel quad) of a step: 384 (MW 3) or 256
@@ -150,7 +157,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_w4_kernel(W4Params p) {
   {
     const int i = lane & 31;
 #pragma unroll
-    for (int m = 0; m < MW; ++m) pb[m] = (unsigned)(half * HALF + ((i % TC) * COLP + m * QT + i / TC) * 16);
+    for (int m = 0; m < MW; ++m)
+      pb[m] = G::COLT ? (unsigned)(half * HALF + (m * COLP + i) * 16)    // column m; tap kx reads column m + kx - 1
+                      : (unsigned)(half * HALF + ((i % TC) * COLP + m * QT + i / TC) * 16);
   }
 
   f32x16 acc[6][MW];
@@ -196,7 +205,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_w4_kernel(W4Params p) {
       auto item = [&](int it, unsigned& vb, unsigned& lofs) {
         const int cq = it & 3, rest = it >> 2, quad = rest % PQ, c = rest / PQ;
         vb = (unsigned)(((4 * quad - first) * p.W + c) * p.Cin * 4 + cq * 16);
-        lofs = (unsigned)((cq >> 1) * HALF + ((c + 1) * COLP + quad) * 16 + (cq & 1) * 8);
+        lofs = (unsigned)((cq >> 1) * HALF + ((c + (G::COLT ? 0 : 1)) * COLP + quad) * 16 + (cq & 1) * 8);
       };
       item(tid, vbA, lofsA);
       if (MW == 3) item(256 + (tid & 127), vbB, lofsB);
@@ -238,20 +247,24 @@ __global__ __launch_bounds__(256, 1) void conv3x3_w4_kernel(W4Params p) {
           else store_piece(buf, lofsB, pos, w4_transform(pos, z, preB[0], preB[1], preB[2], preB[3], preB[4]));
         }
       };
+      // column tiles: tap kx of tile (= column) m reads column m + kx - 1, which exists for (m, kx) in {(0,1), (0,2), (1,0), (1,1)}
+      auto tap_valid = [](int m, int kx) { return !G::COLT || (m + kx - 1 >= 0 && m + kx - 1 <= 1); };
       auto a_load = [&](const unsigned char* buf, int gi, bf16x8 (&a)[MW][2]) {
         if (W4_KO & 2) { if (gi) return; }
         const int kx = gi / 6, q = gi % 6;
-        const unsigned char* vh = buf + (2 * q) * PLANE + kx * COLP * 16;
+        const unsigned char* vh = buf + (2 * q) * PLANE;
+        const int koff = (G::COLT ? kx - 1 : kx) * COLP * 16;
 #pragma unroll
         for (int m = 0; m < MW; ++m) {
-          a[m][0] = *(const bf16x8*)(vh + pb[m]);
-          a[m][1] = *(const bf16x8*)(vh + PLANE + pb[m]);
+          if (!tap_valid(m, kx)) continue;
+          a[m][0] = *(const bf16x8*)(vh + ((int)pb[m] + koff));
+          a[m][1] = *(const bf16x8*)(vh + PLANE + ((int)pb[m] + koff));
         }
       };
 
       // ---- prologue: zero halo columns of both buffers, step 0 into buffer 0, rows of step 1 requested ----
       {
-        constexpr int NZ = 2 * 12 * 2 * 2 * COLP;   // 16-byte slots: buffers x planes x k-halves x 2 columns x COLP
+        constexpr int NZ = G::COLT ? 0 : 2 * 12 * 2 * 2 * COLP;   // 16-byte slots: buffers x planes x k-halves x 2 columns x COLP
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         for (int i = tid; i < NZ; i += 256) {
           const int slot = i % COLP, col = (i / COLP) & 1, hh = (i / (2 * COLP)) % 24, b = i / (48 * COLP);
@@ -311,19 +324,24 @@ __global__ __launch_bounds__(256, 1) void conv3x3_w4_kernel(W4Params p) {
           if (!(W4_KO & 32)) {
             // operand order (weights, pixels): D rows = channels, columns = pixels, so that a lane ends up with four
             // CONSECUTIVE channels of one pixel per register quad (16-byte stores in the epilogue)
+            const int kxg = gi / 6;
 #pragma unroll
             for (int m = 0; m < MW; ++m)
-              acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[gi % RING][0], af[gi % NA][m][1], acc[q][m], 0, 0, 0);
+              if (tap_valid(m, kxg))
+                acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[gi % RING][0], af[gi % NA][m][1], acc[q][m], 0, 0, 0);
 #pragma unroll
             for (int m = 0; m < MW; ++m)
-              acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[gi % RING][1], af[gi % NA][m][0], acc[q][m], 0, 0, 0);
+              if (tap_valid(m, kxg))
+                acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[gi % RING][1], af[gi % NA][m][0], acc[q][m], 0, 0, 0);
 #pragma unroll
             for (int m = 0; m < MW; ++m)
-              acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[gi % RING][0], af[gi % NA][m][0], acc[q][m], 0, 0, 0);
+              if (tap_valid(m, kxg))
+                acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[gi % RING][0], af[gi % NA][m][0], acc[q][m], 0, 0, 0);
           } else {
 #pragma unroll
             for (int m = 0; m < MW; ++m)
-              asm volatile("" :: "v"(af[gi % NA][m][0]), "v"(af[gi % NA][m][1]), "v"(wr[gi % RING][0]), "v"(wr[gi % RING][1]));
+              if (tap_valid(m, gi / 6))
+                asm volatile("" :: "v"(af[gi % NA][m][0]), "v"(af[gi % NA][m][1]), "v"(wr[gi % RING][0]), "v"(wr[gi % RING][1]));
           }
           if (MORE) {
             if (gi < NPIECE) commit_piece(nxt, gi);
@@ -350,7 +368,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_w4_kernel(W4Params p) {
   // 16-byte store per (tile, g, row).  The two columns of a pooling window sit in lanes l, l ^ 1. ----
   const int chw = n_tile * 128 + wave * 32 + 4 * half;
   const FastDiv4 by_hp(p.Hp), by_hp_out(MODE == MODE_POOL ? p.Hp_out : 1);
-  const int pi = lane & 31, col = pi % TC;
+  const int pi = lane & 31;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 sc4[4], sh4[4];
 #pragma unroll
@@ -358,9 +376,35 @@ __global__ __launch_bounds__(256, 1) void conv3x3_w4_kernel(W4Params p) {
     sc4[g] = all_pad ? zero4 : *(const f32x4*)(p.scale + chw + 8 * g);   // dead blocks store zeros
     sh4[g] = all_pad ? zero4 : *(const f32x4*)(p.shift + chw + 8 * g);
   }
+  if (MODE == MODE_MEANW) {
+    // conv block 6, second conv: mean over the two mel columns = the wave's two (column) tiles, same lane, same register;
+    // out (B, H, Cout) dense (cnn_encoder.py:443: torch.mean(x, dim=3))
+    static_assert(MODE != MODE_MEANW || G::COLT, "the mean over mel is the two-column form's epilogue");
+    const int qg = quad0 + pi, gr = 4 * qg;
+    const int bclip = gr / p.Hp, h = gr - bclip * p.Hp;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 mean[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        float ya[4], yb[4];
+        w4_outputs(acc[0][0][r], acc[1][0][r], acc[2][0][r], acc[3][0][r], acc[4][0][r], acc[5][0][r], sc4[g][e], sh4[g][e], ya);
+        w4_outputs(acc[0][1][r], acc[1][1][r], acc[2][1][r], acc[3][1][r], acc[4][1][r], acc[5][1][r], sc4[g][e], sh4[g][e], yb);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mean[j][e] = 0.5f * (ya[j] + yb[j]);
+      }
+      if (gr < p.rows_total) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (h + j < p.H && !(W4_KO & 64)) *(f32x4*)(p.out + ((size_t)bclip * p.H + h + j) * p.Cout + chw + 8 * g) = mean[j];
+      }
+    }
+  } else {
 #pragma unroll
   for (int m = 0; m < MW; ++m) {
-    const int qg = quad0 + m * QT + pi / TC;
+    const int col = G::COLT ? m : pi % TC;
+    const int qg = quad0 + (G::COLT ? pi : m * QT + pi / TC);
     const int gr = 4 * qg;
     const bool inside = gr < p.rows_total;
     f32x4 y[4][4];   // y[g][j][e]: channel quad g, output row j, channel chw + 8 g + e
@@ -409,6 +453,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_w4_kernel(W4Params p) {
         if (inside && !(W4_KO & 64)) *(f32x4*)(p.out + oi) = o;
       }
     }
+  }
   }
 #ifdef W4_CLK
   __builtin_amdgcn_s_waitcnt(0);
@@ -460,7 +505,7 @@ int launch_w4_mw(const W4Params& p, int mw, hipStream_t s) {
 
 // workgroups of a launch with MW tiles per wave
 static long w4_grid(int rows_total, int W, int Cout, int mw) {
-  const int pq = mw * (32 / W);
+  const int pq = W == 2 ? 32 : mw * (32 / W);
   return (long)((rows_total / 4 + pq - 1) / pq) * (Cout / 128);
 }
 
@@ -468,9 +513,10 @@ static int w4_dispatch(const float* in, const void* wfrag, const float* scale, c
                        int H, int W, int Cin, int Cout, int mode, int map_mode, int mw, const int* clip_frames, int need_mul,
                        int need_add, void* stream, Drop drop) {
   if (!in || !wfrag || !scale || !shift || !out) return AC_ERR_ARG;
-  if (B <= 0 || Hp <= H || (Hp & 3) || !(W == 32 || W == 16 || W == 8 || W == 4) || Cin % 16 || Cin < 32 || Cout % 128)
+  if (B <= 0 || Hp <= H || (Hp & 3) || !(W == 32 || W == 16 || W == 8 || W == 4 || W == 2) || Cin % 16 || Cin < 32 || Cout % 128)
     return AC_ERR_ARG;
-  if (mode != MODE_FULL && mode != MODE_POOL) return AC_ERR_ARG;
+  if (W == 2 ? (mode != MODE_FULL && mode != MODE_MEANW) : (mode != MODE_FULL && mode != MODE_POOL)) return AC_ERR_ARG;
+  if (mode == MODE_MEANW && drop.thresh != 0) return AC_ERR_ARG;   // dropout sits BEFORE the mean over mel: use mode 0
   if ((unsigned long long)B * Hp >= (1ull << 29)) return AC_ERR_ARG;          // row indices are ints (x 4 in the epilogue)
   if ((unsigned long long)(Cin / 16) * 18 * (Cout / 32) * 2048 >= (1ull << 31)) return AC_ERR_ARG;   // packed weights: one descriptor
   W4Params p;
@@ -500,6 +546,7 @@ static int w4_dispatch(const float* in, const void* wfrag, const float* scale, c
   if (W == TCV) return mode == MODE_FULL ? launch_w4_mw<MODE_FULL, TCV>(p, mw, s) : launch_w4_mw<MODE_POOL, TCV>(p, mw, s);
   W4_CASE(32) W4_CASE(16) W4_CASE(8) W4_CASE(4)
 #undef W4_CASE
+  if (W == 2) return mode == MODE_FULL ? launch_w4<MODE_FULL, 2, 2>(p, s) : launch_w4<MODE_MEANW, 2, 2>(p, s);
   return AC_ERR_ARG;
 }
 
@@ -530,6 +577,6 @@ extern "C" int ac_conv3x3_bn_relu_wino43_drop(const float* in, const void* wfrag
 }
 
 extern "C" long ac_conv3x3_wino43_workgroups(int B, int Hp, int W, int Cout) {
-  if (B <= 0 || Hp <= 0 || (Hp & 3) || !(W == 32 || W == 16 || W == 8 || W == 4) || Cout % 128) return 0;
+  if (B <= 0 || Hp <= 0 || (Hp & 3) || !(W == 32 || W == 16 || W == 8 || W == 4 || W == 2) || Cout % 128) return 0;
   return w4_grid(B * Hp, W, Cout, 2);
 }

@@ -216,8 +216,8 @@ def wino43_workgroups(B, Hp, W, Cout):
 def conv3x3_bn_relu_wino43(x, wfrag, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode=-1, need=None, dropout=None,
                            tiles_per_wave=0):
     """F(4,3) Winograd along time on split-bf16 operands, one wave per SIMD (csrc/conv3x3_wino43.hip); ``wfrag`` from
-    ``pack_conv_weight_wino43_frag``.  Covers W in (32, 16, 8, 4), Cout % 128 == 0, Hp % 4 == 0, modes 0 / 1; ``need`` and
-    ``dropout`` as for ``conv3x3_bn_relu_wino1d``."""
+    ``pack_conv_weight_wino43_frag``.  Covers W in (32, 16, 8, 4) with modes 0 / 1 and W = 2 with modes 0 / 2 (mean over
+    mel), Cout % 128 == 0, Hp % 4 == 0; ``need`` and ``dropout`` as for ``conv3x3_bn_relu_wino1d``."""
     lib = _lib.load()
     hook = CONV_LAUNCH_HOOK
     if hook is not None:

@@ -431,7 +431,7 @@ def test_ragged_batch_skips_dead_rows_bit_identically(hip_model, monkeypatch):
     convolve the rows a clip's own length cannot bring to one of its output frames (cnn_encoder.rows_needed).  What the
     model returns - the GRU's attn_emb / fc_emb, logits, ids - must be BIT-identical to the run that convolves all the
     padding like the reference (collate_func.py:29-32, cnn_encoder.py:446-450), and each clip must equal the clip run
-    alone under the same padding (1e-5: the GEMM paths are chosen by row count)."""
+    alone under the same padding (5e-5)."""
     from audiocaption_amd import procedural as P
     secs = [10.0, 3.1, 7.4, 5.0, 9.2, 4.3]
     wav_len = [int(s_ * 32000) for s_ in secs]
@@ -455,7 +455,9 @@ def test_ragged_batch_skips_dead_rows_bit_identically(hip_model, monkeypatch):
         one = hip_model(dict(inp, wav=wav[i:i + 1].contiguous(), wav_len=[n]))   # padded like in the batch (the mel of the
         #                                                                          last frames sees the zeros, not a reflection)
         t = int(one["attn_emb_len"][0])
-        assert _maxdiff(f"clip {i} alone: attn_emb", one["attn_emb"][0, :t], skip["attn_emb"][i, :t]) < 1e-5
+        # 5e-5: the clip alone is an even-length batch (block 6 on F(4,3)), the ragged batch keeps block 6 on F(2,3) - two
+        # f32-grade forms of the same convolution (2^-16 operand error each); the GEMM paths are chosen by row count
+        assert _maxdiff(f"clip {i} alone: attn_emb", one["attn_emb"][0, :t], skip["attn_emb"][i, :t]) < 5e-5
         assert torch.equal(one["seq"][0], skip["seq"][i])
 
 

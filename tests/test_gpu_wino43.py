@@ -68,6 +68,30 @@ def test_conv3x3_wino43_vs_conv2d(K, B, H, W, Cin, Cout, mode, map_mode, tiles):
     assert _report(f"conv[wino43 x{tiles}] {B}x{H}x{W} {Cin}->{Cout} mode{mode}", out.reshape(want.shape), want) < tol
 
 
+@pytest.mark.parametrize("B,H,Cin,Cout,mode", [(5, 3, 1024, 2048, 0), (5, 3, 2048, 2048, 2), (1, 31, 64, 128, 2), (3, 31, 512, 256, 0),
+                                               (37, 31, 256, 256, 2), (2, 93, 128, 128, 2)])
+def test_conv3x3_wino43_two_column_form(K, B, H, Cin, Cout, mode):
+    """Conv block 6 (W = 2): column tiles, the taps on the zero padding beside the image skipped; mode 0 and the mean over the
+    two mel columns (cnn_encoder.py:443) against F.conv2d on the CPU."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(B * 100 + H + Cin)
+    x = torch.randn(B, Cin, H, 2, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * math.sqrt(2.0 / (9 * Cin))
+    sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    y = F.relu(F.conv2d(x, w, padding=1) * sc[None, :, None, None] + sh[None, :, None, None])
+    Hp = _hp4(H)
+    if mode == 2:
+        want = y.mean(dim=3).transpose(1, 2).contiguous()
+        out = torch.full((B, H, Cout), 7.0).cuda()
+    else:
+        want = _to_rows(y, Hp)
+        out = torch.full((B * Hp, 2, Cout), 7.0).cuda()
+    K.conv3x3_bn_relu_wino43(_to_rows(x, Hp).cuda(), K.pack_conv_weight_wino43_frag(w.cuda()), sc.cuda(), sh.cuda(), out, B, Hp, H,
+                             2, Cin, Cout, mode)
+    tol = 1e-3 * max(1.0, math.sqrt(9 * Cin / 576))
+    assert _report(f"conv[wino43, W = 2] {B}x{H} {Cin}->{Cout} mode{mode}", out.reshape(want.shape), want) < tol
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout,mode", [(16, 250, 16, 128, 256, 0), (16, 250, 16, 256, 256, 1), (34, 125, 8, 256, 512, 1),
                                                   (9, 500, 32, 64, 128, 0), (40, 62, 4, 512, 1024, 1)])
 def test_conv3x3_wino43_many_workgroups(K, B, H, W, Cin, Cout, mode):
@@ -165,11 +189,11 @@ def test_conv3x3_wino43_rejects_what_it_does_not_cover(K):
     wp = torch.zeros(4, 18, 4, 2, 64, 8, dtype=torch.bfloat16).cuda()
     sc = torch.ones(128).cuda()
     with pytest.raises(HipLibraryError):
-        K.conv3x3_bn_relu_wino43(x, wp, sc, sc, out, 2, 8, 5, 2, 64, 128, 0)      # W = 2: the F(2,3) kernel's layer
+        K.conv3x3_bn_relu_wino43(x, wp, sc, sc, out, 2, 8, 5, 2, 64, 128, 1)      # W = 2 is never pooled
     x = torch.zeros(2 * 6, 4, 64).cuda()
     with pytest.raises(HipLibraryError):
         K.conv3x3_bn_relu_wino43(x, wp, sc, sc, out, 2, 6, 5, 4, 64, 128, 0)      # Hp % 4 != 0
-    assert K.wino43_workgroups(64, 256, 16, 256) == (64 * 64 + 3) // 4 * 2 and K.wino43_workgroups(1, 32, 2, 2048) == 0
+    assert K.wino43_workgroups(64, 256, 16, 256) == (64 * 64 + 3) // 4 * 2 and K.wino43_workgroups(64, 32, 2, 2048) == 16 * 16
 
 
 # ---- conv block 1 in one kernel (csrc/conv3x3_block1_w4.hip) ----------------------------------------------------------

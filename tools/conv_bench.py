@@ -65,7 +65,7 @@ def main():
                 wp = K.pack_conv_weight_wino1d_frag(w)
                 fn = lambda: K.conv3x3_bn_relu_wino1d(x, wp, sc, sh, out, B, Hp, H, W, Cin, Cout, mode, args.map_mode)
             elif algo.startswith("wino43"):
-                if W not in (32, 16, 8, 4) or Cout % 128 or mode == 2:
+                if W not in (32, 16, 8, 4, 2) or Cout % 128 or (mode == 2) != (W == 2 and name == "b6c2"):
                     continue
                 wp = K.pack_conv_weight_wino43_frag(w)
                 tiles = int(algo[7:]) if len(algo) > 6 else 0          # "wino43", "wino43x2", "wino43x3"
