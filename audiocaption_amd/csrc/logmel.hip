@@ -76,13 +76,14 @@ __device__ __forceinline__ void dft<8>(float2 (&u)[8]) {
 
 // One Stockham pass of radix R over an M-point sequence; Ns = product of the radices already done.
 // Butterfly j (0 <= j < M/R) reads in[j + r*M/R], applies the twiddle exp(-2 pi i r k/(Ns R)) with
-// k = j mod Ns, and writes X[r] to out[(j - k) * R + k + r * Ns].
-template <int M, int R, int Ns, int N>
-__device__ __forceinline__ void stockham_store(float2 (&u)[R], float2* out, const float2* tw, int j) {
+// k = j mod Ns, and writes X[r] to out[(j - k) * R + k + r * Ns].  The R - 1 twiddles of a lane are the same for every
+// frame (j = lane): they live in registers (tw[r - 1]).
+template <int M, int R, int Ns>
+__device__ __forceinline__ void stockham_store(float2 (&u)[R], float2* out, const float2 (&tw)[R - 1], int j) {
   const int k = j % Ns;
   if (Ns > 1) {
 #pragma unroll
-    for (int r = 1; r < R; ++r) u[r] = cmul(u[r], tw[(r * k * (M / (Ns * R))) * (N / M)]);
+    for (int r = 1; r < R; ++r) u[r] = cmul(u[r], tw[r - 1]);
   }
   dft<R>(u);
   const int j0 = (j - k) * R + k;
@@ -90,28 +91,73 @@ __device__ __forceinline__ void stockham_store(float2 (&u)[R], float2* out, cons
   for (int r = 0; r < R; ++r) out[j0 + r * Ns] = u[r];
 }
 
-template <int M, int R, int Ns, int N>
-__device__ __forceinline__ void stockham_pass(const float2* in, float2* out, const float2* tw, int lane) {
+template <int M, int R, int Ns>
+__device__ __forceinline__ void stockham_pass(const float2* in, float2* out, const float2 (&tw)[R - 1], int lane) {
   if (lane < M / R) {
     float2 u[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) u[r] = in[lane + r * (M / R)];
-    stockham_store<M, R, Ns, N>(u, out, tw, lane);
+    stockham_store<M, R, Ns>(u, out, tw, lane);
   }
 }
+
+constexpr int MEL_CSR = 2048;   // non-zero filterbank weights of all 64 filters (slaney 50-14000 Hz at 1024: 1055; htk at 512: 546)
 
 template <int N>
 __global__ __launch_bounds__(256, 4) void logmel_kernel(LogmelParams p) {
   constexpr int M = N / 2;
   constexpr int R0 = (N == 1024) ? 8 : 4;  // first radix; the remaining two passes are radix 8
   constexpr int WAVES = 4;
-  __shared__ float2 s_tw[N];
+  constexpr int NU = M / 64 + 1;           // bins a lane unpacks: lane + 64 i, i < NU (the last one only for lane 0)
+  __shared__ float s_w[MEL_CSR];           // filterbank weights, filter by filter (lane l: s_w[woff .. woff + hi - lo])
   __shared__ float2 s_buf[WAVES][2][M];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  for (int i = tid; i < N; i += 256) s_tw[i] = p.twiddle[i];
+
+  // ---- per-lane constants, the same for every frame: window samples, twiddles of the three passes and of the unpacking,
+  // this lane's filter (support and weights).  Nothing below the frame loop reads a table from global memory. ----
+  float win[2 * R0];
+#pragma unroll
+  for (int r = 0; r < R0; ++r) {
+    const int n = 2 * (lane + r * (M / R0));
+    win[2 * r] = p.window[n];
+    win[2 * r + 1] = p.window[n + 1];
+  }
+  float2 tw1[7], tw2[7], twu[NU];
+  {
+    const int k1 = lane % R0, k2 = lane % (R0 * 8);
+#pragma unroll
+    for (int r = 1; r < 8; ++r) {
+      tw1[r - 1] = p.twiddle[(r * k1 * (M / (R0 * 8))) * (N / M)];
+      tw2[r - 1] = p.twiddle[(r * k2 * (M / (R0 * 8 * 8))) * (N / M)];
+    }
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      const int k = lane + 64 * i;
+      twu[i] = k < M ? p.twiddle[k] : make_float2(-1.f, 0.f);
+    }
+  }
+  const float2 tw0[R0 - 1] = {};   // first pass: Ns = 1, no twiddles
+  const int mlo = p.mel_lo[lane], mhi = p.mel_hi[lane];
+  int woff = 0;
+  {
+    // exclusive prefix sum of the support lengths over the 64 lanes (filters)
+    const int cnt = mhi >= mlo ? mhi - mlo + 1 : 0;
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int up = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += up;
+    }
+    woff = incl - cnt;
+    const int total_w = __shfl(incl, 63, 64);
+    if (wave == 0 && total_w <= MEL_CSR)
+      for (int k = mlo; k <= mhi; ++k) s_w[woff + k - mlo] = p.melfb[k * 64 + lane];
+    if (total_w > MEL_CSR) woff = -1;   // a filterbank denser than the table: weights straight from memory
+  }
+  const float bn_s = p.scale ? p.scale[lane] : 1.f, bn_t = p.scale ? p.shift[lane] : 0.f;
   __syncthreads();
 
   float2* bufA = s_buf[wave][0];
@@ -122,54 +168,77 @@ __global__ __launch_bounds__(256, 4) void logmel_kernel(LogmelParams p) {
 #define WAVE_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
   const long total = (long)p.B * p.rows_per_clip;
 
-  for (long slot0 = (long)blockIdx.x * WAVES; slot0 < total; slot0 += (long)gridDim.x * WAVES) {
-    const long slot = slot0 + wave;
-    const bool in_range = slot < total;
-    const int b = in_range ? (int)(slot / p.rows_per_clip) : 0;
-    const int t = in_range ? (int)(slot % p.rows_per_clip) : 0;
-    const bool active = in_range && t < p.T;
-
-    if (active) {
-      // ---- pass 0 straight from HBM/L2: windowed samples, reflect padding at both ends ----
-      const float* x = p.wav + (long)b * p.L;
-      const int g0 = t * p.hop - N / 2;
-      float2 u[R0];
+  // the samples of a frame (reflect padding at both ends), two per radix leg; requested one frame AHEAD of their use
+  auto frame_of = [&](long slot, int& b, int& t, bool& in_range) {
+    in_range = slot < total;
+    b = in_range ? (int)(slot / p.rows_per_clip) : 0;
+    t = in_range ? (int)(slot % p.rows_per_clip) : 0;
+    return in_range && t < p.T;
+  };
+  auto samples = [&](int b, int t, float2 (&u)[R0]) {
+    const float* x = p.wav + (long)b * p.L;
+    const int g0 = t * p.hop - N / 2;
 #pragma unroll
-      for (int r = 0; r < R0; ++r) {
-        const int n = 2 * (lane + r * (M / R0));
-        int g = g0 + n, g1 = g0 + n + 1;
-        g = g < 0 ? -g : (g >= p.L ? 2 * (p.L - 1) - g : g);
-        g1 = g1 < 0 ? -g1 : (g1 >= p.L ? 2 * (p.L - 1) - g1 : g1);
-        u[r] = make_float2(x[g] * p.window[n], x[g1] * p.window[n + 1]);
-      }
-      stockham_store<M, R0, 1, N>(u, bufA, s_tw, lane);
+    for (int r = 0; r < R0; ++r) {
+      const int n = 2 * (lane + r * (M / R0));
+      int g = g0 + n, g1 = g0 + n + 1;
+      g = g < 0 ? -g : (g >= p.L ? 2 * (p.L - 1) - g : g);
+      g1 = g1 < 0 ? -g1 : (g1 >= p.L ? 2 * (p.L - 1) - g1 : g1);
+      u[r] = make_float2(x[g], x[g1]);
     }
+  };
+  float2 nxt[R0];
+  int nb, nt;
+  bool n_in;
+  const long step = (long)gridDim.x * WAVES;
+  long slot = (long)blockIdx.x * WAVES + wave;
+  bool n_act = frame_of(slot, nb, nt, n_in);
+  if (n_act) samples(nb, nt, nxt);
+
+  for (long slot0 = (long)blockIdx.x * WAVES; slot0 < total; slot0 += step) {
+    const int b = nb, t = nt;
+    const bool in_range = n_in, active = n_act;
+    float2 u[R0];
+#pragma unroll
+    for (int r = 0; r < R0; ++r) u[r] = make_float2(nxt[r].x * win[2 * r], nxt[r].y * win[2 * r + 1]);
+    slot += step;
+    n_act = frame_of(slot, nb, nt, n_in);
+    if (n_act) samples(nb, nt, nxt);   // in flight under this frame's transform
+
+    if (active) stockham_store<M, R0, 1>(u, bufA, tw0, lane);   // pass 0 on the windowed samples
     WAVE_LDS_SYNC();
-    if (active) stockham_pass<M, 8, R0, N>(bufA, bufB, s_tw, lane);
+    if (active) stockham_pass<M, 8, R0>(bufA, bufB, tw1, lane);
     WAVE_LDS_SYNC();
-    if (active) stockham_pass<M, 8, R0 * 8, N>(bufB, bufA, s_tw, lane);
+    if (active) stockham_pass<M, 8, R0 * 8>(bufB, bufA, tw2, lane);
     WAVE_LDS_SYNC();
     if (active) {
       // ---- unpack the packed-real transform to bins 0..M and take the power ----
-      for (int k = lane; k <= M; k += 64) {
-        const float2 zk = bufA[k & (M - 1)];
-        const float2 zc = bufA[(M - k) & (M - 1)];
-        const float2 e = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
-        const float2 o = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));
-        const float2 w = (k < M) ? s_tw[k] : make_float2(-1.f, 0.f);
-        const float2 xk = cadd(e, cmul(w, o));
-        pw[k] = xk.x * xk.x + xk.y * xk.y;
+#pragma unroll
+      for (int i = 0; i < NU; ++i) {
+        const int k = lane + 64 * i;
+        if (k <= M) {
+          const float2 zk = bufA[k & (M - 1)];
+          const float2 zc = bufA[(M - k) & (M - 1)];
+          const float2 e = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
+          const float2 o = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));
+          const float2 xk = cadd(e, cmul(twu[i], o));
+          pw[k] = xk.x * xk.x + xk.y * xk.y;
+        }
       }
     }
     WAVE_LDS_SYNC();
     if (in_range) {
       float v = 0.f;
       if (active) {
-        const int lo = p.mel_lo[lane], hi = p.mel_hi[lane];
         float s = 0.f;
-        for (int k = lo; k <= hi; ++k) s = fmaf(pw[k], p.melfb[k * 64 + lane], s);
+        if (woff >= 0) {
+          const float* wl = s_w + woff - mlo;
+          for (int k = mlo; k <= mhi; ++k) s = fmaf(pw[k], wl[k], s);
+        } else {
+          for (int k = mlo; k <= mhi; ++k) s = fmaf(pw[k], p.melfb[k * 64 + lane], s);
+        }
         v = 10.0f * log10f(fmaxf(s, 1e-10f));
-        if (p.scale) v = fmaf(v, p.scale[lane], p.shift[lane]);
+        if (p.scale) v = fmaf(v, bn_s, bn_t);
       }
       p.out[b * p.stride_b + t * p.stride_t + lane * p.stride_m] = v;
     }
