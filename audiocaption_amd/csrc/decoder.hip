@@ -486,7 +486,7 @@ template <int PRO>
 __global__ __launch_bounds__(64 * DEC_WAVES) void dec_gemm_kernel(DecGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];
   float* sX = dsm;   // [16][KC + 4] A tile: the fused producer's rows, or a coalesced copy of X
-  float* red = dsm + DEC_T * (DEC_KC + 4);  // [DEC_WAVES][16*17] split-K partials
+  float* red = dsm + DEC_T * ((p.K < DEC_KC ? p.K : DEC_KC) + 4);  // [DEC_WAVES][16*17] split-K partials
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kq = lane >> 4;           // which 4 of the 16 k of a group this lane feeds
   const int m0 = blockIdx.y * DEC_T;
@@ -632,9 +632,9 @@ template <int PRO>
 int launch_dec_gemm(const DecGemmParams& p, hipStream_t s) {
   if (p.K % 64 || (PRO != PRO_PLAIN && p.K > DEC_MAX_D) || (p.K > DEC_KC && p.K % DEC_KC)) return AC_ERR_ARG;
   const int KC = p.K < DEC_KC ? p.K : DEC_KC;
-  (void)KC;
   if (p.ntb < 1 || (p.ntb > 1 && p.K > DEC_KC)) return AC_ERR_ARG;
-  const size_t lds = ((size_t)DEC_T * (DEC_KC + 4) + (size_t)DEC_WAVES * DEC_T * 17) * sizeof(float);
+  // the A tile is [16][KC + 4]: sized by the launch's K chunk, so that the K = 256 projections fit 7 workgroups to a CU
+  const size_t lds = ((size_t)DEC_T * (KC + 4) + (size_t)DEC_WAVES * DEC_T * 17) * sizeof(float);
   const int ntiles = (p.N + DEC_T - 1) / DEC_T;
   dim3 grid((ntiles + p.ntb - 1) / p.ntb, (p.M + DEC_T - 1) / DEC_T);
   hipLaunchKernelGGL((dec_gemm_kernel<PRO>), grid, dim3(64 * DEC_WAVES), lds, s, p);
@@ -1101,7 +1101,8 @@ int decoder_step(const ac_trm_weights* w, const float* memkv, const int* mem_len
   float* xb = ws.x2;
   DecGemmParams g;
   g.tok = tok; g.tok_stride = tok_stride; g.t = t; g.emb = w->emb; g.pe = w->pe; g.emb_scale = sqrtf((float)d);
-  g.M = R; g.ntb = 1;
+  static const int dev_ntb = getenv("AUDIOCAPTION_DEC_NTB") ? atoi(getenv("AUDIOCAPTION_DEC_NTB")) : 1;   // development
+  g.M = R; g.ntb = dev_ntb;
   // pending join carried into the next projection: x_next = LayerNorm(jx + jy) * jw + jb
   const float *jx = nullptr, *jy = nullptr, *jw = nullptr, *jb = nullptr;
   // the reference's decoder shape (d_model 256 = 4 heads of 64) takes the fused per-row sub-layer kernel: 5 launches per
@@ -1166,7 +1167,10 @@ int decoder_step(const ac_trm_weights* w, const float* memkv, const int* mem_len
       AC_TRY(launch_dec_gemm<PRO_PLAIN>(g, s));
       g.X = ws.ff; g.ldx = w->dim_ff; g.Wp = pk + PL[l].l2; g.bias = L.l2_b; g.Y = ws.tmp; g.ldy = d;
       g.N = d; g.K = w->dim_ff; g.relu = 0; g.xout = nullptr;
+      const int ntb_keep = g.ntb;
+      if (g.K > DEC_KC) g.ntb = 1;
       AC_TRY(launch_dec_gemm<PRO_PLAIN>(g, s));
+      g.ntb = ntb_keep;
       jx = xa; jy = ws.tmp; jw = L.n3_w; jb = L.n3_b;
       float* tsw = xa; xa = xb; xb = tsw;
       continue;
@@ -1214,7 +1218,8 @@ int classifier_step(const ac_trm_weights* w, const StepOut& fin, int R, float* x
   DecGemmParams g;
   g.tok = nullptr; g.tok_stride = 0; g.t = 0; g.emb = nullptr; g.pe = nullptr; g.emb_scale = 0.f;
   g.M = R; g.N = w->vocab; g.K = w->d_model; g.relu = 0;
-  g.ntb = 4;  // 1092 column tiles: four per block keep the grid near one resident wave of blocks
+  static const int dev_cls_ntb = getenv("AUDIOCAPTION_DEC_CLS_NTB") ? atoi(getenv("AUDIOCAPTION_DEC_CLS_NTB")) : 4;   // development
+  g.ntb = dev_cls_ntb;  // 1092 column tiles: four per block keep the grid near one resident wave of blocks
   g.X = fin.x; g.ldx = w->d_model; g.Y2 = fin.y; g.ldy2 = w->d_model; g.ln_w = fin.ln_w; g.ln_b = fin.ln_b;
   size_t cls_off;
   pack_layout(w, nullptr, &cls_off);

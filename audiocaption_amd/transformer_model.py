@@ -154,11 +154,46 @@ def _device_flags(enc):
     return torch.cat([a.view(1).to(torch.int32) if a is not None else z, b.view(1).to(torch.int32) if b is not None else z])
 
 
+def _masked_stream(dev, first_cu, n_cus):
+    """A HIP stream restricted to CU-mask bits first_cu .. first_cu + n_cus - 1 (``ac_stream_create_cu_mask``), wrapped for
+    torch.  The stream lives as long as the process (a handful per model; never destroyed under work in flight)."""
+    import ctypes
+    from . import _lib
+    out = ctypes.c_void_p()
+    with torch.cuda.device(dev):
+        check(_lib.load().ac_stream_create_cu_mask(int(first_cu), int(n_cus), ctypes.byref(out)), "ac_stream_create_cu_mask")
+    return torch.cuda.ExternalStream(out.value, device=dev)
+
+
+def _cu_split():
+    """AUDIOCAPTION_DECODE_CUS="n" or "n,exclusive": the greedy decode chains of the throughput mode run on a stream
+    restricted to the first n CU-mask bits; with ",exclusive" the encoder stream is restricted to the others.  0 = off."""
+    v = os.environ.get("AUDIOCAPTION_DECODE_CUS", "0").split(",")
+    return int(v[0] or 0), len(v) > 1 and v[1].strip().lower().startswith("ex")
+
+
+def decode_group():
+    """Submissions ``forward_async`` decodes as ONE greedy chain at most (AUDIOCAPTION_DECODE_GROUP, default 4).  Beside a
+    running encoder every launch of a chain waits for compute units the conv workgroups give back, so a chain advances at a
+    quarter of its stand-alone speed and costs the encoder stream CU time per LAUNCH, not per row: one chain per 2 / 3 / 4 / 5
+    batches of 64 clips = 13.2 / 13.9 / 14.3 / 14.2 k clips/s over 40 steps (round 4, wino43 tier)."""
+    return max(1, int(os.environ.get("AUDIOCAPTION_DECODE_GROUP", "4")))
+
+
 def _make_streams(dev):
-    """(encoder stream, decode stream) of the throughput mode.  AUDIOCAPTION_STREAM_PRIORITIES="enc,dec" sets their HIP
-    priorities (lower = more urgent; default 0,0)."""
+    """(encoder stream, decode stream, chain stream) of the throughput mode.  AUDIOCAPTION_STREAM_PRIORITIES="enc,dec" sets
+    their HIP priorities (lower = more urgent; default 0,0).  The chain stream (greedy decode chains) is the decode stream
+    unless AUDIOCAPTION_DECODE_CUS restricts it to a few compute units (see ``_cu_split``)."""
     pe, pd = (int(v) for v in os.environ.get("AUDIOCAPTION_STREAM_PRIORITIES", "0,0").split(","))
-    return torch.cuda.Stream(dev, priority=pe), torch.cuda.Stream(dev, priority=pd)
+    n_dec, exclusive = _cu_split()
+    enc_s, dec_s = torch.cuda.Stream(dev, priority=pe), torch.cuda.Stream(dev, priority=pd)
+    chain_s = dec_s
+    if n_dec > 0:
+        total = torch.cuda.get_device_properties(dev).multi_processor_count
+        chain_s = _masked_stream(dev, 0, n_dec)
+        if exclusive:
+            enc_s = _masked_stream(dev, n_dec, total - n_dec)
+    return enc_s, dec_s, chain_s
 
 
 class PendingCaption:
@@ -168,11 +203,12 @@ class PendingCaption:
     def __init__(self, model=None):
         self._model = model
         self._done = self._seq = self._lp = self._out = self._release = self._result = None
-        self._flag = self._input = None
+        self._flag = self._input = self._cnt = None
 
-    def _fill(self, done_event, host_seq, host_logprob, output, release, host_flag=None):
+    def _fill(self, done_event, host_seq, host_logprob, output, release, host_flag=None, host_cnt=None):
         self._done, self._seq, self._lp, self._out, self._release = done_event, host_seq, host_logprob, output, release
         self._flag = host_flag
+        self._cnt = host_cnt   # shared chain: this batch's unfinished counts, to blank the steps it would not have run
 
     def result(self):
         if getattr(self, "_lazy", None) is not None:   # beam search: the host-driven loop runs now, on the decode stream
@@ -185,6 +221,12 @@ class PendingCaption:
         out = dict(self._out)
         out["seq"] = self._seq.clone()
         out["sampled_logprob"] = self._lp.clone()
+        if getattr(self, "_cnt", None) is not None:
+            # A chain shared with other batches runs until ALL of them have finished; the reference stops a batch when its own
+            # rows have (base.py:167) and leaves the later columns at their initial 0: step t ran iff rows were unfinished after t - 1
+            ran = torch.ones(self._cnt.shape[0], dtype=torch.bool)
+            ran[1:] = self._cnt[:-1] > 0
+            out["sampled_logprob"][:, ~ran] = 0
         flags = self._flag.clone() if self._flag is not None else None
         if self._release is not None:  # hand the pinned staging buffers back to the pool
             self._release()
@@ -194,7 +236,7 @@ class PendingCaption:
             if redo is not None:
                 out = redo
         self._result = out
-        self._seq = self._lp = None
+        self._seq = self._lp = self._cnt = None
         return dict(out)
 
 
@@ -213,7 +255,7 @@ class TransformerModel(CaptionModel):
         the decode of batch i fills the gaps of the matrix-bound encoder of batch i+1.  Results are identical
         to ``model(input_dict)``; only the schedule differs.  Returns a ``PendingCaption``.
 
-        ``pair`` (default: AUDIOCAPTION_PAIR_DECODE = "auto"): up to AUDIOCAPTION_DECODE_GROUP (2) consecutive submissions of
+        ``pair`` (default: AUDIOCAPTION_PAIR_DECODE = "auto"): up to AUDIOCAPTION_DECODE_GROUP (4) consecutive submissions of
         the same shape can be decoded as ONE chain (rows are independent: same tokens, same logits; the chain is latency-bound, so 128 rows cost what 64
         do).  Beside a running encoder a chain advances at a quarter of its stand-alone speed (its ~200 dependent launches
         each wait for workgroup slots: 8.5 ms instead of 1.9 ms per batch against an encoder of 6.3 ms,
@@ -235,7 +277,7 @@ class TransformerModel(CaptionModel):
         dev = input_dict["wav"].device
         if self._streams is None or self._streams[0].device != dev:
             self._streams = _make_streams(dev)
-        enc_s, dec_s = self._streams
+        enc_s, dec_s, chain_s = self._streams
         cur = torch.cuda.current_stream(dev)
         enc_s.wait_stream(cur)  # inputs produced on the caller's stream
         # A composite encoder (CrnnEncoder) runs in two halves: the convolutions on the encoder stream, the GRU (six launches of
@@ -270,7 +312,7 @@ class TransformerModel(CaptionModel):
             enc_done.record(enc_s)
         # "auto" pairing asks whether the decode stream is idle: asked BEFORE this batch's own GRU is queued on it (afterwards
         # the stream is never idle, and "auto" would hold every lone submission until result())
-        dec_was_idle = dec_s.query()
+        dec_was_idle = chain_s.query() and dec_s.query()
         if split_enc:
             with torch.cuda.stream(dec_s):
                 dec_s.wait_event(enc_done)
@@ -283,10 +325,8 @@ class TransformerModel(CaptionModel):
         max_length = int(input_dict.get("max_length", self.max_length))
         item = (PendingCaption(self), enc, enc_done, max_length)
         item[0]._input = submitted
-        # AUDIOCAPTION_DECODE_GROUP (default 2): submissions per chain at most (one chain per 1 / 2 / 3 / 4 batches of 64
-        # clips: 6.39 / 6.21 / 6.05 / 6.04 ms per step over 24 steps, 6.37 / 6.08 / 6.03 / 5.91 over 60; the default bench run
-        # of 20 steps measures 6.15 with 2 and 6.19 with 3 - its last chains run after the last encoder)
-        gmax = max(1, int(os.environ.get("AUDIOCAPTION_DECODE_GROUP", "2"))) if pair != "0" else 1
+        # submissions per chain at most: see decode_group()
+        gmax = decode_group() if pair != "0" else 1
         held = self._held or []
         if held:
             h = held[0]
@@ -311,7 +351,7 @@ class TransformerModel(CaptionModel):
         dev = input_dict["wav"].device
         if self._streams is None or self._streams[0].device != dev:
             self._streams = _make_streams(dev)
-        enc_s, dec_s = self._streams
+        enc_s, dec_s = self._streams[:2]
         enc_s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(enc_s):
             enc = self.encoder(input_dict)
@@ -364,7 +404,7 @@ class TransformerModel(CaptionModel):
         for g in group:
             g._lazy = None
         self._lazy_queue = [r for r in refs if r() is not None and r()._lazy is not None]
-        enc_s, dec_s = self._streams
+        enc_s, dec_s = self._streams[:2]
         if len(items) > 1 and not merge:
             return self._run_concurrent(group, items)
         with torch.cuda.stream(dec_s):
@@ -436,7 +476,7 @@ class TransformerModel(CaptionModel):
 
     def _decode_group(self, items):
         """One greedy chain over the rows of all ``items`` (pending, enc, enc_done, max_length) on the decode stream."""
-        enc_s, dec_s = self._streams
+        enc_s, _, dec_s = self._streams   # the chain stream (the decode stream unless AUDIOCAPTION_DECODE_CUS restricts it)
         max_length = items[0][3]
         with torch.cuda.stream(dec_s):
             for _, enc, ev, _ in items:
@@ -462,8 +502,9 @@ class TransformerModel(CaptionModel):
                 if not pool:
                     pool.append((torch.empty(B, max_length, dtype=torch.int64).pin_memory(),
                                  torch.empty(B, max_length, dtype=torch.float32).pin_memory(),
-                                 torch.zeros(2, dtype=torch.int32).pin_memory()))
-                host_seq, host_lp, host_flag = pool.pop()
+                                 torch.zeros(2, dtype=torch.int32).pin_memory(),
+                                 torch.zeros(max_length, dtype=torch.int32).pin_memory()))
+                host_seq, host_lp, host_flag, host_cnt = pool.pop()
                 host_seq.copy_(res["seq"][rows], non_blocking=True)
                 host_lp.copy_(res["sampled_logprob"][rows], non_blocking=True)
                 dflags = _device_flags(enc)
@@ -477,14 +518,17 @@ class TransformerModel(CaptionModel):
                     cnt = cnts[len(staged)]
                 else:   # rows still unfinished after step t: finished rows hold end_idx (csrc/decoder.hip greedy_pick)
                     cnt = (res["seq"][rows] != self.end_idx).sum(0).to(torch.int32)
+                if len(items) > 1:
+                    host_cnt.copy_(cnt, non_blocking=True)
                 out = {"logit": res["logit"][rows], "embed": res["embed"][rows], "unfinished_cnt": cnt}
                 out.update(enc)
-                staged.append((pending, host_seq, host_lp, host_flag, out, pool))
+                staged.append((pending, host_seq, host_lp, host_flag, host_cnt, len(items) > 1, out, pool))
             done = torch.cuda.Event()
             done.record(dec_s)
-        for pending, host_seq, host_lp, host_flag, out, pool in staged:
+        for pending, host_seq, host_lp, host_flag, host_cnt, shared, out, pool in staged:
             pending._fill(done, host_seq, host_lp, out,
-                          (lambda pool=pool, a=host_seq, b=host_lp, c=host_flag: pool.append((a, b, c))), host_flag)
+                          (lambda pool=pool, a=host_seq, b=host_lp, c=host_flag, d=host_cnt: pool.append((a, b, c, d))), host_flag,
+                          host_cnt if shared else None)
 
     # ---- greedy (base.py:152-218) -----------------------------------------------------------------
     def greedy_search(self, input_dict):

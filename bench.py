@@ -43,6 +43,11 @@ if REPO not in sys.path:
 
 import torch
 
+
+def _decode_group():
+    from audiocaption_amd.transformer_model import decode_group
+    return decode_group()
+
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 / fp16 MFMA peak (v_mfma_f32_32x32x16_{bf16,f16})
 HBM_PEAK_GBS = 8000.0
@@ -497,7 +502,7 @@ def bench_effb2(args, ranks, steps, warmup):
 
     # one-time setup: every chain shape a greedy run can produce (a lone batch, a full group, a shorter last group) is used
     # twice, so that no HIP-graph capture lands in the warm-up or the timed steps (as in the Cnn14 mode)
-    gmax = max(1, int(os.environ.get("AUDIOCAPTION_DECODE_GROUP", "2")))
+    gmax = _decode_group()
     for n_prime in [1 + 2 * gmax] + [1 + gmax + k for k in range(1, gmax) for _ in (0, 1)] + [1, 1]:
         run_steps(n_prime)
     run_steps(max(warmup, 2))
@@ -850,7 +855,7 @@ def main():
     if not args.sync_steps:
         # forward_async decodes up to AUDIOCAPTION_DECODE_GROUP submissions as one chain: every chain shape a run can
         # produce (a lone batch, a full group, the shorter groups left at the end of a run) is used twice here
-        gmax = max(1, int(os.environ.get("AUDIOCAPTION_DECODE_GROUP", "2")))
+        gmax = _decode_group()
         for n_prime in [1 + 2 * gmax] + [1 + gmax + k for k in range(1, gmax) for _ in (0, 1)] + [1, 1]:
             run_steps(n_prime)
     # ---- timed region: exactly K steps of the default tier ----

@@ -521,6 +521,17 @@ int ac_ingest_resample(const void* src, int src_half, const long* src_off, const
  * holds under matrix load - the context of `roofline.frac`, whose denominator is the NOMINAL dense peak. */
 int ac_mfma_bf16_probe(float* out, int blocks, int iters, void* stream);
 
+/* Diagnostic: `blocks` workgroups of `threads` threads record where they ran - out[2 b] = XCC_ID register, out[2 b + 1] =
+ * HW_ID register (cu_id bits 11:8, sh_id bit 12, se_id bits 15:13) - and stay resident for spin_ticks of the 100 MHz clock. */
+int ac_placement_probe(int* out, int blocks, int threads, int spin_ticks, void* stream);
+
+/* A HIP stream restricted to n_cus compute units (hipExtStreamCreateWithCUMask, mask bits first_cu .. first_cu + n_cus - 1).  The throughput
+ * mode (TransformerModel.forward_async) runs its latency-bound decode chains on such a stream: their small workgroups are
+ * packed onto a few CUs instead of each holding a CU that a one-workgroup-per-CU conv kernel of the encoder stream then
+ * cannot use.  The only entry points of this library that create / destroy a driver object; the caller owns the stream. */
+int ac_stream_create_cu_mask(int first_cu, int n_cus, void** out);
+int ac_stream_destroy(void* stream);
+
 #ifdef __cplusplus
 }
 #endif

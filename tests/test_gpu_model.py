@@ -487,6 +487,26 @@ def test_forward_async_pair_decode_mixed_shapes(hip_model):
     assert torch.equal(again["seq"], want[0]["seq"])
 
 
+@pytest.mark.parametrize("group", ["1", "3", "4"])
+def test_forward_async_decode_groups_equal_blocking(hip_model, monkeypatch, group):
+    """AUDIOCAPTION_DECODE_GROUP submissions share one greedy chain (default 4: transformer_model.decode_group): seven
+    same-shaped batches (full groups and a shorter last one) give the bits of the blocking call, batch by batch."""
+    from audiocaption_amd import procedural as P
+    monkeypatch.setenv("AUDIOCAPTION_DECODE_GROUP", group)
+    wavs = [torch.from_numpy(P.synthetic_wav(3, 48000, seed=20 + s_, varied=True)).cuda() for s_ in range(7)]
+    inputs = [{"mode": "inference", "wav": w, "wav_len": [48000, 40000, 33000], "specaug": False,
+               "sample_method": "greedy", "max_length": 8} for w in wavs]
+    want = [hip_model(dict(i)) for i in inputs]
+    for _ in range(2):   # the second pass replays the captured chains
+        pend = [hip_model.forward_async(dict(i), pair=True) for i in inputs]
+        for k in (6, 0, 3, 1, 2, 5, 4):
+            g, w = pend[k].result(), want[k]
+            assert torch.equal(w["seq"], g["seq"]) and torch.equal(w["logit"], g["logit"])
+            assert torch.equal(w["sampled_logprob"], g["sampled_logprob"])
+            assert torch.equal(w["unfinished_cnt"].cpu(), g["unfinished_cnt"].cpu())
+    assert hip_model._held is None
+
+
 @pytest.mark.parametrize("group,conc", [("1", "2"), ("2", "1"), ("1", "1")])
 def test_forward_async_beam_equals_blocking(hip_model, monkeypatch, group, conc):
     """Beam search through forward_async (encoders submitted up front, the host-driven searches run at result() on the
