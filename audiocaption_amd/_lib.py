@@ -122,7 +122,7 @@ SIGNATURES = {
     "ac_ingest_resample": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ac_mfma_bf16_probe": (_I, [_P, _I, _I, _P]),
     "ac_placement_probe": (_I, [_P, _I, _I, _I, _P]),
-    "ac_stream_create_cu_mask": (_I, [_I, _I, ctypes.POINTER(ctypes.c_void_p)]),
+    "ac_stream_create_cu_mask": (_I, [_I, _I, _P]),
     "ac_stream_destroy": (_I, [_P]),
 }
 

@@ -161,7 +161,7 @@ def _masked_stream(dev, first_cu, n_cus):
     from . import _lib
     out = ctypes.c_void_p()
     with torch.cuda.device(dev):
-        check(_lib.load().ac_stream_create_cu_mask(int(first_cu), int(n_cus), ctypes.byref(out)), "ac_stream_create_cu_mask")
+        check(_lib.load().ac_stream_create_cu_mask(int(first_cu), int(n_cus), ctypes.addressof(out)), "ac_stream_create_cu_mask")
     return torch.cuda.ExternalStream(out.value, device=dev)
 
 

@@ -138,7 +138,8 @@ def test_feat_len_and_geometry():
     T, H, Hp = cnn.geometry(320000)
     assert T == 1001 and H == [1001, 500, 250, 125, 62, 31] and Hp == [1024, 512, 256, 128, 64, 32]
     T, H, Hp = cnn.geometry(960000)
-    assert H[5] == 93 and Hp[5] == 94 and all(Hp[k] == 2 * Hp[k + 1] and Hp[k] > H[k] for k in range(5))
+    assert H[5] == 93 and Hp[5] == 96 and all(Hp[k] == 2 * Hp[k + 1] and Hp[k] > H[k] for k in range(5))
+    assert all(h % 4 == 0 for h in Hp)   # row quads of the F(4,3) kernels never straddle two clips
     with pytest.raises(ValueError):
         cnn.geometry(3000)
 
