@@ -111,6 +111,15 @@ def _conv_wino43(x, w, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode
                         dropout=dropout)
 
 
+def ragged_exact():
+    """AUDIOCAPTION_RAGGED_EXACT=1: a ragged batch returns the BITS of the run that convolves all its padding (``rows_needed(
+    quads=True)``, block 6 on F(2,3)).  Default 0: every conv skips what lies beyond the rows an output frame DEPENDS on; the
+    F(4,3) kernels then form the last live quad of a clip from input rows that were themselves skipped (zeros) beyond that
+    line - rows whose contribution cancels in exact arithmetic and to the tier's 2^-16 operand error here: valid frames
+    within 5e-5 of the dense run (the bar the tier is held to anyway), a fifth fewer rows convolved on Clotho-shaped batches."""
+    return os.environ.get("AUDIOCAPTION_RAGGED_EXACT", "0") == "1"
+
+
 def rows_needed(block, conv, quads=False):
     """(mul, add): output rows of conv ``conv`` (1 | 2) of conv block ``block`` (1..6) that can reach an output frame below a
     clip's own ``attn_emb_len`` = mul * attn_emb_len + add.  Block 6 is not pooled: its second conv needs exactly the
@@ -370,7 +379,7 @@ class Cnn14Encoder(nn.Module):
             conv = functools.partial(conv, splitk_buf=lambda n: self._buf("w1_splitk", n, dev))
 
         def need(block, j):   # ragged batches: the rows of this layer a clip's own length can bring to an output frame
-            return {"need": (clip_frames,) + rows_needed(block, j, quads=algo == "wino43")} \
+            return {"need": (clip_frames,) + rows_needed(block, j, quads=algo == "wino43" and ragged_exact())} \
                 if clip_frames is not None and algo in WINO else {}
 
         mixed = algo == "f16x2" and pk.get("mixed", False)
@@ -443,9 +452,9 @@ class Cnn14Encoder(nn.Module):
         ragged = skip_fc and algo in WINO and os.environ.get("AUDIOCAPTION_SKIP_DEAD_ROWS", "1") != "0" \
             and int(feat_length.min()) < int(feat_length.max())
         frames = K.upload(feat_length, wav.device, torch.int32) if ragged else None
-        # a batch of uneven lengths keeps block 6 on the F(2,3) kernel whether or not rows are skipped (same kernels = same
-        # bits with AUDIOCAPTION_SKIP_DEAD_ROWS on and off; see _conv_wino43)
-        uneven = skip_fc and int(feat_length.min()) < int(feat_length.max())
+        # AUDIOCAPTION_RAGGED_EXACT=1: a batch of uneven lengths keeps block 6 on the F(2,3) kernel whether or not rows are
+        # skipped (same kernels = same bits with AUDIOCAPTION_SKIP_DEAD_ROWS on and off; see _conv_wino43, ragged_exact)
+        uneven = skip_fc and ragged_exact() and int(feat_length.min()) < int(feat_length.max())
         attn_emb = self.encode(wav, min_frames=min_frames, algo=algo, overflow=flag, clip_frames=frames,
                                x0=input_dict.get("_logmel"), block6_f23=uneven)
         out = {"attn_emb": attn_emb, "attn_emb_len": feat_length}

@@ -426,12 +426,15 @@ def test_decode_is_bit_stable_beside_matrix_heavy_kernels(hip_model, state4981):
     assert differing == 0
 
 
-def test_ragged_batch_skips_dead_rows_bit_identically(hip_model, monkeypatch):
+@pytest.mark.parametrize("exact", ["1", "0"])
+def test_ragged_batch_skips_dead_rows_bit_identically(hip_model, monkeypatch, exact):
     """Ragged batch (3 ... 10 s clips, zero-padded to the longest as the collate does): the default conv tier does not
     convolve the rows a clip's own length cannot bring to one of its output frames (cnn_encoder.rows_needed).  What the
     model returns - the GRU's attn_emb / fc_emb, logits, ids - must be BIT-identical to the run that convolves all the
-    padding like the reference (collate_func.py:29-32, cnn_encoder.py:446-450), and each clip must equal the clip run
-    alone under the same padding (5e-5)."""
+    padding like the reference (collate_func.py:29-32, cnn_encoder.py:446-450) under AUDIOCAPTION_RAGGED_EXACT=1 and within
+    the tier's own bar (attn_emb 5e-5, logits 1e-4, same ids) in the default mode (cnn_encoder.ragged_exact), and each clip
+    must equal the clip run alone under the same padding (5e-5)."""
+    monkeypatch.setenv("AUDIOCAPTION_RAGGED_EXACT", exact)
     from audiocaption_amd import procedural as P
     secs = [10.0, 3.1, 7.4, 5.0, 9.2, 4.3]
     wav_len = [int(s_ * 32000) for s_ in secs]
@@ -448,8 +451,15 @@ def test_ragged_batch_skips_dead_rows_bit_identically(hip_model, monkeypatch):
     full = hip_model(dict(inp))
     monkeypatch.setenv("AUDIOCAPTION_SKIP_DEAD_ROWS", "1")
     skip = hip_model(dict(inp))
-    for k in ("attn_emb", "fc_emb", "logit", "sampled_logprob"):
-        assert torch.equal(full[k], skip[k]), k
+    if exact == "1":
+        for k in ("attn_emb", "fc_emb", "logit", "sampled_logprob"):
+            assert torch.equal(full[k], skip[k]), k
+    else:
+        lens = [int(v) for v in full["attn_emb_len"]]
+        for i, t in enumerate(lens):
+            assert _maxdiff(f"clip {i}: attn_emb, skipped vs dense", skip["attn_emb"][i, :t], full["attn_emb"][i, :t]) < 5e-5
+        assert _maxdiff("fc_emb, skipped vs dense", skip["fc_emb"], full["fc_emb"]) < 5e-5
+        assert _maxdiff("logit, skipped vs dense", skip["logit"], full["logit"]) < 1e-4
     assert torch.equal(full["seq"], skip["seq"])
     for i, n in enumerate(wav_len):
         one = hip_model(dict(inp, wav=wav[i:i + 1].contiguous(), wav_len=[n]))   # padded like in the batch (the mel of the
