@@ -63,6 +63,7 @@ __device__ unsigned long long w4_clk[8];
 #endif
 
 constexpr int KS = 16;   // input channels per K step = one MFMA k-step
+constexpr int W4_OUT_TILE = 4 * 32 * 144;   // epilogue: a wave's LDS tile of 4 rows x 32 pixels x (128 + 16) bytes
 
 struct W4Params {
   const float* in;
@@ -406,7 +407,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_w4_kernel(W4Params p) {
     const int col = G::COLT ? m : pi % TC;
     const int qg = quad0 + (G::COLT ? pi : m * QT + pi / TC);
     const int gr = 4 * qg;
-    const bool inside = gr < p.rows_total;
     f32x4 y[4][4];   // y[g][j][e]: channel quad g, output row j, channel chw + 8 g + e
 #pragma unroll
     for (int g = 0; g < 4; ++g)
@@ -418,22 +418,38 @@ __global__ __launch_bounds__(256, 1) void conv3x3_w4_kernel(W4Params p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) y[g][j][e] = yy[j];
       }
+    // The values go to memory through a wave-private LDS tile ([row][pixel], 144-byte pixel pitch): lane (pixel, half)
+    // writes its channel quads, lane (P = l / 8, q = l % 8) reads quad q of pixel 8 k + P back, so that a store instruction
+    // writes the wave's 128 contiguous bytes of 8 pixels.  Straight from the accumulator layout every lane's 16 bytes were
+    // a memory request of their own (a lane's neighbour in memory sits 32 lanes away): 64 requests per instruction, and a
+    // conv1 layer's 128 KB per workgroup took 9 k cycles to drain (tools/w4_variants.py, EXPERIMENTS.md).
+    unsigned char* wt = dsm_raw + wave * W4_OUT_TILE;
+    constexpr int PITCH = 144;
+    const int P8 = lane >> 3, q8 = lane & 7;
     if (MODE == MODE_FULL) {
       const int h = by_hp.mod(gr);   // Hp % 4 == 0: the four rows of a quad belong to one clip
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {   // the four stores that complete a pixel's 128-byte line of this wave back to back
-          const size_t oi = ((size_t)(gr + j) * p.W + col) * p.Cout + chw + 8 * g;
-          f32x4 v = h + j < p.H ? y[g][j] : zero4;
+        for (int g = 0; g < 4; ++g)
+          *(f32x4*)(wt + (j * 32 + pi) * PITCH + (2 * g + half) * 16) = h + j < p.H ? y[g][j] : zero4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int px = 8 * k + P8;
+        const int pcol = G::COLT ? m : px % TC;
+        const int pgr = 4 * (quad0 + (G::COLT ? px : m * QT + px / TC));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f32x4 v = *(const f32x4*)(wt + (j * 32 + px) * PITCH + q8 * 16);
+          const size_t oi = ((size_t)(pgr + j) * p.W + pcol) * p.Cout + n_tile * 128 + wave * 32 + 4 * q8;
           if (p.drop.thresh != 0) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] *= p.drop.mask(oi + e);
           }
-          if (inside && !(W4_KO & 64)) *(f32x4*)(p.out + oi) = v;
+          if (pgr < p.rows_total && !(W4_KO & 64)) *(f32x4*)(p.out + oi) = v;
         }
-    } else {   // a row quad is two pooled rows: the even lane of a column pair stores the first, the odd lane the second
-      const int pr = 2 * qg + (col & 1);
+      }
+    } else {   // a row quad is two pooled rows: the even lane of a column pair holds the first, the odd lane the second
       const bool valid = by_hp_out.mod(2 * qg) + (col & 1) < p.H_out;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -444,13 +460,19 @@ __global__ __launch_bounds__(256, 1) void conv3x3_w4_kernel(W4Params p) {
           const float a = t0[e] + dpp_mov<DPP_QUAD_XOR1>(t0[e]), b = t1[e] + dpp_mov<DPP_QUAD_XOR1>(t1[e]);
           o[e] = 0.25f * ((col & 1) ? b : a);
         }
-        const size_t oi = ((size_t)pr * p.W_out + (col >> 1)) * p.Cout + chw + 8 * g;
-        if (!valid) o = zero4;
+        *(f32x4*)(wt + pi * PITCH + (2 * g + half) * 16) = valid ? o : zero4;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int px = 8 * k + P8;
+        const int pcol = px % TC, pqg = quad0 + m * QT + px / TC;
+        f32x4 o = *(const f32x4*)(wt + px * PITCH + q8 * 16);
+        const size_t oi = ((size_t)(2 * pqg + (pcol & 1)) * p.W_out + (pcol >> 1)) * p.Cout + n_tile * 128 + wave * 32 + 4 * q8;
         if (p.drop.thresh != 0) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] *= p.drop.mask(oi + e);
         }
-        if (inside && !(W4_KO & 64)) *(f32x4*)(p.out + oi) = o;
+        if (4 * pqg < p.rows_total && !(W4_KO & 64)) *(f32x4*)(p.out + oi) = o;
       }
     }
   }
@@ -477,7 +499,7 @@ int launch_w4(W4Params p, hipStream_t s) {
   if (p.map_mode == 2) grid = (unsigned)(((p.MT + 7) / 8) * 8 * p.NT);
   else if (p.map_mode == 3) grid = (unsigned)(((p.MT + 8 / p.NT - 1) / (8 / p.NT)) * 8);
   else grid = (unsigned)(p.MT * p.NT);
-  constexpr size_t lds = (size_t)2 * G::VBUF;
+  constexpr size_t lds = (size_t)2 * G::VBUF > (size_t)4 * W4_OUT_TILE ? (size_t)2 * G::VBUF : (size_t)4 * W4_OUT_TILE;
   static_assert(lds <= 160 * 1024, "V planes exceed the LDS");
   static bool attr_set = false;
   if (!attr_set) {
