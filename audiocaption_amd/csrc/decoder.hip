@@ -188,61 +188,97 @@ struct RowParams {
   float* qout; long ldqo;
 };
 
-__device__ __forceinline__ float attn_head_row(const AttnParams& p, int r, int h, int lane, float* sc, bool active) {
-  // head h of row r, one wave; returns output channel `lane` (< 64) of the head.  Mirrors attn_step_kernel.  Waves with
-  // `active` false only take part in the workgroup barriers.
-  (void)active;
+constexpr int ATT_KPRE = 8, ATT_VPRE = 32;
+struct AttnLoads {            // what a wave has requested for one attention phase (one head of one row)
+  f32x4 kpre[ATT_KPRE];       // key rows of the first 32 keys: lane (ks = l / 16, d4 = l % 16) holds dims 4 d4 .. + 3 of key 4 i + ks
+  float vpre[ATT_VPRE];       // value column `lane` of the first 32 keys
+};
+
+// Request everything head h of row r reads from memory - NOT the query: it may not exist yet.  The newest key / value
+// (this step's projection, which also goes into the cache for the steps to come) is read from where the projection left it
+// instead of being stored, fenced and read back.
+__device__ __forceinline__ void attn_issue_k(const AttnParams& p, int r, int h, int lane, f32x4 (&kpre)[ATT_KPRE]) {
   const int kr = r / p.row_div;
   const size_t hoff = (size_t)h * 64;
-  if (p.new_k) {
-    const size_t dst = (size_t)kr * p.row_stride + (size_t)(p.nkeys - 1) * p.key_stride + hoff + lane;
-    p.Kw[dst] = p.new_k[(size_t)r * p.ld_new + hoff + lane];
-    p.Vw[dst] = p.new_v[(size_t)r * p.ld_new + hoff + lane];
+  const float* Kb = p.K + (size_t)kr * p.row_stride + hoff;
+  const float* nk = p.new_k ? p.new_k + (size_t)r * p.ld_new + hoff : nullptr;
+  const int newest = p.new_k ? p.nkeys - 1 : -1;
+  const int ks = lane >> 4, d4 = lane & 15;
+  // branch-free: a key beyond the last one re-reads the last one (its score is never used), so that the number of loads in
+  // flight is known to the compiler and a later wait can leave the younger ones in flight
+  const int last = p.nkeys - 1;
+#pragma unroll
+  for (int i = 0; i < ATT_KPRE; ++i) {
+    const int j = 4 * i + ks < last ? 4 * i + ks : last;
+    const float* src = j == newest ? nk + 4 * d4 : Kb + (size_t)j * p.key_stride + 4 * d4;
+    kpre[i] = *(const f32x4*)src;
   }
-  __syncthreads();
+}
+
+__device__ __forceinline__ void attn_issue_v(const AttnParams& p, int r, int h, int lane, float (&vpre)[ATT_VPRE]) {
+  const int kr = r / p.row_div;
+  const size_t hoff = (size_t)h * 64;
+  const float* Vb = p.V + (size_t)kr * p.row_stride + hoff;
+  const float* nk = p.new_k ? p.new_k + (size_t)r * p.ld_new + hoff : nullptr;
+  const float* nv = p.new_k ? p.new_v + (size_t)r * p.ld_new + hoff : nullptr;
+  const int newest = p.new_k ? p.nkeys - 1 : -1;
+  const int last = p.nkeys - 1;
+#pragma unroll
+  for (int j = 0; j < ATT_VPRE; ++j) {   // branch-free like the keys; columns beyond the last key are zeroed below
+    const int jj = j < last ? j : last;
+    const float* src = jj == newest ? nv + lane : Vb + (size_t)jj * p.key_stride + lane;
+    vpre[j] = *src;
+  }
+#pragma unroll
+  for (int j = 0; j < ATT_VPRE; ++j) vpre[j] = j < p.nkeys ? vpre[j] : 0.f;
+  if (p.new_k) {   // the cache rows of this step, for the steps to come (nobody in this launch reads them back)
+    const size_t dst = (size_t)kr * p.row_stride + (size_t)newest * p.key_stride + hoff + lane;
+    p.Kw[dst] = nk[lane];
+    p.Vw[dst] = nv[lane];
+  }
+}
+
+__device__ __forceinline__ void attn_issue(const AttnParams& p, int r, int h, int lane, AttnLoads& L) {
+  attn_issue_k(p, r, h, lane, L.kpre);
+  attn_issue_v(p, r, h, lane, L.vpre);
+}
+
+// Head h of row r, one wave, from the requested rows; returns output channel `lane` (< 64) of the head.  The arithmetic
+// of attn_step_kernel.
+__device__ __forceinline__ float attn_compute(const AttnParams& p, int r, int h, int lane, float* sc, const AttnLoads& L) {
+  const int kr = r / p.row_div;
+  const size_t hoff = (size_t)h * 64;
   const float* qp = p.q + (size_t)r * p.ldq + hoff;
   const float* Kb = p.K + (size_t)kr * p.row_stride + hoff;
   const float* Vb = p.V + (size_t)kr * p.row_stride + hoff;
+  const float* nk = p.new_k ? p.new_k + (size_t)r * p.ld_new + hoff : nullptr;
+  const float* nv = p.new_k ? p.new_v + (size_t)r * p.ld_new + hoff : nullptr;
+  const int newest = p.new_k ? p.nkeys - 1 : -1;
   const int klen = p.key_len ? p.key_len[kr] : p.nkeys;
+  const int ks = lane >> 4, d4 = lane & 15;
+  const f32x4 q4 = *(const f32x4*)(qp + 4 * d4);
   if (lane < 32 && lane >= p.nkeys) sc[lane] = 0.f;
-  {
-    const int ks = lane >> 4, d4 = lane & 15;
-    const f32x4 q4 = *(const f32x4*)(qp + 4 * d4);
-    // the key rows of the first 32 keys are all requested at once (a decode step has <= 21 self keys; 31 audio frames
-    // for a 10 s clip): one memory round trip instead of one per four keys
-    constexpr int KPRE = 8;
-    f32x4 kpre[KPRE];
-#pragma unroll
-    for (int i = 0; i < KPRE; ++i) {
-      const int j = 4 * i + ks;
-      kpre[i] = j < p.nkeys ? *(const f32x4*)(Kb + (size_t)j * p.key_stride + 4 * d4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
 #pragma unroll 4
-    for (int j0 = 0; j0 < p.nkeys; j0 += 4) {
-      const int j = j0 + ks;
-      float s = 0.f;
-      if (j < p.nkeys) {
-        f32x4 kv;
-        if (j0 < 4 * KPRE) {
+  for (int j0 = 0; j0 < p.nkeys; j0 += 4) {
+    const int j = j0 + ks;
+    float s = 0.f;
+    if (j < p.nkeys) {
+      f32x4 kv;
+      if (j0 < 4 * ATT_KPRE) {
 #pragma unroll
-          for (int i = 0; i < KPRE; ++i)
-            if (j0 == 4 * i) kv = kpre[i];
-        } else {
-          kv = *(const f32x4*)(Kb + (size_t)j * p.key_stride + 4 * d4);
-        }
-        s = (q4[0] * kv[0] + q4[1] * kv[1]) + (q4[2] * kv[2] + q4[3] * kv[3]);
+        for (int i = 0; i < ATT_KPRE; ++i)
+          if (j0 == 4 * i) kv = L.kpre[i];
+      } else {
+        kv = *(const f32x4*)(j == newest ? nk + 4 * d4 : Kb + (size_t)j * p.key_stride + 4 * d4);
       }
-      s = row16_sum(s);
-      if (d4 == 0 && j < p.nkeys) {
-        const bool masked = (j >= klen) || (p.key_mask && p.key_mask[(size_t)r * p.mask_stride + j]);
-        sc[j] = masked ? -INFINITY : s * p.scale;
-      }
+      s = (q4[0] * kv[0] + q4[1] * kv[1]) + (q4[2] * kv[2] + q4[3] * kv[3]);
+    }
+    s = row16_sum(s);
+    if (d4 == 0 && j < p.nkeys) {
+      const bool masked = (j >= klen) || (p.key_mask && p.key_mask[(size_t)r * p.mask_stride + j]);
+      sc[j] = masked ? -INFINITY : s * p.scale;
     }
   }
-  constexpr int VPRE = 32;
-  float vpre[VPRE];
-#pragma unroll
-  for (int j = 0; j < VPRE; ++j) vpre[j] = j < p.nkeys ? Vb[(size_t)j * p.key_stride + lane] : 0.f;
   __syncthreads();
   float m = -INFINITY;
   for (int j = lane; j < p.nkeys; j += 64) m = fmaxf(m, sc[j]);
@@ -257,14 +293,21 @@ __device__ __forceinline__ float attn_head_row(const AttnParams& p, int r, int h
   __syncthreads();
   float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
 #pragma unroll
-  for (int j = 0; j < VPRE; j += 4) {
-    o0 = fmaf(sc[j], vpre[j], o0);
-    o1 = fmaf(sc[j + 1], vpre[j + 1], o1);
-    o2 = fmaf(sc[j + 2], vpre[j + 2], o2);
-    o3 = fmaf(sc[j + 3], vpre[j + 3], o3);
+  for (int j = 0; j < ATT_VPRE; j += 4) {
+    o0 = fmaf(sc[j], L.vpre[j], o0);
+    o1 = fmaf(sc[j + 1], L.vpre[j + 1], o1);
+    o2 = fmaf(sc[j + 2], L.vpre[j + 2], o2);
+    o3 = fmaf(sc[j + 3], L.vpre[j + 3], o3);
   }
-  for (int j = VPRE; j < p.nkeys; ++j) o0 = fmaf(sc[j], Vb[(size_t)j * p.key_stride + lane], o0);
+  for (int j = ATT_VPRE; j < p.nkeys; ++j) o0 = fmaf(sc[j], j == newest ? nv[lane] : Vb[(size_t)j * p.key_stride + lane], o0);
   return ((o0 + o1) + (o2 + o3)) / den;
+}
+
+__device__ __forceinline__ float attn_head_row(const AttnParams& p, int r, int h, int lane, float* sc, bool active) {
+  (void)active;
+  AttnLoads L;
+  attn_issue(p, r, h, lane, L);
+  return attn_compute(p, r, h, lane, sc, L);
 }
 
 // Matrix-vector product against a transposed 256 x 256 matrix, split over the 4 waves of the workgroup: wave w owns
@@ -330,6 +373,16 @@ __device__ __forceinline__ float row_gemv256(const float* WT, const float* bias,
   return y;
 }
 
+#ifdef AC_ROW_STAMPS   // development (tools/row_stamps.py): phase timestamps (100 MHz) of workgroup 0 of dec_row2_kernel
+__device__ unsigned long long g_row_stamps[16];
+#define ROW_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_row_stamps[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int ac_row_stamps_read(unsigned long long* out16) {
+  return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_row_stamps), sizeof(g_row_stamps)) == hipSuccess ? 0 : -2;
+}
+#else
+#define ROW_STAMP(k) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(256, 2) void dec_row_kernel(RowParams p) {
   __shared__ float sc[ROW_H][MAX_KEYS];
   __shared__ __attribute__((aligned(16))) float sx[ROW_D];
@@ -372,11 +425,17 @@ __global__ __launch_bounds__(256, 2) void dec_row2_kernel(RowParams p1, RowParam
   __shared__ float red[8];
   const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float xn;
+  ROW_STAMP(0);
+  const float resv = p1.res[(size_t)r * p1.ldres + tid];
+  sx[tid] = attn_head_row(p1.a, r, wave, lane, sc[wave], true);
+  // (Requesting the cross attention's rows up here as well - they depend on nothing computed in this kernel - was tried:
+  // held in registers they make the compiler serialise the matrix-vector products' loads (2.3 -> 14 us each); parked in
+  // LDS the cross phase drops from 4.2 to 1.9 us and the self phase grows by as much, waiting for them to land.)
   {
-    const float resv = p1.res[(size_t)r * p1.ldres + tid];
-    sx[tid] = attn_head_row(p1.a, r, wave, lane, sc[wave], true);
     __syncthreads();
+    ROW_STAMP(1);
     const float v = resv + row_gemv256(p1.WoT, p1.bo, sx, part, tid);
+    ROW_STAMP(2);
     const float s1 = wave_sum(v);
     if (lane == 0) red[wave] = s1;
     __syncthreads();
@@ -390,15 +449,19 @@ __global__ __launch_bounds__(256, 2) void dec_row2_kernel(RowParams p1, RowParam
     p1.xout[(size_t)r * p1.ldxo + tid] = xn;
     sx[tid] = xn;
     __syncthreads();
+    ROW_STAMP(3);
     sq[tid] = row_gemv256(p1.WqT, p1.bq, sx, part, tid);
     __syncthreads();
+    ROW_STAMP(4);
   }
   AttnParams a2 = p2.a;
   a2.q = sq;            // the cross query of this row, still in LDS
   a2.ldq = 0;
   sx[tid] = attn_head_row(a2, r, wave, lane, sc[wave], true);
   __syncthreads();
+  ROW_STAMP(5);
   const float v = xn + row_gemv256(p2.WoT, p2.bo, sx, part, tid);
+  ROW_STAMP(6);
   const float s1 = wave_sum(v);
   __syncthreads();      // red[] of the first half has been read by every thread
   if (lane == 0) red[wave] = s1;
@@ -410,6 +473,7 @@ __global__ __launch_bounds__(256, 2) void dec_row2_kernel(RowParams p1, RowParam
   __syncthreads();
   const float rstd = rsqrtf(((red[4] + red[5]) + (red[6] + red[7])) * (1.0f / ROW_D) + 1e-5f);
   p2.xout[(size_t)r * p2.ldxo + tid] = dl * rstd * p2.ln_w[tid] + p2.ln_b[tid];
+  ROW_STAMP(7);
 }
 
 // WT[k][n] = W[n][k] for a d x d matrix (rows n of W may be a slice of a taller matrix: ldw)
