@@ -192,6 +192,8 @@ constexpr int ATT_KPRE = 8, ATT_VPRE = 32;
 struct AttnLoads {            // what a wave has requested for one attention phase (one head of one row)
   f32x4 kpre[ATT_KPRE];       // key rows of the first 32 keys: lane (ks = l / 16, d4 = l % 16) holds dims 4 d4 .. + 3 of key 4 i + ks
   float vpre[ATT_VPRE];       // value column `lane` of the first 32 keys
+  unsigned char mpre[ATT_KPRE];   // key_mask of those keys (0 without a mask)
+  int klen;                   // keys of this row that exist (key_len, or all)
 };
 
 // Request everything head h of row r reads from memory - NOT the query: it may not exist yet.  The newest key / value
@@ -240,6 +242,15 @@ __device__ __forceinline__ void attn_issue_v(const AttnParams& p, int r, int h, 
 
 __device__ __forceinline__ void attn_issue(const AttnParams& p, int r, int h, int lane, AttnLoads& L) {
   attn_issue_k(p, r, h, lane, L.kpre);
+  {   // the mask bytes and the row's key count travel with the keys (they used to be a second round trip inside the score loop)
+    const int ks = lane >> 4, last = p.nkeys - 1;
+#pragma unroll
+    for (int i = 0; i < ATT_KPRE; ++i) {
+      const int j = 4 * i + ks < last ? 4 * i + ks : last;
+      L.mpre[i] = p.key_mask ? p.key_mask[(size_t)r * p.mask_stride + j] : (unsigned char)0;
+    }
+    L.klen = p.key_len ? p.key_len[r / p.row_div] : p.nkeys;
+  }
   attn_issue_v(p, r, h, lane, L.vpre);
 }
 
@@ -254,7 +265,7 @@ __device__ __forceinline__ float attn_compute(const AttnParams& p, int r, int h,
   const float* nk = p.new_k ? p.new_k + (size_t)r * p.ld_new + hoff : nullptr;
   const float* nv = p.new_k ? p.new_v + (size_t)r * p.ld_new + hoff : nullptr;
   const int newest = p.new_k ? p.nkeys - 1 : -1;
-  const int klen = p.key_len ? p.key_len[kr] : p.nkeys;
+  const int klen = L.klen;
   const int ks = lane >> 4, d4 = lane & 15;
   const f32x4 q4 = *(const f32x4*)(qp + 4 * d4);
   if (lane < 32 && lane >= p.nkeys) sc[lane] = 0.f;
@@ -262,20 +273,22 @@ __device__ __forceinline__ float attn_compute(const AttnParams& p, int r, int h,
   for (int j0 = 0; j0 < p.nkeys; j0 += 4) {
     const int j = j0 + ks;
     float s = 0.f;
+    unsigned char mk = 0;
     if (j < p.nkeys) {
       f32x4 kv;
       if (j0 < 4 * ATT_KPRE) {
 #pragma unroll
         for (int i = 0; i < ATT_KPRE; ++i)
-          if (j0 == 4 * i) kv = L.kpre[i];
+          if (j0 == 4 * i) { kv = L.kpre[i]; mk = L.mpre[i]; }
       } else {
         kv = *(const f32x4*)(j == newest ? nk + 4 * d4 : Kb + (size_t)j * p.key_stride + 4 * d4);
+        mk = p.key_mask ? p.key_mask[(size_t)r * p.mask_stride + j] : (unsigned char)0;
       }
       s = (q4[0] * kv[0] + q4[1] * kv[1]) + (q4[2] * kv[2] + q4[3] * kv[3]);
     }
     s = row16_sum(s);
     if (d4 == 0 && j < p.nkeys) {
-      const bool masked = (j >= klen) || (p.key_mask && p.key_mask[(size_t)r * p.mask_stride + j]);
+      const bool masked = (j >= klen) || mk;
       sc[j] = masked ? -INFINITY : s * p.scale;
     }
   }
