@@ -518,7 +518,7 @@ def bench_effb2(args, ranks, steps, warmup):
     enc_ms = e0.elapsed_time(e1) / 3
     alg_bytes = 100e6 * (args.seconds / 10.0) * B
     traffic, tsrc = None, None
-    for name in ("r03_traffic_effb2.json", "r02_traffic_effb2.json", "r01_traffic_effb2.json"):
+    for name in ("r04_traffic_effb2.json", "r03_traffic_effb2.json", "r02_traffic_effb2.json", "r01_traffic_effb2.json"):
         tpath = os.path.join(REPO, "profiles", name)
         if os.path.exists(tpath) and args.seconds == 10.0:
             with open(tpath) as f:   # PMC-measured HBM bytes per clip (collected in separate --pmc passes), scaled to B
