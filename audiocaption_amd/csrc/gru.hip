@@ -137,6 +137,11 @@ constexpr int GQ = 4, HQ = H / GQ;              // parts per (clip, direction); 
 constexpr int HQP = HQ + 4;                      // LDS pitch of a quarter of h: the four k quarters hit different banks
 constexpr long long GRU_SPIN_TICKS = 200000000;   // 2 s of the 100 MHz wall clock
 
+__global__ void gru_split_reset_kernel(unsigned long long* w, unsigned words) {
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i < words) w[i] = 0ull;
+}
+
 __global__ __launch_bounds__(256) void gru_layer_split_kernel(GruSplitParams p) {
   __shared__ __attribute__((aligned(16))) float sh[GQ * HQP];
   __shared__ unsigned s_ticket;
@@ -303,8 +308,16 @@ extern "C" int ac_gru_layer_split(const float* gx, const float* whh, const float
   p.error = (unsigned*)workspace;
   p.ticket = (unsigned*)((char*)workspace + 64);
   p.xch = (unsigned long long*)((char*)workspace + 128);
-  // granules and the ticket start from zero on EVERY launch (a memset node when captured); the error word is sticky
-  if (hipMemsetAsync((char*)workspace + 64, 0, 64 + gran, (hipStream_t)stream) != hipSuccess) return AC_ERR_LAUNCH;
+  // Granules and the ticket start from zero on EVERY launch; the error word is sticky.  By a KERNEL, not hipMemsetAsync: as
+  // a memset node of a captured graph the clearing was not reliably ordered before the kernel node that follows it in
+  // replays (rocm 7.2: with the host synchronised before a replay the tickets carried on from the previous launch, every
+  // workgroup took itself for a surplus one and returned - a stale layer output; with the frozen Cnn14 of the next iteration
+  // running beside the step the clearing landed in the middle of the recurrence - partner timeouts).
+  {
+    const unsigned words = (unsigned)((64 + gran) / 8);
+    hipLaunchKernelGGL(gru_split_reset_kernel, dim3((words + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (unsigned long long*)((char*)workspace + 64), words);
+  }
   hipLaunchKernelGGL(gru_layer_split_kernel, dim3(2 * GQ * B), dim3(256), 0, (hipStream_t)stream, p);
   return ac_check_launch();
 }

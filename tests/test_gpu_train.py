@@ -833,7 +833,8 @@ def test_cnn_look_ahead_is_the_same_training_trajectory(train_model, state4981):
         wav = torch.from_numpy(Pr.synthetic_wav(B, L, seed=4 + k, varied=True)).cuda()
         cap = torch.tensor([[1, 9 + k, 30, 2, 0], [1, 7, 7 + k, 12, 2]])
         batches.append({"mode": "train", "wav": wav, "wav_len": [L, L - 16000 * k], "specaug": True, "cap": cap.cuda(),
-                        "cap_len": np.array([4, 5]), "ss_ratio": 0.7})
+                        "cap_len": np.array([4, 5]), "ss_ratio": 1.0})   # teacher forced: a free-running pass would turn a
+        #                                       last-bit difference of a logit into another token now and then - chaos, not schedule
 
     def run(look_ahead):
         model.load_state_dict(state4981, strict=True)
@@ -846,6 +847,7 @@ def test_cnn_look_ahead_is_the_same_training_trajectory(train_model, state4981):
             nxt = batches[(it + 1) % 2] if look_ahead and it < 4 else None
             losses.append(float(eng.step(batches[it % 2], opt, next_batch=nxt)["loss"]))
         torch.cuda.synchronize()
+        assert eng.skipped_updates() == 0 and not eng.gru_timeout()
         return losses, eng.flat.flat.clone()
 
     plain, p0 = run(False)
@@ -856,4 +858,5 @@ def test_cnn_look_ahead_is_the_same_training_trajectory(train_model, state4981):
     assert all(abs(a - b) <= 5e-6 * abs(a) for a, b in zip(plain, ahead))
     # (Adam turns a last-bit difference of a near-zero gradient into a full +-lr step of that one parameter: the mean
     # over the 10.7 M parameters is what shows that the trajectories coincide)
-    assert float((p0 - p1).abs().mean()) <= 1e-7 and float((p0 - p1).abs().max()) <= 5e-3
+    # ... and a single parameter can be off by at most 2 * lr per iteration (both runs stepping it in opposite directions)
+    assert float((p0 - p1).abs().mean()) <= 1e-7 and float((p0 - p1).abs().max()) <= 2 * 1e-3 * 5 * 1.01
