@@ -860,3 +860,38 @@ def test_cnn_look_ahead_is_the_same_training_trajectory(train_model, state4981):
     # over the 10.7 M parameters is what shows that the trajectories coincide)
     # ... and a single parameter can be off by at most 2 * lr per iteration (both runs stepping it in opposite directions)
     assert float((p0 - p1).abs().mean()) <= 1e-7 and float((p0 - p1).abs().max()) <= 2 * 1e-3 * 5 * 1.01
+
+
+def test_graph_replay_after_host_sync_equals_eager(train_model, state4981):
+    """Replayed iterations must not depend on what the host did between them.  The split GRU kernel's ticket / granule
+    clearing used to be a hipMemsetAsync: as a memset node it was not reliably ordered before the kernel node in replays,
+    and with the host synchronised before a replay every workgroup took itself for a surplus one and returned (a stale layer
+    output: losses 6.70 / 5.92 instead of 6.73 / 5.81 from the third iteration on).  Eager and graph, each with a device
+    synchronisation before every step, give the same trajectory."""
+    from audiocaption_amd import procedural as Pr
+    from audiocaption_amd.optim import FusedAdam
+    from audiocaption_amd.train import TrainEngine
+    model = train_model
+    B, L = 2, 96000
+    batches = []
+    for k in range(2):
+        wav = torch.from_numpy(Pr.synthetic_wav(B, L, seed=4 + k, varied=True)).cuda()
+        cap = torch.tensor([[1, 9 + k, 30, 2, 0], [1, 7, 7 + k, 12, 2]])
+        batches.append({"mode": "train", "wav": wav, "wav_len": [L, L - 16000 * k], "specaug": True, "cap": cap.cuda(),
+                        "cap_len": np.array([4, 5]), "ss_ratio": 1.0})
+
+    def run(use_graph):
+        model.load_state_dict(state4981, strict=True)
+        model.train()
+        eng = TrainEngine(model, seed=77)
+        opt = FusedAdam([p for p in model.parameters() if p.requires_grad], lr=1e-3)
+        losses = []
+        for it in range(5):
+            torch.cuda.synchronize()
+            losses.append(float(eng.step(batches[it % 2], opt, use_graph=use_graph)["loss"]))
+        assert eng.skipped_updates() == 0 and not eng.gru_timeout()
+        return losses
+
+    eager, graph = run(False), run(True)
+    print("losses eager", eager, "graph", graph)
+    assert all(abs(a - b) <= 5e-6 * abs(a) for a, b in zip(eager, graph))
