@@ -209,6 +209,9 @@ __global__ __launch_bounds__(256) void gru_layer_split_kernel(GruSplitParams p) 
     }
     // A SEPARATE statement, not an else-branch: publishers (kq = 0) and pollers share waves, and a wave that entered the
     // polling side first would spin while its own publishing lanes are masked off - every part waiting for every other.
+    // The empty asm is a compiler barrier for memory operations: nothing else stops hipcc from placing the polling loop -
+    // relaxed atomics on other addresses - ahead of the publishing store (it did, in a multi-sequence variant of this kernel).
+    asm volatile("" ::: "memory");
     if (kq != 0 && step + 1 < len) {
       // another part's value j of h(t) (not needed after the last step)
       unsigned long long* gq = theirs + (step & 1) * HQ + j;
