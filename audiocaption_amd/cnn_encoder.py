@@ -100,9 +100,10 @@ def _conv_wino43(x, w, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode
     """The "wino43" tier's launcher: ``w`` is (F(2,3) pack, F(4,3) pack or None).  F(4,3) when the kernel covers the layer
     and the launch fills the chip (a workgroup owns a CU: single clips run the K-sliced F(2,3) form instead)."""
     w23, w43 = w if isinstance(w, tuple) else (w, None)
-    # (batches of uneven lengths keep block 6 on F(2,3) - the caller passes it the F(2,3) pack only: its tiles are taller than a
-    # clip, nothing can be skipped there anyway, and the quad-wide input window of F(4,3) would cost every layer upstream
-    # four more valid rows per clip - ``rows_needed``)
+    # (AUDIOCAPTION_RAGGED_EXACT=1 only: batches of uneven lengths then keep block 6 on F(2,3) - the caller passes it the F(2,3)
+    # pack only: its tiles are taller than a clip, nothing can be skipped there anyway, and the quad-wide input window of
+    # F(4,3) would cost every layer upstream four more valid rows per clip - ``rows_needed``.  In the default mode ragged
+    # batches run F(4,3) on block 6 too and valid frames are within 5e-5 of the dense run, not bit-identical)
     if w43 is not None and (mode != 1 if W == 2 else mode != 2) and Hp % 4 == 0 \
             and K.wino43_workgroups(B, Hp, W, Cout) >= W43_MIN_WORKGROUPS:
         return K.conv3x3_bn_relu_wino43(x, w43, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode, need=need,

@@ -74,6 +74,20 @@ __device__ __forceinline__ float ac_swish_exact(float v) { return v * ac_sigmoid
 // (s_waitcnt vmcnt(0)), which would force every global prefetch in flight to land at each barrier.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: remembered per (launch site, device), so
+// that a process which touches a second GPU sets it there as well (a plain function-local flag would skip it and the
+// launch would fail with more than 64 KiB of dynamic LDS).  One word per site: bit d = device d has the attribute.
+struct AcLdsAttr { unsigned long long done = 0; };
+static inline int ac_allow_lds(const void* kernel, int bytes, AcLdsAttr* st) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return AC_ERR_LAUNCH;
+  const bool tracked = dev >= 0 && dev < 64;
+  if (tracked && ((__atomic_load_n(&st->done, __ATOMIC_ACQUIRE) >> dev) & 1ull)) return AC_OK;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return AC_ERR_LAUNCH;
+  if (tracked) __atomic_fetch_or(&st->done, 1ull << dev, __ATOMIC_RELEASE);
+  return AC_OK;
+}
+
 static inline int ac_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? AC_OK : AC_ERR_LAUNCH;

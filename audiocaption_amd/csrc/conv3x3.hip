@@ -941,13 +941,8 @@ int launch_conv_bf16x3(const ConvParams& p, hipStream_t s) {
   const int TC = 1 << p.tc_log2, TR = 128 >> p.tc_log2;
   const int pitch = (TC + 2) * BROW + patch_row_pad_slots(TC) * 8;
   const size_t lds = ((size_t)(TR + 2) * pitch * 2 + (size_t)4 * BN * BROW) * 2;  // bytes (bf16 elements x 2)
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv3x3_bf16x3_kernel<BN, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess)
-      return AC_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static AcLdsAttr lds_attr;   // per device
+  if (ac_allow_lds((const void*)conv3x3_bf16x3_kernel<BN, MODE>, 160 * 1024, &lds_attr) != AC_OK) return AC_ERR_LAUNCH;
   hipLaunchKernelGGL((conv3x3_bf16x3_kernel<BN, MODE>), dim3(grid), dim3(256), lds, s, p);
   return ac_check_launch();
 }

@@ -411,19 +411,16 @@ __global__ __launch_bounds__(256, 1) void block1_w4_kernel(B1Params p) {
 
 template <bool FUSED>
 int launch_b1(const B1Params& p, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)block1_w4_kernel<FUSED>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
-        hipSuccess)
-      return AC_ERR_LAUNCH;
-    attr_set = true;
-  }
-  static int cus = 0;
+  static AcLdsAttr lds_attr;   // per device
+  if (ac_allow_lds((const void*)block1_w4_kernel<FUSED>, 160 * 1024, &lds_attr) != AC_OK) return AC_ERR_LAUNCH;
+  static int cus_of[64];   // compute units per device (one persistent workgroup each), 0 = not asked yet
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return AC_ERR_LAUNCH;
+  if (dev >= 0 && dev < 64) cus = __atomic_load_n(&cus_of[dev], __ATOMIC_RELAXED);
   if (!cus) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return AC_ERR_LAUNCH;
-    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return AC_ERR_LAUNCH;
+    if (cus <= 0) cus = 256;
+    if (dev >= 0 && dev < 64) __atomic_store_n(&cus_of[dev], cus, __ATOMIC_RELAXED);
   }
   const unsigned grid = (unsigned)(p.tiles < cus ? p.tiles : cus);
   hipLaunchKernelGGL(block1_w4_kernel<FUSED>, dim3(grid), dim3(256), (size_t)B1_LDS, s, p);

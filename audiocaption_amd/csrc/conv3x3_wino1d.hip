@@ -622,13 +622,8 @@ int launch_w1(W1Params p, hipStream_t s) {
   else if (p.map_mode == 4) grid = (unsigned)(((p.MT / p.mt_cols + 7) / 8) * 8 * p.mt_cols * p.NT);
   else grid = (unsigned)(p.MT * p.NT);
   constexpr size_t lds = (size_t)2 * G::VBUF * 2;   // two buffers of 4 positions x (hi, lo) planes, bf16
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv3x3_w1_kernel<MODE, TC, FULLW, WIDE, CW>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return AC_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static AcLdsAttr lds_attr;   // per device
+  if (ac_allow_lds((const void*)conv3x3_w1_kernel<MODE, TC, FULLW, WIDE, CW>, 160 * 1024, &lds_attr) != AC_OK) return AC_ERR_LAUNCH;
   int slices = 1;
   if (p.partial) {
     slices = w1_slices(grid, p.Cin / KS, &p.ksteps);

@@ -501,13 +501,8 @@ int launch_w4(W4Params p, hipStream_t s) {
   else grid = (unsigned)(p.MT * p.NT);
   constexpr size_t lds = (size_t)2 * G::VBUF > (size_t)4 * W4_OUT_TILE ? (size_t)2 * G::VBUF : (size_t)4 * W4_OUT_TILE;
   static_assert(lds <= 160 * 1024, "V planes exceed the LDS");
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv3x3_w4_kernel<MODE, TC, MW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess)
-      return AC_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static AcLdsAttr lds_attr;   // per device
+  if (ac_allow_lds((const void*)conv3x3_w4_kernel<MODE, TC, MW>, 160 * 1024, &lds_attr) != AC_OK) return AC_ERR_LAUNCH;
   hipLaunchKernelGGL((conv3x3_w4_kernel<MODE, TC, MW>), dim3(grid), dim3(256), lds, s, p);
   return ac_check_launch();
 }
@@ -539,7 +534,7 @@ static int w4_dispatch(const float* in, const void* wfrag, const float* scale, c
     return AC_ERR_ARG;
   if (W == 2 ? (mode != MODE_FULL && mode != MODE_MEANW) : (mode != MODE_FULL && mode != MODE_POOL)) return AC_ERR_ARG;
   if (mode == MODE_MEANW && drop.thresh != 0) return AC_ERR_ARG;   // dropout sits BEFORE the mean over mel: use mode 0
-  if ((unsigned long long)B * Hp >= (1ull << 29)) return AC_ERR_ARG;          // row indices are ints (x 4 in the epilogue)
+  if ((unsigned long long)B * Hp >= (1ull << 23)) return AC_ERR_ARG;          // the epilogue finds a row's clip offset with FastDiv4::mod (float reciprocal: exact below 2^23 rows); callers chunk clips beyond it
   if ((unsigned long long)(Cin / 16) * 18 * (Cout / 32) * 2048 >= (1ull << 31)) return AC_ERR_ARG;   // packed weights: one descriptor
   W4Params p;
   p.in = in; p.wpk = wfrag; p.scale = scale; p.shift = shift; p.out = out;

@@ -253,13 +253,8 @@ int ed_lds_limit() {
 
 template <int K, int S>
 int launch_expand_dw(EdP p, int B, int groups, size_t lds, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)expand_dw_kernel<K, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) !=
-        hipSuccess)
-      return AC_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static AcLdsAttr lds_attr;   // per device
+  if (ac_allow_lds((const void*)expand_dw_kernel<K, S>, 156 * 1024, &lds_attr) != AC_OK) return AC_ERR_LAUNCH;
   dim3 grid((p.To + p.R - 1) / p.R, B, groups);
   hipLaunchKernelGGL((expand_dw_kernel<K, S>), grid, dim3(256), lds, st, p);
   return ac_check_launch();

@@ -211,6 +211,11 @@ __global__ __launch_bounds__(256) void gru_layer_split_kernel(GruSplitParams p) 
     // polling side first would spin while its own publishing lanes are masked off - every part waiting for every other.
     // The empty asm is a compiler barrier for memory operations: nothing else stops hipcc from placing the polling loop -
     // relaxed atomics on other addresses - ahead of the publishing store (it did, in a multi-sequence variant of this kernel).
+    // Pinned twice: __atomic_signal_fence is the language-level statement (atomic operations of this thread are not moved
+    // across a seq_cst signal fence: no instruction, compiler ordering only), the empty asm is the same for every other
+    // memory operation.  tests/test_cpu_host.py::test_split_gru_publishes_before_it_polls checks the order in the ISA of the
+    // library that ships (the sc1 granule store precedes the first sc1 granule load of the loop body).
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
     asm volatile("" ::: "memory");
     if (kq != 0 && step + 1 < len) {
       // another part's value j of h(t) (not needed after the last step)
@@ -285,12 +290,8 @@ extern "C" int ac_gru_layer(const float* gx, const float* whhT, const float* bhh
   GruParams p;
   p.gx = gx; p.whhT = whhT; p.bhh = bhh; p.lens = lens; p.out = out; p.B = B; p.T = T;
   const size_t lds = (size_t)GRU_KLDS * 3 * H * sizeof(float);
-  static bool allowed = false;
-  if (!allowed) {
-    if (hipFuncSetAttribute((const void*)gru_layer_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return AC_ERR_LAUNCH;
-    allowed = true;
-  }
+  static AcLdsAttr lds_attr;   // per device
+  if (ac_allow_lds((const void*)gru_layer_kernel, (int)lds, &lds_attr) != AC_OK) return AC_ERR_LAUNCH;
   hipLaunchKernelGGL(gru_layer_kernel, dim3(2 * B), dim3(768), lds, (hipStream_t)stream, p);
   return ac_check_launch();
 }

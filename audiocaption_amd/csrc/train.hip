@@ -1402,13 +1402,7 @@ static size_t attn_lds_bytes(int lmax, int tkmax, bool bwd) {
   if (bwd) f += (size_t)lmax * HDP + (size_t)lmax * (tkmax + 1);
   return f * sizeof(float);
 }
-static int attn_allow_lds(const void* kern, bool* done) {
-  if (*done) return AC_OK;
-  if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_MAX) != hipSuccess)
-    return AC_ERR_LAUNCH;
-  *done = true;
-  return AC_OK;
-}
+static int attn_allow_lds(const void* kern, AcLdsAttr* done) { return ac_allow_lds(kern, ATT_LDS_MAX, done); }
 
 int ac_attn_seq_fwd(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv, float* o, long ldo,
                     float* P, int pl, int ptk, const int* qrow0, const int* qlen, const int* krow0, const int* klen,
@@ -1427,7 +1421,7 @@ int ac_attn_seq_fwd(const float* q, long ldq, const float* k, long ldk, const fl
   p.lmax = lmax; p.tkmax = tkmax;
   const size_t lds = attn_lds_bytes(lmax, tkmax, false);
   if (lds > (size_t)ATT_LDS_MAX) return AC_ERR_ARG;
-  static bool allowed = false;
+  static AcLdsAttr allowed;   // per device
   if (attn_allow_lds((const void*)attn_seq_fwd_kernel, &allowed) != AC_OK) return AC_ERR_LAUNCH;
   hipLaunchKernelGGL(attn_seq_fwd_kernel, dim3(nseq, nhead), dim3(256), lds, (hipStream_t)stream, p);
   return ac_check_launch();
@@ -1451,7 +1445,7 @@ int ac_attn_seq_bwd(const float* q, long ldq, const float* k, long ldk, const fl
   p.lmax = lmax; p.tkmax = tkmax;
   const size_t lds = attn_lds_bytes(lmax, tkmax, true);
   if (lds > (size_t)ATT_LDS_MAX) return AC_ERR_ARG;
-  static bool allowed = false;
+  static AcLdsAttr allowed;   // per device
   if (attn_allow_lds((const void*)attn_seq_bwd_kernel, &allowed) != AC_OK) return AC_ERR_LAUNCH;
   hipLaunchKernelGGL(attn_seq_bwd_kernel, dim3(nseq, nhead), dim3(256), lds, (hipStream_t)stream, p);
   return ac_check_launch();
@@ -1527,12 +1521,8 @@ int ac_gru_layer_train(const float* gx, const float* whhT, const float* bhh, con
                        int B, int T, int hidden, void* stream) {
   if (!gx || !whhT || !bhh || !lens || !out || !save || B <= 0 || T <= 0 || hidden != H) return AC_ERR_ARG;
   const size_t lds = (size_t)GRU_KLDS * 3 * H * sizeof(float);
-  static bool allowed = false;
-  if (!allowed) {
-    if (hipFuncSetAttribute((const void*)gru_train_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return AC_ERR_LAUNCH;
-    allowed = true;
-  }
+  static AcLdsAttr lds_attr;   // per device
+  if (ac_allow_lds((const void*)gru_train_fwd_kernel, (int)lds, &lds_attr) != AC_OK) return AC_ERR_LAUNCH;
   hipLaunchKernelGGL(gru_train_fwd_kernel, dim3(2 * B), dim3(768), lds, (hipStream_t)stream, gx, whhT, bhh, lens, out, save, T);
   return ac_check_launch();
 }
@@ -1542,12 +1532,8 @@ int ac_gru_layer_bwd(const float* dout, const float* out, const float* save, con
   if (!dout || !out || !save || !whh || !lens || !dgx || !dgh || !hprev || B <= 0 || T <= 0 || hidden != H)
     return AC_ERR_ARG;
   const size_t lds = (size_t)GRU_KLDS * 3 * H * sizeof(float);
-  static bool allowed = false;
-  if (!allowed) {
-    if (hipFuncSetAttribute((const void*)gru_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return AC_ERR_LAUNCH;
-    allowed = true;
-  }
+  static AcLdsAttr lds_attr;   // per device
+  if (ac_allow_lds((const void*)gru_bwd_kernel, (int)lds, &lds_attr) != AC_OK) return AC_ERR_LAUNCH;
   hipLaunchKernelGGL(gru_bwd_kernel, dim3(2 * B), dim3(768), lds, (hipStream_t)stream, dout, out, save, whh, lens, dgx, dgh,
                      hprev, T);
   return ac_check_launch();

@@ -36,9 +36,16 @@ class WaveformIngest:
 
     def __init__(self, orig_sr, target_sr, min_duration=0.32, device="cuda", audio_duration=None, rng=None):
         """``audio_duration`` (seconds, caption_dataset.py:58-66): every clip comes out with exactly
-        ``int(audio_duration * target_sr)`` samples - longer clips are cropped at ``rng.randint(0, excess)`` (default: the
-        ``random`` module, one draw per longer clip in batch order, like the dataset's ``__getitem__`` calls), shorter ones
-        zero-padded."""
+        ``int(audio_duration * target_sr)`` samples - longer clips are cropped at an offset drawn uniformly from
+        ``0 .. excess`` INCLUSIVE like ``random.randint(0, excess)`` (caption_dataset.py:124; one draw per longer clip in
+        batch order, like the dataset's ``__getitem__`` calls), shorter ones zero-padded.  ``rng``: the ``random`` module
+        (default), a ``random.Random``, a ``numpy.random.Generator`` or a ``numpy.random.RandomState`` - each is asked through
+        its own inclusive-range call (``_draw_offset``).
+
+        One instance serves one caller at a time: ``__call__`` holds a lock (the two pinned staging buffers, their events and
+        the turn counter are shared state); loader threads that should pack in parallel take one instance each."""
+        import threading
+        self._lock = threading.Lock()
         self.orig_sr, self.target_sr = int(orig_sr), int(target_sr)
         self.min_length = int(min_duration * target_sr)
         self.num_audio_samples = int(audio_duration * target_sr) if audio_duration is not None else None
@@ -54,6 +61,17 @@ class WaveformIngest:
         else:
             self.width, self.orig, self.new = 0, 1, 1
             self.kernel = self.tap_lo = self.tap_hi = None
+
+    def _draw_offset(self, excess):
+        """Uniform integer in [0, excess], whatever the generator's own convention for the upper bound is."""
+        rng = self.rng
+        if hasattr(rng, "integers"):                       # numpy.random.Generator: upper bound exclusive
+            return int(rng.integers(0, excess + 1))
+        if hasattr(rng, "randrange"):                      # random / random.Random: randint(0, n) == randrange(n + 1)
+            return int(rng.randint(0, excess))
+        if hasattr(rng, "randint"):                        # numpy.random.RandomState: upper bound exclusive
+            return int(rng.randint(0, excess + 1))
+        raise TypeError("rng must be the random module, a random.Random, a numpy Generator or a numpy RandomState")
 
     def _staging(self, n, dtype):
         """One of two page-locked staging buffers of at least n elements (kept between calls, grown by doubling); the one
@@ -85,6 +103,10 @@ class WaveformIngest:
         "blacklist_aid"} with the keys of ``WavPadCollate``."""
         if self.device.type != "cuda":
             raise _lib.HipLibraryError("WaveformIngest runs on a ROCm device; there is no CPU fallback")
+        with self._lock:
+            return self._ingest(data_list)
+
+    def _ingest(self, data_list):
         lib = _lib.load()
         aids, clips, lens, black, starts, kept = [], [], [], [], [], []
         n_fix = self.num_audio_samples
@@ -98,7 +120,7 @@ class WaveformIngest:
             aids.append(aid)
             clips.append(np.asarray(wav))
             lens.append(olen)
-            starts.append(self.rng.randint(0, olen - n_fix) if n_fix is not None and olen > n_fix else 0)
+            starts.append(self._draw_offset(olen - n_fix) if n_fix is not None and olen > n_fix else 0)
             kept.append(final)
         if not clips:
             raise ValueError("every clip is shorter than min_duration")

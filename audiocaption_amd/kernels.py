@@ -195,6 +195,18 @@ def conv3x3_block1_wino43(x0, w1, scale1, shift1, wfrag2, scale2, shift2, out, B
     ``pack_conv_weight_wino43_frag``; ``need`` / ``dropout`` as for ``conv3x3_bn_relu_wino1d``."""
     cf, mul, add = need if need is not None else (None, 0, 0)
     dp, dseed, ddev = dropout if dropout is not None else (0.0, 0, None)
+    hook = CONV_LAUNCH_HOOK
+    if hook is not None:
+        info = {"B": B, "H": H, "Hp": Hp, "W": 64, "Cin": 1, "Cout": 64, "mode": 1, "algo": "block1_w4"}
+        hook("pre", info)
+        try:
+            return _block1_wino43(x0, w1, scale1, shift1, wfrag2, scale2, shift2, out, B, Hp, H, cf, mul, add, dp, dseed, ddev)
+        finally:
+            hook("post", info)
+    return _block1_wino43(x0, w1, scale1, shift1, wfrag2, scale2, shift2, out, B, Hp, H, cf, mul, add, dp, dseed, ddev)
+
+
+def _block1_wino43(x0, w1, scale1, shift1, wfrag2, scale2, shift2, out, B, Hp, H, cf, mul, add, dp, dseed, ddev):
     check(_lib.load().ac_conv3x3_block1_wino43(ptr(x0), ptr(w1), ptr(scale1), ptr(shift1), ptr(wfrag2), ptr(scale2),
                                                ptr(shift2), ptr(out), B, Hp, H, ptr(cf), int(mul), int(add), float(dp),
                                                int(dseed), ddev, stream()), "ac_conv3x3_block1_wino43")

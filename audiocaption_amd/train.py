@@ -971,8 +971,13 @@ class TrainEngine:
         """Launch the frozen Cnn14 forward (log-mel, SpecAugment, conv stack with its dropout) of a batch on the side stream
         NOW, for the iteration that will run with dropout seed ``seed``: it is matrix-bound and does not depend on any
         trainable parameter, so it overlaps the latency-bound GRU / decoder forward and backward of the iteration in
-        flight (3 of ~7.5 ms at batch 32).  ``step`` picks the result up when it is handed the same ``wav`` tensor; the
-        masks are those the in-line forward would draw (same counter hash, same seed word): same loss, same gradients."""
+        flight (3 of ~7.5 ms at batch 32).  ``step`` picks the result up when it is handed the same batch - the same ``wav``
+        storage at the same version counter and shape, the same SpecAugment flag, train / eval mode and dropout seed
+        (``_pf_key``); anything else (a loader that refills one static tensor in place, an explicit ``dropout_seed``, a
+        train-mode ``forward`` in between that advanced the seed) discards the look-ahead and the Cnn14 forward is run
+        again for the batch in hand.  Hand ``next_batch`` fresh tensors (or at least do not write into them before the
+        step that consumes them).  The masks are those the in-line forward would draw (same counter hash, same seed
+        word): same loss, same gradients."""
         model = self.model
         enc = model.encoder
         wav = input_dict["wav"]
@@ -1004,7 +1009,14 @@ class TrainEngine:
             ev = torch.cuda.Event()
             ev.record(side)
         attn.record_stream(cur)
-        self._pf = {"wav": wav, "attn": attn, "event": ev, "seed": int(seed)}
+        self._pf = {"wav": wav, "attn": attn, "event": ev, "seed": int(seed), "key": self._pf_key(input_dict, seed)}
+
+    def _pf_key(self, input_dict, seed):
+        """What a look-ahead Cnn14 result was computed FROM: the step that consumes it must present the same."""
+        wav = input_dict["wav"]
+        cnn = self.model.encoder.cnn
+        return (wav.data_ptr(), wav._version, tuple(wav.shape), wav.dtype, bool(input_dict.get("specaug", False)),
+                bool(cnn.training), int(seed))
 
     def step(self, input_dict, optimizer, smoothing=0.1, max_grad_norm=1.0, process_group=None, use_graph=True,
              next_batch=None):
@@ -1027,15 +1039,17 @@ class TrainEngine:
         # with a look-ahead in play this iteration's own Cnn14 forward goes through the side stream as well.
         if input_dict.get("_cnn_attn") is None and (next_batch is not None or getattr(self, "_pf", None) is not None):
             pf = getattr(self, "_pf", None)
-            if pf is None or pf["wav"] is not input_dict["wav"]:
-                self.prefetch_cnn(input_dict, int(input_dict.get("dropout_seed", self.seed)))
+            want = int(input_dict.get("dropout_seed", self.seed))   # the caller's seed wins over the one guessed a step ahead
+            if pf is None or pf["key"] != self._pf_key(input_dict, want):
+                self.prefetch_cnn(input_dict, want)
                 pf = self._pf
             self._pf = None
             torch.cuda.current_stream(input_dict["wav"].device).wait_event(pf["event"])
-            input_dict = dict(input_dict, _cnn_attn=pf["attn"], dropout_seed=pf["seed"])
+            input_dict = dict(input_dict, _cnn_attn=pf["attn"], dropout_seed=want)
         st = self._prepare(input_dict)
         if next_batch is not None:
-            self.prefetch_cnn(next_batch, self.seed)   # the seed the next iteration draws by default
+            # the next iteration's own seed if it carries one, else the one it will draw by default
+            self.prefetch_cnn(next_batch, int(next_batch.get("dropout_seed", self.seed)))
         st["steps"] += 1
         world = dist_world_size(process_group)
         # Several ranks: the backward runs as TWO parts - up to the end of the decoder's backward, then the GRU's backward

@@ -86,8 +86,11 @@ int ac_conv3x3_bn_relu_bf16x3_gw(const float* in, const void* wfrag, const float
  * Ragged batches (the reference pads every clip to the batch maximum and convolves the padding, collate_func.py:29-32,
  * cnn_encoder.py:446-450): clip_frames (device int32 [B], may be NULL) = every clip's own attn_emb_len; workgroups whose
  * output rows all lie at or beyond need_mul * clip_frames[b] + need_add of their clip(s) skip the convolution and store
- * zeros.  The caller derives (need_mul, need_add) per layer from the receptive field downstream, so that every output
- * frame below clip_frames[b] - all the temporal encoder reads (model_util.py:10-27) - is bit-identical. */
+ * zeros.  The caller derives (need_mul, need_add) per layer from the receptive field downstream.  With this F(2,3) kernel
+ * every output frame below clip_frames[b] - all the temporal encoder reads (model_util.py:10-27) - is then bit-identical
+ * to the run that convolves the padding.  The F(4,3) kernels below form a row quad from six input rows: the same
+ * (need_mul, need_add) leave valid frames within the tier's own error of the dense run (measured <= 5e-5, token ids
+ * equal), and bit-identity needs the wider windows of cnn_encoder.rows_needed(quads=True) (AUDIOCAPTION_RAGGED_EXACT=1). */
 int ac_conv3x3_bn_relu_wino1d(const float* in, const void* wfrag, const float* scale, const float* shift,
                               float* out, int B, int Hp, int H, int W, int Cin, int Cout, int mode,
                               int map_mode, const int* clip_frames, int need_mul, int need_add, void* stream);
@@ -121,7 +124,9 @@ int ac_conv3x3_bn_relu_wino1d_splitk(const float* in, const void* wfrag, const f
  * Hp % 4 == 0; wfrag
  * [Cin/16][3 kx x 6 positions][Cout/32][hi, lo][64 lanes][8] bf16 (U = G g in f64, then split).  tiles_per_wave: 3 (288
  * accumulators, 9 MFMAs per weight fragment pair), 2, or 0 = chosen by the launch's last-round occupancy.  The input is
- * addressed through a buffer descriptor rebased per workgroup, so any B * Hp * W * Cin is accepted (B * Hp < 2^29).
+ * addressed through a buffer descriptor rebased per workgroup, so any B * Hp * W * Cin is accepted (B * Hp < 2^23 rows: the
+ * epilogue's row -> clip arithmetic; callers chunk clips beyond it).  Ragged batches: see the contract note above - valid
+ * frames within 5e-5 of the dense run with the F(2,3) windows, bit-identical with the quad-wide ones.
  * AC_ERR_ARG for shapes outside this list. */
 int ac_conv3x3_bn_relu_wino43(const float* in, const void* wfrag, const float* scale, const float* shift, float* out,
                               int B, int Hp, int H, int W, int Cin, int Cout, int mode, int map_mode, int tiles_per_wave,

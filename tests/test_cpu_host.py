@@ -287,3 +287,48 @@ def test_contrastive_kd_wrapper_loss():
     # clear refusal instead of a KeyError on the training output or a loss that trains only the heads
     with pytest.raises(NotImplementedError, match="head-only"):
         w({"feat": feat, "mode": "train", "tchr_output": {"embedding": tchr}})
+
+
+def test_split_gru_publishes_before_it_polls(tmp_path):
+    """The split GRU kernel's hand-off (csrc/gru.hip) lives on PROGRAM ORDER inside a wave: the lanes kq = 0 publish their
+    hidden value as a tagged granule, the other lanes of the same wave then poll their partners' granules.  Relaxed atomics
+    on different addresses may be reordered by the compiler (it did once, in a sibling variant: every part then waits for
+    every other).  The source pins the order with a signal fence + a compiler barrier; this test checks the ISA hipcc emits
+    for the shipped flags: inside the recurrence loop the write-through (sc1) granule store comes before the first sc1
+    granule load, and the sleeping re-poll loop comes after both."""
+    import subprocess
+    asm = tmp_path / "gru.s"
+    cmd = [build._hipcc(), "-x", "hip", "-S", "--cuda-device-only", os.path.join(build.CSRC, "gru.hip"), "-o", str(asm)] \
+        + [f for f in build.FLAGS if f != "-fPIC"] + build.NO_PACKED_F32
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()
+    text = asm.read_text().split("\n")
+    start = next(i for i, l in enumerate(text) if re.match(r"^_ZN.*gru_layer_split_kernel.*:", l))
+    end = next(i for i in range(start, len(text)) if text[i].startswith(".Lfunc_end"))
+    body = [l.strip() for l in text[start:end]]
+    stores = [i for i, l in enumerate(body) if l.startswith("global_store_dwordx2") and " sc1" in l]
+    loads = [i for i, l in enumerate(body) if l.startswith("global_load_dwordx2") and " sc1" in l]
+    sleeps = [i for i, l in enumerate(body) if l.startswith("s_sleep")]
+    assert len(stores) == 1, "one granule store per step"
+    assert len(loads) == 2 and len(sleeps) == 1, "a first poll and a sleeping re-poll"
+    assert stores[0] < loads[0] < sleeps[0] < loads[1], (stores, loads, sleeps)
+    # the two sit in consecutive blocks of the loop body: only forward skips (exec-mask branches) between them
+    between = body[stores[0] + 1:loads[0]]
+    assert len(between) <= 32 and not any(l.startswith("s_barrier") or l.startswith("s_sleep") for l in between), between
+
+
+def test_ingest_crop_offsets_cover_the_inclusive_range_for_every_rng_kind():
+    """caption_dataset.py:124 draws ``random.randint(0, excess)`` - both ends included.  ``WaveformIngest`` accepts the
+    ``random`` module, a ``random.Random``, a numpy ``Generator`` and a numpy ``RandomState`` (whose own upper bounds are
+    exclusive): every one must reach offset ``excess`` and none may exceed it."""
+    import random
+    from audiocaption_amd.ingest import WaveformIngest
+    for rng in (random, random.Random(1), np.random.default_rng(1), np.random.RandomState(1)):
+        ing = WaveformIngest(32000, 32000, audio_duration=1.0, rng=rng)
+        seen = {ing._draw_offset(3) for _ in range(400)}
+        assert seen == {0, 1, 2, 3}, (type(rng), seen)
+    r1, r2 = random.Random(7), random.Random(7)
+    ing = WaveformIngest(32000, 32000, audio_duration=1.0, rng=r1)
+    assert [ing._draw_offset(20000) for _ in range(5)] == [r2.randint(0, 20000) for _ in range(5)]   # the dataset's own draws
+    with pytest.raises(TypeError):
+        WaveformIngest(32000, 32000, audio_duration=1.0, rng=object())._draw_offset(3)

@@ -862,6 +862,88 @@ def test_cnn_look_ahead_is_the_same_training_trajectory(train_model, state4981):
     assert float((p0 - p1).abs().mean()) <= 1e-7 and float((p0 - p1).abs().max()) <= 2 * 1e-3 * 5 * 1.01
 
 
+def test_cnn_look_ahead_keeps_the_callers_seed_and_notices_a_refilled_batch(train_model, state4981):
+    """The look-ahead must not change WHAT is computed: (a) an explicit ``dropout_seed`` (resume, reproducibility) wins over
+    the seed the look-ahead guessed a step earlier; (b) a loader that refills ONE static ``wav`` tensor in place gets the
+    features of the new contents, not those computed from the old ones (the look-ahead is keyed on storage, version counter,
+    shape, SpecAugment flag, mode and seed - ``TrainEngine._pf_key``); (c) a train-mode ``forward`` between two steps, which
+    advances the engine's seed, does not make the next step reuse masks that forward already drew."""
+    import random
+    from audiocaption_amd import procedural as Pr
+    from audiocaption_amd.optim import FusedAdam
+    from audiocaption_amd.train import TrainEngine
+    model = train_model
+    B, L = 2, 96000
+    wavs = [torch.from_numpy(Pr.synthetic_wav(B, L, seed=14 + k, varied=True)).cuda() for k in range(3)]
+    cap = torch.tensor([[1, 9, 30, 2, 0], [1, 7, 8, 12, 2]]).cuda()
+
+    def batch(wav, **kw):
+        return dict({"mode": "train", "wav": wav, "wav_len": [L, L - 16000], "specaug": True, "cap": cap,
+                     "cap_len": np.array([4, 5]), "ss_ratio": 1.0}, **kw)
+
+    def run(schedule):
+        model.load_state_dict(state4981, strict=True)
+        model.train()
+        random.seed(3)
+        eng = TrainEngine(model, seed=77)
+        opt = FusedAdam([p for p in model.parameters() if p.requires_grad], lr=1e-3)
+        losses = schedule(eng, opt)
+        torch.cuda.synchronize()
+        assert eng.skipped_updates() == 0 and not eng.gru_timeout()
+        return losses
+
+    seeds = [501, 77, 9000]   # explicit seeds, unrelated to the engine's own sequence
+
+    def plain(eng, opt):
+        return [float(eng.step(batch(wavs[i], dropout_seed=seeds[i]), opt)["loss"]) for i in range(3)]
+
+    def ahead_explicit(eng, opt):   # (a): next_batch carries its own seed
+        out = []
+        for i in range(3):
+            nxt = batch(wavs[i + 1], dropout_seed=seeds[i + 1]) if i < 2 else None
+            out.append(float(eng.step(batch(wavs[i], dropout_seed=seeds[i]), opt, next_batch=nxt)["loss"]))
+        return out
+
+    def ahead_guessed_wrong(eng, opt):   # (a'): the look-ahead guessed the default seed, the step then names another one
+        out = []
+        for i in range(3):
+            nxt = batch(wavs[i + 1]) if i < 2 else None     # no seed: prefetched with the engine's default
+            out.append(float(eng.step(batch(wavs[i], dropout_seed=seeds[i]), opt, next_batch=nxt)["loss"]))
+        return out
+
+    def ahead_refilled(eng, opt):   # (b): one static tensor, refilled in place between the look-ahead and its step
+        static = wavs[0].clone()
+        out = []
+        for i in range(3):
+            cur = batch(static, dropout_seed=seeds[i])
+            out.append(float(eng.step(cur, opt, next_batch=batch(static, dropout_seed=seeds[min(i + 1, 2)]))["loss"]))
+            if i < 2:
+                torch.cuda.synchronize()
+                static.copy_(wavs[i + 1])    # the look-ahead already ran on the OLD contents
+        return out
+
+    ref = run(plain)
+    for name, sched in (("explicit", ahead_explicit), ("guessed", ahead_guessed_wrong), ("refilled", ahead_refilled)):
+        got = run(sched)
+        print(name, ref, got)
+        assert all(abs(a - b) <= 5e-6 * abs(a) for a, b in zip(ref, got)), (name, ref, got)
+
+    # (c) default seeds with a train-mode forward between two steps
+    def plain_fwd(eng, opt):
+        a = float(eng.step(batch(wavs[0]), opt)["loss"])
+        eng.forward(batch(wavs[2]))
+        return [a, float(eng.step(batch(wavs[1]), opt)["loss"])]
+
+    def ahead_fwd(eng, opt):
+        a = float(eng.step(batch(wavs[0]), opt, next_batch=batch(wavs[1]))["loss"])
+        eng.forward(batch(wavs[2]))                     # advances the seed: the look-ahead's guess is stale now
+        return [a, float(eng.step(batch(wavs[1]), opt)["loss"])]
+
+    ref, got = run(plain_fwd), run(ahead_fwd)
+    print("forward between", ref, got)
+    assert all(abs(a - b) <= 5e-6 * abs(a) for a, b in zip(ref, got))
+
+
 def test_graph_replay_after_host_sync_equals_eager(train_model, state4981):
     """Replayed iterations must not depend on what the host did between them.  The split GRU kernel's ticket / granule
     clearing used to be a hipMemsetAsync: as a memset node it was not reliably ordered before the kernel node in replays,
