@@ -65,19 +65,26 @@ def _oracle_in_chunks(state, wav, wav_len, chunk=16):
 
 def _check_against_chunks(out, ref, wav_len):
     """Ids and logits of the batched HIP run against the per-chunk oracle runs, each over the steps ITS chunk decoded (the
-    reference stops a batch when every clip of it has emitted <end>: base.py:206-211)."""
-    worst, compared = 0.0, 0
+    reference stops a batch when every clip of it has emitted <end>: base.py:206-211).  Clip by clip, step by step: the ids
+    must agree wherever the oracle's own top-1 / top-2 margin exceeds 2e-3 (a difference at a near-tie ends the comparison of
+    that clip: what follows was decoded from another prefix); logits are compared on the common prefix."""
+    worst, compared, ties = 0.0, 0, 0
+    seq, logit = out["seq"].cpu(), out["logit"].cpu()
     for k, o in enumerate(ref["per_chunk"]):
         lo = k * ref["chunk"]
-        hi = lo + o["seq"].shape[0]
         st = o["steps"]
-        worst = max(worst, _maxdiff(f"logits clips {lo}..{hi - 1}", out["logit"][lo:hi, :st], o["logit"][:, :st]))
         top2 = o["logit"][:, :st].topk(2, -1).values
-        gap = float((top2[..., 0] - top2[..., 1]).min())
-        if gap > 2e-3:   # a near-tie (never seen on these inputs) would make the id comparison meaningless
-            compared += 1
-            assert torch.equal(out["seq"][lo:hi, :st].cpu(), o["seq"][:, :st]), f"token ids differ in clips {lo}..{hi - 1}"
-    assert compared == len(ref["per_chunk"]), "fixture: every chunk's ids should be comparable"
+        gap = top2[..., 0] - top2[..., 1]
+        for r in range(o["seq"].shape[0]):
+            for t in range(st):
+                worst = max(worst, float((logit[lo + r, t] - o["logit"][r, t]).abs().max()))
+                if int(seq[lo + r, t]) != int(o["seq"][r, t]):
+                    assert float(gap[r, t]) <= 2e-3, f"clip {lo + r} step {t}: ids differ at a margin of {float(gap[r, t]):.2e}"
+                    ties += 1
+                    break
+                compared += 1
+    print(f"worst |logit diff| {worst:.3e} over {compared} (clip, step) pairs with equal ids; {ties} clips left at a near-tie")
+    assert compared >= 8 * len(wav_len) and ties <= len(wav_len) // 8
     return worst
 
 
