@@ -54,6 +54,9 @@ namespace {
 #ifndef W4_ADEPTH   // A fragments are read this many groups ahead (1 or 2)
 #define W4_ADEPTH 2
 #endif
+#ifndef W4_ROWPAIR  // two tiles per wave: the rows of TWO consecutive K steps are requested together (two register sets), so that
+#define W4_ROWPAIR 1 //   both 64-byte halves of a pixel's 128-byte line are asked for back to back - see `rows_request`
+#endif
 
 #ifdef W4_CLK   // development: shader-clock cycles of the prologue / K loop / epilogue, 100 MHz ticks of the whole block, count
 __device__ unsigned long long w4_clk[8];
@@ -83,8 +86,12 @@ struct W4Params {
 enum { MODE_FULL = 0, MODE_POOL = 1, MODE_MEANW = 2 };   // MEANW: mean over the two mel columns of block 6 (column tiles)
 
 // block -> (row block, channel tile); block b runs on XCD b % 8 (speed only).  1: an XCD streams one weight column slab
-// (NT % 8 == 0); 3: NT in {1, 2, 4, 8}: the channel tiles of a row block sit on 8 / NT ... XCDs each owning one slab;
-// 2: the channel tiles of a row block back to back on one XCD
+// (NT % 8 == 0); 3: NT in {1, 2, 4, 8}: the channel tiles of a row block sit on 8 / NT ... XCDs each owning one slab, row
+// blocks dealt round-robin; 4 (default for those NT): the same with a contiguous range of row blocks per XCD;
+// 2: the channel tiles of a row block back to back on one XCD.  Fabric reads per launch, B = 64, FETCH_SIZE x 2 in MiB
+// (profiles/r05_w4_fetch.txt): mode 3 with rows requested a step apart 604 / 928 / 500 / 792 / 378 / 722 / 346 / 672 for
+// b2c1 .. b5c2, mode 4 with paired row requests 328 / 652 / 330 / 658 / 330 / 658 / 330 / 656 (input 256 / 512 / 128 / 256 /
+// 64 / 128 / 32 / 64 MiB, read once by each of the NT XCD groups; weights 0.6 ... 72 MiB, once per XCD and round)
 __device__ __forceinline__ bool w4_block_map(const W4Params& p, int& m_tile, int& n_tile) {
   const int bid = blockIdx.x;
   const int xcd = bid & 7, seq = bid >> 3;
@@ -100,6 +107,12 @@ __device__ __forceinline__ bool w4_block_map(const W4Params& p, int& m_tile, int
     n_tile = xcd % p.NT;
     m_tile = seq * per + xcd / p.NT;
     if (m_tile >= p.MT) return false;
+  } else if (p.map_mode == 4) {   // like 3, but an XCD owns a CONTIGUOUS range of row blocks: the halo rows two neighbouring
+    const int per = 8 / p.NT;     //   blocks share (2 of the 10 a block reads at W = 32) are then hits in that XCD's L2
+    const int mtg = (p.MT + per - 1) / per;
+    n_tile = xcd % p.NT;
+    m_tile = (xcd / p.NT) * mtg + seq;
+    if (seq >= mtg || m_tile >= p.MT) return false;
   } else {
     n_tile = bid % p.NT;
     m_tile = bid / p.NT;
@@ -216,7 +229,23 @@ __global__ __launch_bounds__(256, 1) void conv3x3_w4_kernel(W4Params p) {
     auto run = [&](auto HPB_) {
       constexpr int HPB = decltype(HPB_)::value;
       constexpr int RB = HPB ? 1 : 0;      // first row of the shared item this wave needs
-      f32x4 preA[6], preB[5];
+      // PAIR (two tiles per wave): a K step is 16 channels = 64 bytes of a pixel's channel vector, HALF a 128-byte line; asked
+      // for a step apart, the second half found the line gone from L1 and L2 (an XCD's 32 workgroups pull 5 MB through a 4 MB
+      // L2 per step) and the fabric delivered every input line twice (tools/traffic_calib.hip: FETCH_SIZE of this pattern =
+      // 2x the bytes; profiles/r05_traffic_calibration.txt).  So the rows of steps s + 2 and s + 3 are requested TOGETHER in
+      // every even step s, into two register sets: the rows of step r live in set r & 1 (`rwp`).
+      constexpr bool PAIR = W4_ROWPAIR && MW == 2;
+      static_assert(!PAIR || W4_PRO2, "the paired form starts from the two-step prologue");
+      f32x4 preA[6], preB[5], rwp[PAIR ? 6 : 1];   // preA = set 0, rwp = set 1
+      auto rows_request_pair = [&](int s) {   // rows of steps s (set 0) and s + 1 (set 1): the two halves of a line back to back
+        if (W4_KO & 8) { if (s > 1) return; }
+        const unsigned cs = (unsigned)(s * KS * 4);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          preA[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, vbA + cs + (unsigned)r * row_bytes, 0, 0));
+          rwp[PAIR ? r : 0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, vbA + cs + (unsigned)(KS * 4) + (unsigned)r * row_bytes, 0, 0));
+        }
+      };
       auto rows_request = [&](int s) {
         if (W4_KO & 8) { if (s) return; }
         const unsigned cs = (unsigned)(s * KS * 4);
@@ -237,6 +266,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_w4_kernel(W4Params p) {
         *(u32x2*)(dst + PLANE) = lo;
       };
       // piece k of a step: 0..5 = positions of the own item, 6..8 = this wave's positions of the shared item
+      auto commit_piece_set1 = [&](unsigned char* buf, int k) {   // PAIR: piece k of the rows in set 1
+        if (W4_KO & 4) return;
+        store_piece(buf, lofsA, k, w4_transform(k, rwp[0], rwp[PAIR ? 1 : 0], rwp[PAIR ? 2 : 0], rwp[PAIR ? 3 : 0],
+                                                rwp[PAIR ? 4 : 0], rwp[PAIR ? 5 : 0]));
+      };
       auto commit_piece = [&](unsigned char* buf, int k) {
         if (W4_KO & 4) return;
         if (k < 6) {
@@ -280,8 +314,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_w4_kernel(W4Params p) {
       // two: step 0's staging below waits for the first set, step 0 of the K loop finds the second one landed), the
       // weight fragments behind them (L2 hits, and the vector-memory counter retires in order)
       f32x4 pre2[6];
-      rows_request(0);
-      if (MW == 2) {
+      if (PAIR) rows_request_pair(0);
+      else rows_request(0);
+      if (MW == 2 && !PAIR) {
         const unsigned cs = (unsigned)(KS * 4);
 #pragma unroll
         for (int r = 0; r < 6; ++r)
@@ -291,7 +326,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_w4_kernel(W4Params p) {
       for (int g0 = 0; g0 < AH; ++g0) w_load(0, g0, wr[g0]);
 #pragma unroll
       for (int k = 0; k < NPIECE; ++k) commit_piece(sV, k);
-      if (MW == 2) {
+      if (PAIR) {
+        // step 0 stages set 1 (rows of step 1) and requests the rows of steps 2 and 3
+      } else if (MW == 2) {
 #pragma unroll
         for (int r = 0; r < 6; ++r) preA[r] = pre2[r];
       } else {
@@ -311,8 +348,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_w4_kernel(W4Params p) {
       for (int g0 = 0; g0 < W4_ADEPTH; ++g0) a_load(sV, g0, af[g0]);
 
       // ---- one K step.  MORE: a step follows (its planes are staged here; the one after it is requested) ----
-      auto step = [&](int s, auto MORE_) {
+      auto step = [&](int s, auto MORE_, auto ODD_) {   // ODD (PAIR only): s & 1 as a compile-time value
         constexpr bool MORE = decltype(MORE_)::value;
+        constexpr bool ODD = decltype(ODD_)::value;
         const unsigned char* cur = sV + (s & 1) * VBUF;
         unsigned char* nxt = sV + ((s + 1) & 1) * VBUF;
 #pragma unroll
@@ -345,8 +383,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_w4_kernel(W4Params p) {
                 asm volatile("" :: "v"(af[gi % NA][m][0]), "v"(af[gi % NA][m][1]), "v"(wr[gi % RING][0]), "v"(wr[gi % RING][1]));
           }
           if (MORE) {
-            if (gi < NPIECE) commit_piece(nxt, gi);
-            if (gi == NPIECE) rows_request(s + 2);   // past the last step: lands in registers nobody reads
+            if (PAIR) {   // even steps stage set 1 (rows of the odd step that follows), then ask for the next two steps' rows
+              if (gi < NPIECE) { if (ODD) commit_piece(nxt, gi); else commit_piece_set1(nxt, gi); }
+              if (gi == NPIECE && !ODD) rows_request_pair(s + 2);   // past the last step: lands in registers nobody reads
+            } else {
+              if (gi < NPIECE) commit_piece(nxt, gi);
+              if (gi == NPIECE) rows_request(s + 2);   // past the last step: lands in registers nobody reads
+            }
           }
           if (gi == LASTG && !(W4_KO & 16)) lds_barrier();   // step s + 1 is complete in `nxt`; the fragments of the groups left are in registers
           __builtin_amdgcn_sched_barrier(0);
@@ -355,9 +398,19 @@ __global__ __launch_bounds__(256, 1) void conv3x3_w4_kernel(W4Params p) {
 #ifdef W4_CLK
       clk_t1 = __builtin_readcyclecounter();
 #endif
+      if (PAIR) {   // nstep is even (Cin % 32 == 0: checked by the dispatcher)
 #pragma unroll 1
-      for (int s = 0; s + 1 < nstep; ++s) step(s, std::true_type{});
-      step(nstep - 1, std::false_type{});
+        for (int s = 0; s + 2 < nstep; s += 2) {
+          step(s, std::true_type{}, std::false_type{});
+          step(s + 1, std::true_type{}, std::true_type{});
+        }
+        step(nstep - 2, std::true_type{}, std::false_type{});
+        step(nstep - 1, std::false_type{}, std::true_type{});
+      } else {
+#pragma unroll 1
+        for (int s = 0; s + 1 < nstep; ++s) step(s, std::true_type{}, std::false_type{});
+        step(nstep - 1, std::false_type{}, std::false_type{});
+      }
     };
     if (MW == 3 && wave >= 2) run(std::integral_constant<int, 3>{});
     else run(std::integral_constant<int, 0>{});
@@ -497,7 +550,7 @@ int launch_w4(W4Params p, hipStream_t s) {
   p.MT = (quads + G::PQ - 1) / G::PQ;
   unsigned grid;
   if (p.map_mode == 2) grid = (unsigned)(((p.MT + 7) / 8) * 8 * p.NT);
-  else if (p.map_mode == 3) grid = (unsigned)(((p.MT + 8 / p.NT - 1) / (8 / p.NT)) * 8);
+  else if (p.map_mode == 3 || p.map_mode == 4) grid = (unsigned)(((p.MT + 8 / p.NT - 1) / (8 / p.NT)) * 8);
   else grid = (unsigned)(p.MT * p.NT);
   constexpr size_t lds = (size_t)2 * G::VBUF > (size_t)4 * W4_OUT_TILE ? (size_t)2 * G::VBUF : (size_t)4 * W4_OUT_TILE;
   static_assert(lds <= 160 * 1024, "V planes exceed the LDS");
@@ -530,8 +583,8 @@ static int w4_dispatch(const float* in, const void* wfrag, const float* scale, c
                        int H, int W, int Cin, int Cout, int mode, int map_mode, int mw, const int* clip_frames, int need_mul,
                        int need_add, void* stream, Drop drop) {
   if (!in || !wfrag || !scale || !shift || !out) return AC_ERR_ARG;
-  if (B <= 0 || Hp <= H || (Hp & 3) || !(W == 32 || W == 16 || W == 8 || W == 4 || W == 2) || Cin % 16 || Cin < 32 || Cout % 128)
-    return AC_ERR_ARG;
+  if (B <= 0 || Hp <= H || (Hp & 3) || !(W == 32 || W == 16 || W == 8 || W == 4 || W == 2) || Cin % 32 || Cin < 32 || Cout % 128)
+    return AC_ERR_ARG;   // (Cin % 32: the K loop walks its 16-channel steps in pairs)
   if (W == 2 ? (mode != MODE_FULL && mode != MODE_MEANW) : (mode != MODE_FULL && mode != MODE_POOL)) return AC_ERR_ARG;
   if (mode == MODE_MEANW && drop.thresh != 0) return AC_ERR_ARG;   // dropout sits BEFORE the mean over mel: use mode 0
   if ((unsigned long long)B * Hp >= (1ull << 23)) return AC_ERR_ARG;          // the epilogue finds a row's clip offset with FastDiv4::mod (float reciprocal: exact below 2^23 rows); callers chunk clips beyond it
@@ -542,10 +595,13 @@ static int w4_dispatch(const float* in, const void* wfrag, const float* scale, c
   p.MT = 0;
   p.NT = Cout / 128;
   p.Hp_out = Hp / 2; p.H_out = H / 2; p.W_out = W / 2;
-  if (map_mode < 0) map_mode = (p.NT % 8 == 0) ? 1 : ((p.NT == 1 || p.NT == 2 || p.NT == 4) ? 3 : 2);
+#ifndef W4_DEFAULT_MAP
+#define W4_DEFAULT_MAP 4
+#endif
+  if (map_mode < 0) map_mode = (p.NT % 8 == 0 && p.NT > 8) ? 1 : ((p.NT == 1 || p.NT == 2 || p.NT == 4 || p.NT == 8) ? W4_DEFAULT_MAP : 2);
   if (map_mode == 1 && p.NT % 8 != 0) return AC_ERR_ARG;
-  if (map_mode == 3 && !(p.NT == 1 || p.NT == 2 || p.NT == 4 || p.NT == 8)) return AC_ERR_ARG;
-  if (map_mode > 3) return AC_ERR_ARG;
+  if ((map_mode == 3 || map_mode == 4) && !(p.NT == 1 || p.NT == 2 || p.NT == 4 || p.NT == 8)) return AC_ERR_ARG;
+  if (map_mode > 4) return AC_ERR_ARG;
   p.map_mode = map_mode;
   p.clip_frames = clip_frames; p.need_mul = need_mul; p.need_add = need_add;
   p.drop = drop;

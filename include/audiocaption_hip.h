@@ -120,7 +120,7 @@ int ac_conv3x3_bn_relu_wino1d_splitk(const float* in, const void* wfrag, const f
  * modes 0 / 1 and ragged-batch arguments as ac_conv3x3_bn_relu_wino1d; replaces the same reference code: ConvBlock.forward,
  * cnn_encoder.py:59-75 (+ the pooling of Cnn14Encoder.forward, :431-441).  Covers the full-width layers W = 32, 16, 8, 4
  * (conv blocks 2-5; modes 0, 1) and W = 2 (block 6: column tiles that skip the taps on the zero padding; modes 0 and
- * 2 = mean over the two mel columns, out (B, H, Cout), cnn_encoder.py:443) with Cout % 128 == 0, Cin % 16 == 0, Cin >= 32,
+ * 2 = mean over the two mel columns, out (B, H, Cout), cnn_encoder.py:443) with Cout % 128 == 0, Cin % 32 == 0,
  * Hp % 4 == 0; wfrag
  * [Cin/16][3 kx x 6 positions][Cout/32][hi, lo][64 lanes][8] bf16 (U = G g in f64, then split).  tiles_per_wave: 3 (288
  * accumulators, 9 MFMAs per weight fragment pair), 2, or 0 = chosen by the launch's last-round occupancy.  The input is

@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--tiles", type=int, default=2)
     ap.add_argument("--layers", default="b2c1,b2c2,b3c1,b3c2,b4c1,b4c2,b5c1,b5c2")
+    ap.add_argument("--only", default="", help="comma-separated variant names to run (default: all built ones)")
     args = ap.parse_args()
     if args.build:
         specs = {s.split("=", 1)[0]: [f for f in s.split("=", 1)[1].split(",") if f] for s in args.specs} if args.specs else DEFAULT
@@ -74,6 +75,8 @@ def main():
     from tools.conv_bench import LAYERS
     names = sorted(os.path.basename(f)[6:-3] for f in glob.glob(os.path.join(BIN, "libw4_*.so")))
     names.sort(key=lambda n: (n != "base", n))
+    if args.only:
+        names = [n for n in names if n in args.only.split(",")]
     P, I = ctypes.c_void_p, ctypes.c_int
     libs = {}
     for v in names:
