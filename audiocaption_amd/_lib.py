@@ -69,6 +69,10 @@ SIGNATURES = {
     "ac_trm_pack_step_weights": (_I, [_WP, _P, _P]),
     "ac_trm_workspace_floats": (_L, [_WP, _I, _I]),
     "ac_trm_greedy": (_I, [_WP, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "ac_trm_cluster_pack_floats": (_L, [_WP]),
+    "ac_trm_cluster_pack": (_I, [_WP, _P, _P]),
+    "ac_trm_cluster_workspace_bytes": (_L, [_I]),
+    "ac_trm_greedy_cluster": (_I, [_WP, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
     "ac_trm_forward_tokens": (_I, [_WP, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
     "ac_trm_beam_step": (_I, [_WP, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P]),
     "ac_trm_beam_update": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -136,8 +136,34 @@ class TransformerDecoder(BaseDecoder):
         check(lib.ac_trm_pack_step_weights(ctypes.byref(w), ptr(pk), stream()), "ac_trm_pack_step_weights")
         keep.append(pk)
         w.step_pk = ctypes.c_void_p(pk.data_ptr())
+        self._cluster_pk = None   # per-part blobs of the one-launch greedy search, packed on first use (cluster_pack)
         self._w, self._w_key, self._w_keep = w, key, keep
         return w
+
+    def cluster_pack(self):
+        """Weights in the layout of the one-launch greedy search (csrc/decoder_cluster.hip: per part, per layer, row-major
+        [k][column] slices), or None when the decoder's shape is not the one that kernel covers.  Cached with ``weights()``."""
+        w = self.weights()
+        if getattr(self, "_cluster_pk", None) is None:
+            lib = _lib.load()
+            n = lib.ac_trm_cluster_pack_floats(ctypes.byref(w))
+            if n <= 0:
+                self._cluster_pk = False
+            else:
+                pk = torch.empty(n, device=self.word_embedding.weight.device, dtype=torch.float32)
+                check(lib.ac_trm_cluster_pack(ctypes.byref(w), ptr(pk), stream()), "ac_trm_cluster_pack")
+                self._cluster_pk = pk
+        return self._cluster_pk if self._cluster_pk is not False else None
+
+    def cluster_covers(self, rows, Tm, max_length):
+        """The one-launch greedy search takes this problem: shape covered, the row's keys and values fit the LDS, and the
+        clusters are resident together (one workgroup per CU, four per row: AUDIOCAPTION_CLUSTER_MAX_ROWS, default 64)."""
+        if self.d_model != 256 or self.nhead != 4 or self.dim_feedforward != 1024 or max_length > 32:
+            return False
+        nlc = ((self.vocab_size + 3) // 4 + 63) // 64 * 64
+        lds = 4 * (256 + 192 + 64 + 256 + 5 * 256 + ((max(Tm, 32) + 3) & ~3) + 256 + 16 + 1024 + nlc
+                   + 2 * self.nlayers * (max_length + Tm) * 64) + 64
+        return lds <= 159 * 1024 and rows <= int(os.environ.get("AUDIOCAPTION_CLUSTER_MAX_ROWS", "64"))
 
     def workspace(self, rows, max_len, device):
         lib = _lib.load()
@@ -192,14 +218,28 @@ class TransformerDecoder(BaseDecoder):
         w = ctypes.byref(self.weights())
         check(lib.ac_trm_memory(w, ptr(st["attn_emb"]), B, Tm, ptr(st["memkv"]), ptr(st["tmp"]), stream()),
               "ac_trm_memory")
+        if st.get("cluster_ws") is not None:
+            check(lib.ac_trm_greedy_cluster(w, ptr(st["cluster_pk"]), ptr(st["memkv"]), ptr(st["mem_len"]), B, Tm, max_length,
+                                            start_idx, end_idx, pad_idx, ptr(st["seq"]), ptr(st["logit"]),
+                                            ptr(st["sampled_logprob"]), ptr(st["embed"]), ptr(st["unfinished_cnt"]),
+                                            ptr(st["cluster_ws"]), int(st["early_stop"]), stream()), "ac_trm_greedy_cluster")
+            return
         check(lib.ac_trm_greedy(w, ptr(st["memkv"]), ptr(st["mem_len"]), B, Tm, max_length, start_idx, end_idx,
                                 pad_idx, ptr(st["seq"]), ptr(st["logit"]), ptr(st["sampled_logprob"]),
                                 ptr(st["embed"]), ptr(st["unfinished_cnt"]), ptr(st["ws"]), stream()),
               "ac_trm_greedy")
 
-    def greedy(self, attn_emb, attn_emb_len, max_length, start_idx, end_idx, pad_idx):
+    def greedy(self, attn_emb, attn_emb_len, max_length, start_idx, end_idx, pad_idx, alone=False, mode=None):
         """On-device greedy search.  Returns device tensors seq (int64), logit, logprob, embed, cnt.  ``attn_emb`` /
         ``attn_emb_len``: one batch, or lists of batches of the same (frames, width) decoded as one chain.
+
+        Two forms of the same search.  "chain": ten launches per step (csrc/decoder.hip) - ~90 us per step whatever the row
+        count, the form that shares the GPU with the next batch's encoder (``forward_async``).  "cluster": ONE persistent
+        launch, a cluster of four workgroups per row (csrc/decoder_cluster.hip) - about half the time per step when
+        nothing else runs on the GPU and the rows fit (``cluster_covers``).  ``mode`` (default: AUDIOCAPTION_GREEDY =
+        "auto"): "auto" takes the cluster form when the caller says the decode runs ``alone`` (the blocking ``model()``
+        call) and the problem is covered.  The returned dict then carries "cluster_error" (device int32 word, non-zero:
+        a workgroup's partners never started - rerun with mode="chain").
 
         The ~370 short launches of a decode are latency-bound, so the fixed launch sequence (memory
         preparation + max_length decoder steps) is captured once per shape (on its second use) into a HIP graph over
@@ -209,7 +249,17 @@ class TransformerDecoder(BaseDecoder):
         dev = parts[0].device                                                           # copied into its rows of the static buffer
         B, (Tm, A) = sum(p_.shape[0] for p_ in parts), parts[0].shape[1:]
         use_graph = os.environ.get("AUDIOCAPTION_DECODE_GRAPH", "1") != "0"
-        key = (dev, B, Tm, max_length, start_idx, end_idx, pad_idx, self._weights_key())
+        mode = mode or os.environ.get("AUDIOCAPTION_GREEDY", "auto")
+        if mode not in ("auto", "chain", "cluster"):
+            raise ValueError(f"AUDIOCAPTION_GREEDY={mode!r}: 'auto', 'chain' or 'cluster'")
+        covered = self.cluster_covers(B, Tm, max_length) and self.cluster_pack() is not None
+        if mode == "cluster" and not covered:
+            raise _lib.HipLibraryError("the one-launch greedy search does not cover this decoder shape / row count")
+        cluster = mode == "cluster" or (mode == "auto" and alone and covered)
+        # AUDIOCAPTION_CLUSTER_EARLY_STOP=0: the one-launch form runs all max_length steps like the launch chain (benchmarks that
+        # compare the two at equal work; the outputs are the same either way)
+        early = os.environ.get("AUDIOCAPTION_CLUSTER_EARLY_STOP", "1") != "0"
+        key = (dev, B, Tm, max_length, start_idx, end_idx, pad_idx, cluster, early, self._weights_key())
         if self._greedy_state is None:
             self._greedy_state = {}
         states = self._greedy_state
@@ -228,6 +278,11 @@ class TransformerDecoder(BaseDecoder):
                 "embed": torch.empty(B, max_length, self.d_model, **f32),
                 "unfinished_cnt": torch.empty(max_length, device=dev, dtype=torch.int32),
             }
+            if cluster:
+                nb = _lib.load().ac_trm_cluster_workspace_bytes(B)
+                st["cluster_ws"] = torch.zeros((nb + 7) // 8, device=dev, dtype=torch.int64)   # error word zeroed once
+                st["cluster_pk"] = self.cluster_pack()
+                st["early_stop"] = early
         states[key] = st                       # most recently used last; batches of changing length keep 8 shapes
         while len(states) > 8:
             states.pop(next(iter(states)))
@@ -251,7 +306,10 @@ class TransformerDecoder(BaseDecoder):
                     self._greedy_launch(st, max_length, start_idx, end_idx, pad_idx)
                 st["graph"] = graph
             st["graph"].replay()
-        return {k: st[k].clone() for k in ("seq", "logit", "sampled_logprob", "embed", "unfinished_cnt")}
+        out = {k: st[k].clone() for k in ("seq", "logit", "sampled_logprob", "embed", "unfinished_cnt")}
+        if cluster:
+            out["cluster_error"] = st["cluster_ws"][:1].clone()
+        return out
 
     def beam_step(self, memkv, mem_len, B, beam, Tm, max_length, t, temp, tokens, mask, cum, ws):
         lib = _lib.load()

@@ -534,8 +534,15 @@ class TransformerModel(CaptionModel):
     def greedy_search(self, input_dict):
         if input_dict.get("temp", 1.0) != 1.0:
             pass  # greedy argmax does not depend on temp (base.py:216-218 ignores it for "greedy")
-        res = self.decoder.greedy(input_dict["attn_emb"], input_dict["attn_emb_len"],
-                                  int(input_dict["max_length"]), self.start_idx, self.end_idx, self.pad_idx)
+        args = (input_dict["attn_emb"], input_dict["attn_emb_len"], int(input_dict["max_length"]), self.start_idx, self.end_idx,
+                self.pad_idx)
+        # the blocking call: nothing else runs on the GPU while this batch decodes -> the one-launch form where it applies
+        res = self.decoder.greedy(*args, alone=True)
+        if "cluster_error" in res and int(res["cluster_error"].item() & 0xffffffff) != 0:
+            import warnings
+            warnings.warn("one-launch greedy search: a workgroup's partners never started (another process on the GPU?); "
+                          "decoding this batch with the launch chain")
+            res = self.decoder.greedy(*args, mode="chain")
         return {
             "seq": res["seq"].cpu(),                          # the reference keeps seq on the CPU (base.py:122)
             "logit": res["logit"],

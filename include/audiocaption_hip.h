@@ -277,6 +277,29 @@ int ac_trm_greedy(const ac_trm_weights* w, const float* memkv, const int* mem_le
                   int start_idx, int end_idx, int pad_idx, int64_t* seq, float* logit, float* logprob,
                   float* embed, int* unfinished_cnt, float* ws, void* stream);
 
+/* The same greedy search (same arguments, same outputs; base.py:152-218, transformer_decoder.py:80-103) as ONE persistent
+ * launch for the case that nothing else runs on the GPU (the blocking model() call, single clips): a row is decoded by a
+ * cluster of four workgroups for all of its steps - part p owns head p of both attention sub-layers (its keys and values
+ * stay in LDS: the projected audio memory of the row and the self-attention cache) and quarter p of the feed-forward
+ * units and of the vocabulary; the parts meet in seven exchanges per step (tagged 8-byte granules through L2, the split
+ * GRU kernel's hand-off) - csrc/decoder_cluster.hip.  ~45 us per step instead of the launch chain's ~90, for up to two
+ * rows per CU; beyond that the clusters run in rounds and ac_trm_greedy is the faster call.  Sums are formed in another
+ * order than ac_trm_greedy's (logits equal to ~1e-6, the same token ids on every fixture).
+ * cluster_pk: ac_trm_cluster_pack_floats(w) floats written by ac_trm_cluster_pack (per-part weight blobs; redo when the
+ * weights change).  workspace: ac_trm_cluster_workspace_bytes(B) bytes, 8-byte aligned; its FIRST 4-byte word is a sticky
+ * error flag the caller zeroes once: non-zero when a workgroup's partners never started within 2 s (outputs invalid).
+ * early_stop != 0: the launch ends one or two steps after every row has emitted <end> (the reference's loop ends there,
+ * base.py:206-211; the columns it would not have written keep their initial values either way); 0: all max_len steps run
+ * (what ac_trm_greedy's launches do).
+ * Shapes: d_model 256, 4 heads, dim_ff 1024, max_len <= 32, nlayers * (Tm + max_len) * 512 + ~20 KB of LDS <= 160 KB;
+ * AC_ERR_ARG otherwise (ac_trm_cluster_pack_floats: -1). */
+long ac_trm_cluster_pack_floats(const ac_trm_weights* w);
+int ac_trm_cluster_pack(const ac_trm_weights* w, float* out, void* stream);
+long ac_trm_cluster_workspace_bytes(int B);
+int ac_trm_greedy_cluster(const ac_trm_weights* w, const float* cluster_pk, const float* memkv, const int* mem_len, int B,
+                          int Tm, int max_len, int start_idx, int end_idx, int pad_idx, int64_t* seq, float* logit,
+                          float* logprob, float* embed, int* unfinished_cnt, void* workspace, int early_stop, void* stream);
+
 /* Decoder forward on given tokens (teacher forcing / plugin call, transformer_decoder.py:80-103):
  * tokens [N][T] int32; key_mask [N][T] uint8 (1 = masked key, the reference's cap_padding_mask /
  * tgt_key_padding_mask, transformer_model.py:22-23,55) or NULL.  embed [N][T][d], logit [N][T][V]. */

@@ -43,3 +43,18 @@ def hip_model(state4981):
     model = A.init_model_from_config(A.cnn14rnn_trm_config(4981), print_fn=lambda s: None)
     model.load_state_dict(state4981, strict=True)
     return model.eval().to("cuda:0")
+
+
+@pytest.fixture(scope="session")
+def diverse_models(state4981):
+    """The product model with the two HIGH-ENTROPY decoder draws of the g4b / g5b fixtures (procedural.DIVERSE)."""
+    import audiocaption_amd as A
+    from audiocaption_amd import procedural as P
+    models = {}
+    for kind in ("greedy", "beam"):
+        st = dict(state4981)
+        st.update(P.to_torch(P.decoder_state_diverse(kind, vocab_size=4981)))
+        m = A.init_model_from_config(A.cnn14rnn_trm_config(4981), print_fn=lambda s: None)
+        m.load_state_dict(st, strict=True)
+        models[kind] = m.eval().to("cuda:0")
+    return models

@@ -156,12 +156,14 @@ def clotho_models():
     return models
 
 
+@pytest.mark.parametrize("mode", ["chain", "cluster"])
 @pytest.mark.parametrize("kind", ["plain", "greedy"])
-def test_greedy_at_the_clotho_vocabulary_vs_oracle(clotho_models, golden_dir, kind):
+def test_greedy_at_the_clotho_vocabulary_vs_oracle(clotho_models, golden_dir, kind, mode, monkeypatch):
     """The headline's vocabulary (4368 rows of classifier and embedding: other GEMM tails than 4981) on the g4 encoder
     outputs: greedy ids identical to the oracle's, logits / log-probabilities within 1e-4 (base.py:152-218)."""
     import os
     from oracle import cpu_path as O
+    monkeypatch.setenv("AUDIOCAPTION_GREEDY", mode)
     model, st = clotho_models[kind]
     g4 = dict(np.load(os.path.join(golden_dir, "g4_greedy.npz")))
     attn, alen = torch.from_numpy(g4["attn_emb"]), torch.from_numpy(g4["attn_emb_len"])

@@ -167,7 +167,15 @@ def test_g3_decoder_forward_vs_reference_golden(hip_model, golden_dir):
     assert torch.equal(out["logit"].cpu().argmax(-1), torch.from_numpy(g["logit_top_idx"][..., 0]))
 
 
-def test_g4_greedy_tokens_identical_to_reference(hip_model, golden_dir):
+@pytest.fixture(params=["chain", "cluster"])
+def greedy_mode(request, monkeypatch):
+    """Both forms of the on-device greedy search: the launch chain (csrc/decoder.hip) and the one-launch cluster kernel
+    (csrc/decoder_cluster.hip), which the blocking call takes by default when it covers the problem."""
+    monkeypatch.setenv("AUDIOCAPTION_GREEDY", request.param)
+    return request.param
+
+
+def test_g4_greedy_tokens_identical_to_reference(hip_model, golden_dir, greedy_mode):
     g = _load(golden_dir, "g4_greedy.npz")
     enc = {"attn_emb": torch.from_numpy(g["attn_emb"]).cuda(), "attn_emb_len": torch.from_numpy(g["attn_emb_len"]),
            "fc_emb": torch.from_numpy(g["fc_emb"]).cuda()}
@@ -196,22 +204,7 @@ def test_g5_beam_tokens_identical_to_reference(hip_model, golden_dir):
         np.testing.assert_array_equal(out["seq"].numpy(), g[f"seq_beam{k}"])
 
 
-@pytest.fixture(scope="module")
-def diverse_models(state4981):
-    """The product model with the two HIGH-ENTROPY decoder draws of the g4b / g5b fixtures (procedural.DIVERSE)."""
-    import audiocaption_amd as A
-    from audiocaption_amd import procedural as P
-    models = {}
-    for kind in ("greedy", "beam"):
-        st = dict(state4981)
-        st.update(P.to_torch(P.decoder_state_diverse(kind, vocab_size=4981)))
-        m = A.init_model_from_config(A.cnn14rnn_trm_config(4981), print_fn=lambda s: None)
-        m.load_state_dict(st, strict=True)
-        models[kind] = m.eval().to("cuda:0")
-    return models
-
-
-def test_g4b_greedy_high_entropy_fixture(diverse_models, golden_dir):
+def test_g4b_greedy_high_entropy_fixture(diverse_models, golden_dir, greedy_mode):
     """Reference greedy ids on a draw whose clips stop at steps 3 / 10 / 19 / 10 and repeat no token more than 4 times
     (g4 repeats one token fourteen times): ids identical, top-8 logits within 1e-4."""
     g4, gb = _load(golden_dir, "g4_greedy.npz"), _load(golden_dir, "g4b_greedy.npz")
@@ -374,20 +367,28 @@ def test_short_clips_leave_the_fp16_activation_tier(hip_model, state4981):
         cnn.conv_algo = saved
 
 
-def test_forward_async_equals_blocking_forward(hip_model):
-    """Throughput mode (two streams, overlapped steps) returns exactly what the blocking call returns."""
+def test_forward_async_equals_blocking_forward(hip_model, monkeypatch):
+    """Throughput mode (two streams, overlapped steps) returns exactly what the blocking call returns when both decode with
+    the same form of the greedy search (the launch chain); the blocking call's default form - the one-launch cluster kernel -
+    sums in another order: the same tokens, logits within 2e-5."""
     from audiocaption_amd import procedural as P
     wavs = [torch.from_numpy(P.synthetic_wav(3, 48000, seed=s_, varied=True)).cuda() for s_ in (1, 2, 3)]
     inputs = [{"mode": "inference", "wav": w, "wav_len": [48000, 40000, 33000], "specaug": False,
                "sample_method": "greedy", "max_length": 8} for w in wavs]
+    default = [hip_model(dict(i)) for i in inputs]
+    monkeypatch.setenv("AUDIOCAPTION_GREEDY", "chain")
     want = [hip_model(dict(i)) for i in inputs]
     pend = [hip_model.forward_async(dict(i)) for i in inputs]
     got = [p.result() for p in pend]
-    for w, g in zip(want, got):
+    for w, g, d in zip(want, got, default):
         assert torch.equal(w["seq"], g["seq"])
         assert torch.equal(w["attn_emb"], g["attn_emb"])
         assert torch.equal(w["logit"], g["logit"])
         assert torch.equal(w["sampled_logprob"], g["sampled_logprob"])
+        steps = int((g["unfinished_cnt"] > 0).sum()) + 1 if "unfinished_cnt" in g else 8
+        steps = min(steps, 8)
+        assert torch.equal(d["seq"], g["seq"]) and torch.equal(d["attn_emb"], g["attn_emb"])
+        assert float((d["logit"][:, :steps] - g["logit"][:, :steps]).abs().max()) < 2e-5
     # the one-workgroup recurrence kernel (gru_algo="single"): another summation order, the same tokens
     for i, g in zip(inputs, got):
         w = hip_model(dict(i, gru_algo="single"))
@@ -471,10 +472,12 @@ def test_ragged_batch_skips_dead_rows_bit_identically(hip_model, monkeypatch, ex
         assert torch.equal(one["seq"][0], skip["seq"][i])
 
 
-def test_forward_async_pair_decode_mixed_shapes(hip_model):
+def test_forward_async_pair_decode_mixed_shapes(hip_model, monkeypatch):
     """Pair decode only joins consecutive submissions of the same shape; anything else is decoded on its own - in every
-    case with the results of the blocking call, whatever order result() is asked in."""
+    case with the results of the blocking call (decoding with the same form of the greedy search: the launch chain),
+    whatever order result() is asked in."""
     from audiocaption_amd import procedural as P
+    monkeypatch.setenv("AUDIOCAPTION_GREEDY", "chain")
 
     def make(n, L, seed, lens):
         w = torch.from_numpy(P.synthetic_wav(n, L, seed=seed, varied=True)).cuda()
@@ -503,6 +506,7 @@ def test_forward_async_decode_groups_equal_blocking(hip_model, monkeypatch, grou
     same-shaped batches (full groups and a shorter last one) give the bits of the blocking call, batch by batch."""
     from audiocaption_amd import procedural as P
     monkeypatch.setenv("AUDIOCAPTION_DECODE_GROUP", group)
+    monkeypatch.setenv("AUDIOCAPTION_GREEDY", "chain")   # bits: both sides decode with the launch chain
     wavs = [torch.from_numpy(P.synthetic_wav(3, 48000, seed=20 + s_, varied=True)).cuda() for s_ in range(7)]
     inputs = [{"mode": "inference", "wav": w, "wav_len": [48000, 40000, 33000], "specaug": False,
                "sample_method": "greedy", "max_length": 8} for w in wavs]
