@@ -69,6 +69,8 @@ SIGNATURES = {
     "ac_trm_pack_step_weights": (_I, [_WP, _P, _P]),
     "ac_trm_workspace_floats": (_L, [_WP, _I, _I]),
     "ac_trm_greedy": (_I, [_WP, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "ac_conv3x3_skinny_workspace_floats": (_L, [_I, _I, _I, _I, _I]),
+    "ac_conv3x3_bn_relu_skinny": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _L, _F, _U64, _P, _P]),
     "ac_trm_cluster_pack_floats": (_L, [_WP]),
     "ac_trm_cluster_pack": (_I, [_WP, _P, _P]),
     "ac_trm_cluster_workspace_bytes": (_L, [_I]),

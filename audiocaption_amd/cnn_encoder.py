@@ -96,10 +96,10 @@ def wino43_covers(W, cout):
 
 
 def _conv_wino43(x, w, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode=-1, need=None, splitk_buf=None,
-                 dropout=None):
+                 dropout=None, cold=False):
     """The "wino43" tier's launcher: ``w`` is (F(2,3) pack, F(4,3) pack or None).  F(4,3) when the kernel covers the layer
     and the launch fills the chip (a workgroup owns a CU: single clips run the K-sliced F(2,3) form instead)."""
-    w23, w43 = w if isinstance(w, tuple) else (w, None)
+    w23, w43, lazy = (tuple(w) + (None,))[:3] if isinstance(w, tuple) else (w, None, None)
     # (AUDIOCAPTION_RAGGED_EXACT=1 only: batches of uneven lengths then keep block 6 on F(2,3) - the caller passes it the F(2,3)
     # pack only: its tiles are taller than a clip, nothing can be skipped there anyway, and the quad-wide input window of
     # F(4,3) would cost every layer upstream four more valid rows per clip - ``rows_needed``.  In the default mode ragged
@@ -108,8 +108,38 @@ def _conv_wino43(x, w, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode
             and K.wino43_workgroups(B, Hp, W, Cout) >= W43_MIN_WORKGROUPS:
         return K.conv3x3_bn_relu_wino43(x, w43, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode, need=need,
                                         dropout=dropout)
+    # Few pixels, heavy weights, COLD weights: blocks 5-6 in the training step at the reference's per-GPU batch of 4 - the
+    # step touches a few hundred MB between two uses of these 360 MB of weights, so they come from HBM every iteration, and
+    # the dropout epilogue of the F(2,3) kernel has no K-sliced form: 2 x 390 us for block 6 of four clips; the
+    # weight-streaming direct form takes ~110 (tools/small_batch_bench.py, tools/train_bench.py --batch 4: 4.30 -> 3.79 ms
+    # per step).  Inference calls re-use the weights from the memory-side cache call after call, where the K-sliced F(2,3)
+    # form is as fast or faster (B = 1: 36 + 61 us vs 27 + 55 for block 6, 34 + 48 vs 39 + 53 for block 5; B = 4: 116 vs
+    # 165): they keep it.
+    if lazy is not None and need is None and splitk_buf is not None and SKINNY and (cold or dropout is not None) \
+            and B * Hp * W <= SKINNY_MAX_PX:
+        n = K.skinny_workspace_floats(B, Hp, W, Cin, Cout)
+        if n > 0:
+            return K.conv3x3_bn_relu_skinny(x, lazy.get(), scale, shift, out, B, Hp, H, W, Cin, Cout, mode, splitk_buf(n),
+                                            dropout=dropout)
     return _conv_wino1d(x, w23, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode, need=need, splitk_buf=splitk_buf,
                         dropout=dropout)
+
+
+SKINNY = os.environ.get("AUDIOCAPTION_SKINNY", "1") != "0"
+SKINNY_MAX_PX = int(os.environ.get("AUDIOCAPTION_SKINNY_MAX_PX", "1024"))   # pixels (B * Hp * W) up to which it is the faster form
+
+
+class _LazyPack:
+    """The direct split-bf16 pack of a layer's weights (csrc/conv3x3_skinny.hip), built on first use: only small launches
+    need it, and conv2 of block 6 alone is 151 MB."""
+
+    def __init__(self, weight):
+        self._weight, self._pk = weight, None
+
+    def get(self):
+        if self._pk is None:
+            self._pk = K.pack_conv_weight_bf16x3_frag(self._weight.detach().float())
+        return self._pk
 
 
 def ragged_exact():
@@ -247,7 +277,8 @@ class Cnn14Encoder(nn.Module):
                         wp = K.pack_conv_weight_wino1d_frag(w)
                     elif algo == "wino43":   # both packs: small launches (single clips) take the K-sliced F(2,3) form
                         wp = (K.pack_conv_weight_wino1d_frag(w),
-                              K.pack_conv_weight_wino43_frag(w) if wino43_covers(64 >> b, w.shape[0]) else None)
+                              K.pack_conv_weight_wino43_frag(w) if wino43_covers(64 >> b, w.shape[0]) else None,
+                              _LazyPack(conv.weight) if b >= 4 else None)   # blocks 5-6 (W = 4, 2): the skinny form
                     elif algo == "bf16x3_lds":
                         wp = K.pack_conv_weight_bf16x3(w)
                     elif algo == "f16x2" and mixed and b == 5:
@@ -375,9 +406,11 @@ class Cnn14Encoder(nn.Module):
         # CU a persistent workgroup; single clips keep conv_first + the K-sliced F(2,3) form
         fuse1_w4 = algo == "wino43" and os.environ.get("AUDIOCAPTION_FUSE_BLOCK1", "1") != "0" and Hp[0] % 8 == 0 \
             and B * Hp[0] // 8 >= W43_MIN_WORKGROUPS and pk.get("b1c2_f43") is not None
-        if algo in WINO and dropout is None and os.environ.get("AUDIOCAPTION_W1_SPLITK", "1") != "0":
+        if algo in WINO and os.environ.get("AUDIOCAPTION_W1_SPLITK", "1") != "0":
             import functools   # single clips: layers of a few workgroups run K-sliced over a shared workspace
             conv = functools.partial(conv, splitk_buf=lambda n: self._buf("w1_splitk", n, dev))
+            if algo == "wino43" and dropout is not None:
+                conv = functools.partial(conv, cold=True)   # the training step: weights come from HBM every iteration
 
         def need(block, j):   # ragged batches: the rows of this layer a clip's own length can bring to an output frame
             return {"need": (clip_frames,) + rows_needed(block, j, quads=algo == "wino43" and ragged_exact())} \

@@ -251,6 +251,30 @@ def conv3x3_bn_relu_wino43(x, wfrag, scale, shift, out, B, Hp, H, W, Cin, Cout, 
     return out
 
 
+def skinny_workspace_floats(B, Hp, W, Cin, Cout):
+    """Floats of workspace ``conv3x3_bn_relu_skinny`` needs for this geometry; 0 = not a launch for that kernel (more than
+    2048 pixels, W other than 2 / 4)."""
+    return int(_lib.load().ac_conv3x3_skinny_workspace_floats(B, Hp, W, Cin, Cout))
+
+
+def conv3x3_bn_relu_skinny(x, wfrag, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, workspace, dropout=None):
+    """Few pixels, heavy weights (conv blocks 5-6 of single clips / small training batches): the K-sliced direct convolution
+    on split-bf16 operands that streams its weights once (csrc/conv3x3_skinny.hip); ``wfrag`` from
+    ``pack_conv_weight_bf16x3_frag``; ``workspace``: f32 tensor of at least ``skinny_workspace_floats`` elements;
+    ``dropout = (p, seed, seed_dev)`` as for ``conv3x3_bn_relu_wino1d`` (modes 0 and 1)."""
+    hook = CONV_LAUNCH_HOOK
+    if hook is not None:
+        info = {"B": B, "H": H, "Hp": Hp, "W": W, "Cin": Cin, "Cout": Cout, "mode": mode, "algo": "skinny"}
+        hook("pre", info)
+    dp, dseed, ddev = dropout if dropout is not None else (0.0, 0, None)
+    check(_lib.load().ac_conv3x3_bn_relu_skinny(ptr(x), ptr(wfrag), ptr(scale), ptr(shift), ptr(out), B, Hp, H, W, Cin, Cout,
+                                               mode, ptr(workspace), workspace.numel(), float(dp), int(dseed), ddev, stream()),
+          "ac_conv3x3_bn_relu_skinny")
+    if hook is not None:
+        hook("post", info)
+    return out
+
+
 def conv3x3_bn_relu_f16x2_gw(x, wfrag, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode=-1, overflow=None):
     """``out``: fp16 for modes 0 / 1 (an f32 ``out`` with mode 1 selects the f32 pooled output that feeds a split-bf16
     block), f32 for mode 2.  ``overflow``: a uint32 / int32 device word OR-ed with 1 when a value stored as fp16

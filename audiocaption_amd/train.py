@@ -1041,6 +1041,8 @@ class TrainEngine:
             pf = getattr(self, "_pf", None)
             want = int(input_dict.get("dropout_seed", self.seed))   # the caller's seed wins over the one guessed a step ahead
             if pf is None or pf["key"] != self._pf_key(input_dict, want):
+                if pf is not None:
+                    self.lookahead_misses = getattr(self, "lookahead_misses", 0) + 1   # a look-ahead that could not be used
                 self.prefetch_cnn(input_dict, want)
                 pf = self._pf
             self._pf = None

@@ -114,6 +114,21 @@ int ac_conv3x3_bn_relu_wino1d_splitk(const float* in, const void* wfrag, const f
                                      int map_mode, const int* clip_frames, int need_mul, int need_add,
                                      float* workspace, long workspace_floats, void* stream);
 
+/* The same layer for FEW PIXELS and heavy weights (conv blocks 5-6 at one to a few clips: conv2 of block 6 is 64 pixels
+ * against 151 MB of weights): a K-sliced DIRECT convolution on split-bf16 operands built to stream the weights once at
+ * memory bandwidth (csrc/conv3x3_skinny.hip) - 9 taps instead of the 12 / 18 transformed ones, eight fragment groups in
+ * flight per wave, all pixels of up to eight 32-pixel tiles per workgroup; the slices' raw sums go to
+ * workspace[slice][B*Hp*W][Cout] and a second kernel adds them IN ORDER (deterministic) and applies BN / ReLU / pool /
+ * mean and, with drop_p > 0, F.dropout on the output (the mask ac_dropout gives the output buffer; modes 0 and 1).
+ * ConvBlock.forward, cnn_encoder.py:59-75 (+ the pooling / mean of :431-444); the arithmetic of
+ * ac_conv3x3_bn_relu_bf16x3_gw (2^-16 operand error), wfrag = ITS pack ([Cin/32][9][2][Cout/32][hi, lo][64][8] bf16).
+ * W = 4 (modes 0, 1) or 2 (modes 0, 2), Cin % 32 == 0, Cout % 128 == 0, B * Hp * W <= 2048 pixels.
+ * ac_conv3x3_skinny_workspace_floats: floats of workspace the geometry needs, 0 when it is not covered (AC_ERR_ARG). */
+long ac_conv3x3_skinny_workspace_floats(int B, int Hp, int W, int Cin, int Cout);
+int ac_conv3x3_bn_relu_skinny(const float* in, const void* wfrag, const float* scale, const float* shift, float* out, int B,
+                              int Hp, int H, int W, int Cin, int Cout, int mode, float* workspace, long workspace_floats,
+                              float drop_p, unsigned long long drop_seed, const unsigned long long* seed_dev, void* stream);
+
 /* Second generation of the f32-grade tier: the same layer as a 1-D Winograd F(4,3) along time (row QUADS: 6 transformed
  * positions per 4 output rows, 18 instead of 36 products per (cin, cout)) on split-bf16 operands - 1.5 bf16 MFMA products
  * per f32 product (F(2,3): 2) - with ONE 512-register wave per SIMD (csrc/conv3x3_wino43.hip).  Same layouts, epilogue
