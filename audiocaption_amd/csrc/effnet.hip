@@ -10,6 +10,7 @@
 // tensor (LDS atomics per workgroup, one global atomic per channel per workgroup).
 #include "ac_common.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -165,6 +166,78 @@ __global__ __launch_bounds__(256) void depthwise_kernel(DwP p) {
   }
   __syncthreads();
   for (int c = threadIdx.x; c < p.C; c += 256) atomicAdd(p.pool + (long)b * p.C + c, spool[c] * p.pool_scale);
+}
+
+// The same layer for stride 1 and a NARROW mel axis (F = 2, 4, 8: the 63 x 4 and 32 x 2 stages, 17 of EfficientNet-B2's 23
+// depthwise layers): lane = channel group of 4, wave = a chunk of consecutive output rows (time); a thread keeps the K input
+// rows x F columns of its window in registers and SLIDES ALONG TIME - one new input row (F 16-byte loads, requested a row
+// ahead) per F output positions, instead of re-reading K rows per output row.  A wave instruction reads / writes 64 channel
+// groups = 1 KiB contiguous.  The squeeze sums of a workgroup's four chunks meet in LDS: one atomic per channel and workgroup.
+template <int K, int F>
+__global__ __launch_bounds__(256) void depthwise_rows_kernel(DwP p, int lc) {
+  __shared__ __attribute__((aligned(16))) float spart[4][64 * 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, C4 = p.C >> 2;
+  const int cg = blockIdx.x * 64 + lane;
+  const int chunk = blockIdx.z * 4 + wave;
+  const int to0 = chunk * lc, to1 = min(p.To, to0 + lc);
+  const bool act = cg < C4 && to0 < to1;
+  const int c = (act ? cg : 0) * 4;
+  const float* xb = p.x + (long)b * p.T * F * p.C + c;
+  float* yb = p.y + (long)b * p.To * F * p.C + c;
+  f32x4 psum = {0.f, 0.f, 0.f, 0.f};
+  if (act) {
+    const f32x4 sc = *(const f32x4*)(p.scale + c), sh = *(const f32x4*)(p.shift + c);
+    f32x4 w[K][K];
+#pragma unroll
+    for (int kt = 0; kt < K; ++kt)
+#pragma unroll
+      for (int kf = 0; kf < K; ++kf) w[kt][kf] = *(const f32x4*)(p.w + (long)(kt * K + kf) * p.C + c);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto load_row = [&](int t, f32x4 (&dst)[F]) {   // input row t (zeros outside the image)
+      const bool ok = t >= 0 && t < p.T;
+      const float* rp = xb + (long)(ok ? t : 0) * F * p.C;
+#pragma unroll
+      for (int f = 0; f < F; ++f) dst[f] = ok ? *(const f32x4*)(rp + (long)f * p.C) : zero4;
+    };
+    f32x4 win[K][F], nxt[F];
+#pragma unroll
+    for (int kt = 0; kt + 1 < K; ++kt) load_row(to0 - p.pb + kt, win[kt + 1]);   // rows of the first window but its last, shifted below
+    load_row(to0 - p.pb + K - 1, nxt);
+    for (int to = to0; to < to1; ++to) {
+#pragma unroll
+      for (int kt = 0; kt + 1 < K; ++kt)
+#pragma unroll
+        for (int f = 0; f < F; ++f) win[kt][f] = win[kt + 1][f];
+#pragma unroll
+      for (int f = 0; f < F; ++f) win[K - 1][f] = nxt[f];
+      if (to + 1 < to1) load_row(to + 1 - p.pb + K - 1, nxt);   // in flight under this row's arithmetic
+#pragma unroll
+      for (int fo = 0; fo < F; ++fo) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < K; ++kt)
+#pragma unroll
+          for (int kf = 0; kf < K; ++kf) {
+            const int f = fo - (K - 1) / 2 + kf;   // "same" padding of an odd kernel at stride 1 (pad_before == (K - 1) / 2)
+            if (f >= 0 && f < F) acc += win[kt][f] * w[kt][kf];
+          }
+        f32x4 v = acc * sc + sh;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = swishf(v[j]);
+        psum += v;
+        *(f32x4*)(yb + ((long)to * F + fo) * p.C) = v;
+      }
+    }
+  }
+  *(f32x4*)(&spart[wave][lane * 4]) = psum;
+  __syncthreads();
+  if (wave == 0 && cg < C4) {
+    const f32x4 t = (*(const f32x4*)(&spart[0][lane * 4]) + *(const f32x4*)(&spart[1][lane * 4])) +
+                    (*(const f32x4*)(&spart[2][lane * 4]) + *(const f32x4*)(&spart[3][lane * 4]));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) atomicAdd(p.pool + (long)b * p.C + cg * 4 + j, t[j] * p.pool_scale);
+  }
 }
 
 // ---- squeeze-excite gate: g[b][c] = sigmoid(W2 swish(W1 mean[b] + b1) + b2) -----------------------------------------
@@ -391,6 +464,20 @@ int ac_effnet_depthwise(const float* x, const float* w, const float* scale, cons
     const char* e = getenv("AUDIOCAPTION_DW_ROWS");
     mult = e ? atoi(e) : 4;   // measured at 128 clips: 2 -> 4 rows per thread -6...-16 us on the 63 x 4 and 32 x 2 stages, 8 and 16 slower
     if (mult < 1) mult = 1;
+  }
+  // stride 1, "same" padding, a narrow mel axis: the rows-in-registers form (AUDIOCAPTION_DW_ROWS_KERNEL=0: the form below)
+  static const bool rows_kernel = !(getenv("AUDIOCAPTION_DW_ROWS_KERNEL") && !strcmp(getenv("AUDIOCAPTION_DW_ROWS_KERNEL"), "0"));
+  if (rows_kernel && stride == 1 && pad_before == (k - 1) / 2 && p.Fo == F && p.To == T &&
+      (F == 2 || F == 4 || (F == 8 && k == 3))) {
+    const int lc = T >= 96 ? 16 : (T >= 48 ? 16 : 8);      // output rows per wave: 4 halo rows per 16 / 8
+    dim3 g((C4 + 63) / 64, B, ((p.To + lc - 1) / lc + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+    if (k == 5 && F == 2) hipLaunchKernelGGL((depthwise_rows_kernel<5, 2>), g, dim3(256), 0, st, p, lc);
+    else if (k == 5) hipLaunchKernelGGL((depthwise_rows_kernel<5, 4>), g, dim3(256), 0, st, p, lc);
+    else if (F == 2) hipLaunchKernelGGL((depthwise_rows_kernel<3, 2>), g, dim3(256), 0, st, p, lc);
+    else if (F == 4) hipLaunchKernelGGL((depthwise_rows_kernel<3, 4>), g, dim3(256), 0, st, p, lc);
+    else hipLaunchKernelGGL((depthwise_rows_kernel<3, 8>), g, dim3(256), 0, st, p, lc);
+    return ac_check_launch();
   }
   int rpb = rstep * mult;
   if (rpb > p.To) rpb = p.To;

@@ -97,6 +97,30 @@ def test_depthwise_kernel_and_squeeze_sums(lib, k, stride, pad, C):
     assert rel("squeeze sums", pool, ref.sum(dim=(2, 3))) < 1e-5
 
 
+@pytest.mark.parametrize("k,Fm,T,C,B", [(5, 4, 63, 720, 3), (5, 2, 32, 1248, 2), (3, 4, 63, 528, 2), (3, 2, 32, 2112, 2),
+                                        (3, 8, 126, 288, 2), (5, 4, 7, 48, 3), (3, 2, 1, 8, 1), (5, 2, 94, 1248, 1), (5, 4, 188, 132, 1)])
+def test_depthwise_rows_in_registers_form(lib, k, Fm, T, C, B, monkeypatch):
+    """Stride 1 on a narrow mel axis (the 63 x 4 and 32 x 2 stages; 188 / 94 rows: 30 s clips): the form that keeps the K x F
+    window in registers and slides along time (csrc/effnet.hip depthwise_rows_kernel) against F.conv2d, chunk borders
+    (partial last chunk, a single row), channel counts that leave lanes idle, and the squeeze sums."""
+    g = torch.Generator().manual_seed(k * 100 + Fm * 10 + T)
+    x = torch.randn(B, T, Fm, C, generator=g)
+    w = torch.randn(C, 1, k, k, generator=g) * 0.3
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    pad = (k - 1) // 2
+    ref = F.conv2d(F.pad(x.permute(0, 3, 2, 1), (pad, pad, pad, pad)), w, stride=1, groups=C)
+    ref = ref * sc[None, :, None, None] + sh[None, :, None, None]
+    ref = ref * torch.sigmoid(ref)
+    ref_cl = ref.permute(0, 3, 2, 1).contiguous()
+    y = torch.full(ref_cl.shape, 7.0, device="cuda")
+    pool = torch.zeros(B, C, device="cuda")
+    wp = w[:, 0].permute(2, 1, 0).contiguous().cuda()
+    assert lib.ac_effnet_depthwise(P(x.cuda()), P(wp), P(sc.cuda()), P(sh.cuda()), P(y), P(pool), 0.5, B, T, Fm, C, k, 1, pad, pad,
+                                   S()) == 0
+    assert rel(f"depthwise rows form k{k} F{Fm} T{T} C{C}", y, ref_cl) < 1e-5
+    assert rel("squeeze sums", pool, 0.5 * ref.sum(dim=(2, 3))) < 1e-5
+
+
 @pytest.mark.parametrize("k,stride,pad,Fm,cin,mid", [(3, 1, (1, 1), 16, 24, 144), (3, 2, (0, 1), 32, 16, 96),
                                                      (5, 2, (2, 2), 10, 24, 144), (5, 1, (2, 2), 4, 88, 528),
                                                      (3, 2, (1, 1), 8, 48, 288), (5, 1, (2, 2), 2, 208, 1248)])
