@@ -168,18 +168,23 @@ __global__ __launch_bounds__(256) void depthwise_kernel(DwP p) {
   for (int c = threadIdx.x; c < p.C; c += 256) atomicAdd(p.pool + (long)b * p.C + c, spool[c] * p.pool_scale);
 }
 
-// The same layer for stride 1 and a NARROW mel axis (F = 2, 4, 8: the 63 x 4 and 32 x 2 stages, 17 of EfficientNet-B2's 23
-// depthwise layers): lane = channel group of 4, wave = a chunk of consecutive output rows (time); a thread keeps the K input
+// The same layer for stride 1 and a NARROW mel axis (F = 2 ... 16: 21 of EfficientNet-B2's 23 depthwise layers): lane = channel group of 4, wave = a chunk of consecutive output rows (time); a thread keeps the K input
 // rows x F columns of its window in registers and SLIDES ALONG TIME - one new input row (F 16-byte loads, requested a row
 // ahead) per F output positions, instead of re-reading K rows per output row.  A wave instruction reads / writes 64 channel
 // groups = 1 KiB contiguous.  The squeeze sums of a workgroup's four chunks meet in LDS: one atomic per channel and workgroup.
-template <int K, int F>
+template <int K, int F, int HALVES>
 __global__ __launch_bounds__(256) void depthwise_rows_kernel(DwP p, int lc) {
+  // HALVES = 2 (F = 8 at K = 5, F = 16): a thread owns HALF of the output columns and keeps the F / 2 + (K - 1) / 2 input
+  // columns they read - the window fits the registers at 1.25-1.5x the loads
+  constexpr int PAD = (K - 1) / 2, NO = F / HALVES, NW = HALVES == 1 ? F : NO + PAD;
   __shared__ __attribute__((aligned(16))) float spart[4][64 * 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.y, C4 = p.C >> 2;
   const int cg = blockIdx.x * 64 + lane;
-  const int chunk = blockIdx.z * 4 + wave;
+  const int hv = HALVES == 1 ? 0 : (int)(blockIdx.z % HALVES);
+  const int chunk = (int)(blockIdx.z / HALVES) * 4 + wave;
+  const int o0 = hv * NO;                               // first output column of this thread
+  const int cw0 = HALVES == 1 ? 0 : (hv == 0 ? 0 : o0 - PAD);   // first input column of its window
   const int to0 = chunk * lc, to1 = min(p.To, to0 + lc);
   const bool act = cg < C4 && to0 < to1;
   const int c = (act ? cg : 0) * 4;
@@ -194,13 +199,13 @@ __global__ __launch_bounds__(256) void depthwise_rows_kernel(DwP p, int lc) {
 #pragma unroll
       for (int kf = 0; kf < K; ++kf) w[kt][kf] = *(const f32x4*)(p.w + (long)(kt * K + kf) * p.C + c);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    auto load_row = [&](int t, f32x4 (&dst)[F]) {   // input row t (zeros outside the image)
+    auto load_row = [&](int t, f32x4 (&dst)[NW]) {   // input row t, columns cw0 .. cw0 + NW - 1 (zeros outside the image)
       const bool ok = t >= 0 && t < p.T;
-      const float* rp = xb + (long)(ok ? t : 0) * F * p.C;
+      const float* rp = xb + ((long)(ok ? t : 0) * F + cw0) * p.C;
 #pragma unroll
-      for (int f = 0; f < F; ++f) dst[f] = ok ? *(const f32x4*)(rp + (long)f * p.C) : zero4;
+      for (int j = 0; j < NW; ++j) dst[j] = ok ? *(const f32x4*)(rp + (long)j * p.C) : zero4;
     };
-    f32x4 win[K][F], nxt[F];
+    f32x4 win[K][NW], nxt[NW];
 #pragma unroll
     for (int kt = 0; kt + 1 < K; ++kt) load_row(to0 - p.pb + kt, win[kt + 1]);   // rows of the first window but its last, shifted below
     load_row(to0 - p.pb + K - 1, nxt);
@@ -208,25 +213,33 @@ __global__ __launch_bounds__(256) void depthwise_rows_kernel(DwP p, int lc) {
 #pragma unroll
       for (int kt = 0; kt + 1 < K; ++kt)
 #pragma unroll
-        for (int f = 0; f < F; ++f) win[kt][f] = win[kt + 1][f];
+        for (int j = 0; j < NW; ++j) win[kt][j] = win[kt + 1][j];
 #pragma unroll
-      for (int f = 0; f < F; ++f) win[K - 1][f] = nxt[f];
+      for (int j = 0; j < NW; ++j) win[K - 1][j] = nxt[j];
       if (to + 1 < to1) load_row(to + 1 - p.pb + K - 1, nxt);   // in flight under this row's arithmetic
 #pragma unroll
-      for (int fo = 0; fo < F; ++fo) {
+      for (int oo = 0; oo < NO; ++oo) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < K; ++kt)
 #pragma unroll
           for (int kf = 0; kf < K; ++kf) {
-            const int f = fo - (K - 1) / 2 + kf;   // "same" padding of an odd kernel at stride 1 (pad_before == (K - 1) / 2)
-            if (f >= 0 && f < F) acc += win[kt][f] * w[kt][kf];
+            // input column of tap kf for output column o0 + oo ("same" padding of an odd kernel at stride 1), as a window
+            // slot: HALVES == 1 or the first half: slot = column; second half: slot = column - (o0 - PAD)
+            const int rel = oo - PAD + kf;                    // column - o0
+            const int slot0 = rel;                            // first half / whole row: o0 == cw0 == 0
+            const int slot1 = rel + PAD;                      // second half: cw0 = o0 - PAD
+            if (HALVES == 1 || hv == 0) {
+              if (slot0 >= 0 && slot0 < NW) acc += win[kt][slot0 < 0 ? 0 : (slot0 < NW ? slot0 : 0)] * w[kt][kf];
+            } else {
+              if (slot1 >= 0 && slot1 < NW && o0 + rel < F) acc += win[kt][slot1 < NW ? slot1 : 0] * w[kt][kf];
+            }
           }
         f32x4 v = acc * sc + sh;
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = swishf(v[j]);
         psum += v;
-        *(f32x4*)(yb + ((long)to * F + fo) * p.C) = v;
+        *(f32x4*)(yb + ((long)to * F + o0 + oo) * p.C) = v;
       }
     }
   }
@@ -468,15 +481,18 @@ int ac_effnet_depthwise(const float* x, const float* w, const float* scale, cons
   // stride 1, "same" padding, a narrow mel axis: the rows-in-registers form (AUDIOCAPTION_DW_ROWS_KERNEL=0: the form below)
   static const bool rows_kernel = !(getenv("AUDIOCAPTION_DW_ROWS_KERNEL") && !strcmp(getenv("AUDIOCAPTION_DW_ROWS_KERNEL"), "0"));
   if (rows_kernel && stride == 1 && pad_before == (k - 1) / 2 && p.Fo == F && p.To == T &&
-      (F == 2 || F == 4 || (F == 8 && k == 3))) {
-    const int lc = T >= 96 ? 16 : (T >= 48 ? 16 : 8);      // output rows per wave: 4 halo rows per 16 / 8
-    dim3 g((C4 + 63) / 64, B, ((p.To + lc - 1) / lc + 3) / 4);
+      (F == 2 || F == 4 || F == 8 || (F == 16 && k == 3))) {
+    const int lc = T >= 48 ? 16 : 8;                        // output rows per wave: 4 (2) halo rows per 16 / 8
+    const int halves = (F == 16 || (F == 8 && k == 5)) ? 2 : 1;
+    dim3 g((C4 + 63) / 64, B, (((p.To + lc - 1) / lc + 3) / 4) * halves);
     hipStream_t st = (hipStream_t)stream;
-    if (k == 5 && F == 2) hipLaunchKernelGGL((depthwise_rows_kernel<5, 2>), g, dim3(256), 0, st, p, lc);
-    else if (k == 5) hipLaunchKernelGGL((depthwise_rows_kernel<5, 4>), g, dim3(256), 0, st, p, lc);
-    else if (F == 2) hipLaunchKernelGGL((depthwise_rows_kernel<3, 2>), g, dim3(256), 0, st, p, lc);
-    else if (F == 4) hipLaunchKernelGGL((depthwise_rows_kernel<3, 4>), g, dim3(256), 0, st, p, lc);
-    else hipLaunchKernelGGL((depthwise_rows_kernel<3, 8>), g, dim3(256), 0, st, p, lc);
+    if (k == 5 && F == 2) hipLaunchKernelGGL((depthwise_rows_kernel<5, 2, 1>), g, dim3(256), 0, st, p, lc);
+    else if (k == 5 && F == 4) hipLaunchKernelGGL((depthwise_rows_kernel<5, 4, 1>), g, dim3(256), 0, st, p, lc);
+    else if (k == 5) hipLaunchKernelGGL((depthwise_rows_kernel<5, 8, 2>), g, dim3(256), 0, st, p, lc);
+    else if (F == 2) hipLaunchKernelGGL((depthwise_rows_kernel<3, 2, 1>), g, dim3(256), 0, st, p, lc);
+    else if (F == 4) hipLaunchKernelGGL((depthwise_rows_kernel<3, 4, 1>), g, dim3(256), 0, st, p, lc);
+    else if (F == 8) hipLaunchKernelGGL((depthwise_rows_kernel<3, 8, 1>), g, dim3(256), 0, st, p, lc);
+    else hipLaunchKernelGGL((depthwise_rows_kernel<3, 16, 2>), g, dim3(256), 0, st, p, lc);
     return ac_check_launch();
   }
   int rpb = rstep * mult;

@@ -98,7 +98,8 @@ def test_depthwise_kernel_and_squeeze_sums(lib, k, stride, pad, C):
 
 
 @pytest.mark.parametrize("k,Fm,T,C,B", [(5, 4, 63, 720, 3), (5, 2, 32, 1248, 2), (3, 4, 63, 528, 2), (3, 2, 32, 2112, 2),
-                                        (3, 8, 126, 288, 2), (5, 4, 7, 48, 3), (3, 2, 1, 8, 1), (5, 2, 94, 1248, 1), (5, 4, 188, 132, 1)])
+                                        (3, 8, 126, 288, 2), (5, 4, 7, 48, 3), (3, 2, 1, 8, 1), (5, 2, 94, 1248, 1), (5, 4, 188, 132, 1),
+                                        (5, 8, 126, 288, 2), (3, 16, 251, 144, 2), (5, 8, 5, 16, 1), (3, 16, 17, 260, 1)])
 def test_depthwise_rows_in_registers_form(lib, k, Fm, T, C, B, monkeypatch):
     """Stride 1 on a narrow mel axis (the 63 x 4 and 32 x 2 stages; 188 / 94 rows: 30 s clips): the form that keeps the K x F
     window in registers and slides along time (csrc/effnet.hip depthwise_rows_kernel) against F.conv2d, chunk borders
