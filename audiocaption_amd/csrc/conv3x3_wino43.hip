@@ -18,19 +18,20 @@
 // within 3e-5 of the fp32 CPU reference, the same as F(2,3) and the direct split form (tests/wino_split_emulation.py).
 //
 // Work decomposition.  Six accumulator sets per (pixel tile, channel tile) do not fit two waves per SIMD, so a workgroup is
-// FOUR waves, one per SIMD, each with up to 512 registers: a wave owns 32 output channels x MW = 3 (2) MFMA tiles of 32
-// (quad, column) pixels x 6 positions = 288 (192) accumulator registers, and every weight fragment pair it fetches from L2
-// feeds 9 (6) MFMAs (the F(2,3) kernel: 6) - per output a third of the weight bytes through the L1.  A workgroup covers
+// FOUR waves, one per SIMD, each with up to 512 registers: a wave owns 32 output channels x MW = 2 MFMA tiles of 32
+// (quad, column) pixels x 6 positions = 192 accumulator registers, and every weight fragment pair it fetches from L2
+// feeds 6 MFMAs.  (MW = 1, 96 accumulators and <= 256 registers: half-size workgroups, two to a CU - the layer whose K
+// loop is shorter than a workgroup's prologue + epilogue; three tiles per wave, 288 accumulators: hipcc keeps every MFMA
+// accumulator in the 256 AGPRs and shuffles the rest through VGPRs, +50 %: not kept.)  A workgroup covers
 // the FULL image width (W = 32, 16, 8, 4 = blocks 2 .. 5) x PQ = MW * 32 / W quads x 128 channels; the two halo columns
 // beside the image are LDS columns that stay zero.  The K loop runs in 16-channel steps over double-buffered V planes in
 // LDS ([position][hi | lo][k-half][column][quad] items of 8 channels = 16 bytes, column pitch chosen so that the 16 lanes
 // of every ds_read_b128 group land in 16 different bank slots).  One wave per SIMD means nothing hides a stall but the
-// wave's own instruction stream, so the step is one straight-line block: the raw rows of step s + 2 are requested in the
-// middle of step s (a whole step of latency, the registers are free by then), the rows of step s + 1 are transformed,
-// split and stored a piece per MFMA group (waves 0-1 / 2-3 share the 128 odd items position-wise so that every lane has
-// work in every piece), the A fragments of a group are read one group ahead, the weight fragments two groups ahead, and
-// the single barrier of a step sits one group before its end so that the first fragments of the next step are read
-// under the last group's MFMAs.
+// wave's own instruction stream, so the step is one straight-line block: the raw rows of steps s + 2 and s + 3 are
+// requested together in the middle of every even step (full 128-byte lines; a step or two of latency), the rows of step
+// s + 1 are transformed, split and stored a piece per MFMA group, the A fragments of a group are read two groups ahead,
+// the weight fragments eight groups ahead in a register ring, and the single barrier of a step sits before its last two
+// groups so that the first fragments of the next step are read under their MFMAs.
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
@@ -123,7 +124,7 @@ __device__ __forceinline__ bool w4_block_map(const W4Params& p, int& m_tile, int
 template <int TC, int MW>
 struct W4Geom {
   static_assert(TC == 32 || TC == 16 || TC == 8 || TC == 4 || TC == 2, "full-width blocks of 32, 16, 8, 4 or 2 mel columns");
-  static_assert(MW == 2 || MW == 3, "two or three MFMA tiles per wave");
+  static_assert(MW == 1 || MW == 2, "one or two MFMA tiles per wave");
   // TC = 2 (conv block 6): COLUMN tiles - tile m is column m of 32 quads, so the taps that read the zero padding beside the
   // image (kx = 0 of column 0, kx = 2 of column 1: a third of the products) are skipped at compile time, and no halo
   // column is staged
@@ -139,13 +140,17 @@ struct W4Geom {
   static constexpr int HALF = ((LCOLS * COLP * 16 + 127) / 128) * 128 + 64;   // bytes of one k-half of a plane (= 64 mod 128:
   static constexpr int PLANE = 2 * HALF;      //   the 8-byte stores of channels 0-7 / 8-15 of four items hit different banks)
   static constexpr int VBUF = 12 * PLANE;     // 6 positions x (hi, lo)
-  static constexpr int NITEM = PQ * TC * 4;   // staging items (quad, column, channel quad) of a step: 384 (MW 3) or 256
-  static_assert(NITEM == 256 || NITEM == 384, "one item per thread, plus half of a shared one for MW = 3");
-  static constexpr int NPIECE = MW == 3 ? 9 : 6;
+  static constexpr int NITEM = PQ * TC * 4;   // staging items (quad, column, channel quad) of a step: 256 (MW 2) or 128
+  static_assert(NITEM == 256 || NITEM == 128, "one item per thread (MW = 1: per thread of waves 0 and 1)");
+  static constexpr int NPIECE = 6;
 };
 
+// MW = 1: HALF-SIZE workgroups - 96 accumulators and <= 256 registers per wave, so TWO workgroups share a CU and one's
+// prologue / epilogue (8 k + 6-14 k cycles: as long as the 4-step K loop of conv1 of block 2) runs under the other's K loop.
+// A weight fragment pair then feeds 3 MFMAs instead of 6: twice the weight bytes through the L1 per product, which is why
+// the long-K layers keep MW = 2 (see w4_dispatch).
 template <int MODE, int TC, int MW>
-__global__ __launch_bounds__(256, 1) void conv3x3_w4_kernel(W4Params p) {
+__global__ __launch_bounds__(256, MW == 1 ? 2 : 1) void conv3x3_w4_kernel(W4Params p) {
   using G = W4Geom<TC, MW>;
   constexpr int QT = G::QT, PQ = G::PQ, COLP = G::COLP, HALF = G::HALF, PLANE = G::PLANE, VBUF = G::VBUF;
   constexpr int NPIECE = G::NPIECE;
@@ -211,24 +216,20 @@ __global__ __launch_bounds__(256, 1) void conv3x3_w4_kernel(W4Params p) {
     };
 
     // Staging items.  Item it = (channel quad it & 3, quad (it >> 2) % PQ, column (it >> 2) / PQ).  Thread t owns item t
-    // whole; MW = 3: items 256 + (t & 127) are shared by threads t and t + 128 position-wise (waves 0-1: V0..V2 from rows
-    // d0..d4, waves 2-3: V3..V5 from rows d1..d5).
+    // whole (MW = 1: the 128 items belong to waves 0 and 1; waves 2 and 3 stage nothing).
     const unsigned row_bytes = (unsigned)row_elems * 4u;
-    unsigned vbA, lofsA, vbB = 0, lofsB = 0;
+    const bool stager = tid < G::NITEM;   // wave-uniform
+    unsigned vbA, lofsA;
     {
       auto item = [&](int it, unsigned& vb, unsigned& lofs) {
         const int cq = it & 3, rest = it >> 2, quad = rest % PQ, c = rest / PQ;
         vb = (unsigned)(((4 * quad - first) * p.W + c) * p.Cin * 4 + cq * 16);
         lofs = (unsigned)((cq >> 1) * HALF + ((c + (G::COLT ? 0 : 1)) * COLP + quad) * 16 + (cq & 1) * 8);
       };
-      item(tid, vbA, lofsA);
-      if (MW == 3) item(256 + (tid & 127), vbB, lofsB);
+      item(stager ? tid : 0, vbA, lofsA);
     }
 
-    // HPB (MW = 3): first position of this wave's share of the shared item, 0 or 3
-    auto run = [&](auto HPB_) {
-      constexpr int HPB = decltype(HPB_)::value;
-      constexpr int RB = HPB ? 1 : 0;      // first row of the shared item this wave needs
+    auto run = [&]() {
       // PAIR (two tiles per wave): a K step is 16 channels = 64 bytes of a pixel's channel vector, HALF a 128-byte line; asked
       // for a step apart, the second half found the line gone from L1 and L2 (an XCD's 32 workgroups pull 5 MB through a 4 MB
       // L2 per step) and the fabric delivered every input line twice (tools/traffic_calib.hip: FETCH_SIZE of this pattern =
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_w4_kernel(W4Params p) {
       // every even step s, into two register sets: the rows of step r live in set r & 1 (`rwp`).
       constexpr bool PAIR = W4_ROWPAIR && MW == 2;
       static_assert(!PAIR || W4_PRO2, "the paired form starts from the two-step prologue");
-      f32x4 preA[6], preB[5], rwp[PAIR ? 6 : 1];   // preA = set 0, rwp = set 1
+      f32x4 preA[6], rwp[PAIR ? 6 : 1];   // preA = set 0, rwp = set 1
       auto rows_request_pair = [&](int s) {   // rows of steps s (set 0) and s + 1 (set 1): the two halves of a line back to back
         if (W4_KO & 8) { if (s > 1) return; }
         const unsigned cs = (unsigned)(s * KS * 4);
@@ -248,15 +249,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_w4_kernel(W4Params p) {
       };
       auto rows_request = [&](int s) {
         if (W4_KO & 8) { if (s) return; }
+        if (!stager) return;
         const unsigned cs = (unsigned)(s * KS * 4);
 #pragma unroll
         for (int r = 0; r < 6; ++r)
           preA[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, vbA + cs + (unsigned)r * row_bytes, 0, 0));
-        if (MW == 3) {
-#pragma unroll
-          for (int r = 0; r < 5; ++r)
-            preB[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, vbB + cs + (unsigned)(r + RB) * row_bytes, 0, 0));
-        }
       };
       auto store_piece = [&](unsigned char* buf, unsigned lofs, int pos, const f32x4 v) {
         u32x2 hi, lo;
@@ -265,7 +262,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_w4_kernel(W4Params p) {
         *(u32x2*)dst = hi;
         *(u32x2*)(dst + PLANE) = lo;
       };
-      // piece k of a step: 0..5 = positions of the own item, 6..8 = this wave's positions of the shared item
+      // piece k of a step: position k of the thread's item
       auto commit_piece_set1 = [&](unsigned char* buf, int k) {   // PAIR: piece k of the rows in set 1
         if (W4_KO & 4) return;
         store_piece(buf, lofsA, k, w4_transform(k, rwp[0], rwp[PAIR ? 1 : 0], rwp[PAIR ? 2 : 0], rwp[PAIR ? 3 : 0],
@@ -273,14 +270,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_w4_kernel(W4Params p) {
       };
       auto commit_piece = [&](unsigned char* buf, int k) {
         if (W4_KO & 4) return;
-        if (k < 6) {
-          store_piece(buf, lofsA, k, w4_transform(k, preA[0], preA[1], preA[2], preA[3], preA[4], preA[5]));
-        } else {
-          const int pos = HPB + (k - 6);
-          const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-          if (HPB == 0) store_piece(buf, lofsB, pos, w4_transform(pos, preB[0], preB[1], preB[2], preB[3], preB[4], z));
-          else store_piece(buf, lofsB, pos, w4_transform(pos, z, preB[0], preB[1], preB[2], preB[3], preB[4]));
-        }
+        if (!stager) return;
+        store_piece(buf, lofsA, k, w4_transform(k, preA[0], preA[1], preA[2], preA[3], preA[4], preA[5]));
       };
       // column tiles: tap kx of tile (= column) m reads column m + kx - 1, which exists for (m, kx) in {(0,1), (0,2), (1,0), (1,1)}
       auto tap_valid = [](int m, int kx) { return !G::COLT || (m + kx - 1 >= 0 && m + kx - 1 <= 1); };
@@ -306,7 +297,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_w4_kernel(W4Params p) {
           *(f32x4*)(sV + b * VBUF + hh * HALF + ((col ? TC + 1 : 0) * COLP + slot) * 16) = z;
         }
       }
-      constexpr int RING = W4_RING, AH = RING - 1, NA = W4_ADEPTH + 1, LASTG = 17 - W4_ADEPTH;
+      constexpr int RING = MW == 1 ? 6 : W4_RING, AH = RING - 1, NA = W4_ADEPTH + 1, LASTG = 17 - W4_ADEPTH;   // MW = 1: 256 registers
       static_assert(18 % RING == 0 && 18 % NA == 0 && NPIECE <= LASTG, "ring positions are static; staging ends before the barrier");
       bf16x8 wr[RING][2];   // ring of weight fragments: group gi lives in wr[gi % RING], requested RING - 1 groups ahead
 #if W4_PRO2
@@ -412,8 +403,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_w4_kernel(W4Params p) {
         step(nstep - 1, std::false_type{}, std::false_type{});
       }
     };
-    if (MW == 3 && wave >= 2) run(std::integral_constant<int, 3>{});
-    else run(std::integral_constant<int, 0>{});
+    run();
   }
 
   W4_STAMP(clk_t2);
@@ -560,14 +550,9 @@ int launch_w4(W4Params p, hipStream_t s) {
   return ac_check_launch();
 }
 
-#ifndef W4_MW3   // development: the three-tile form (288 accumulators exceed the 256 AGPRs: hipcc shuffles them through VGPRs)
-#define W4_MW3 0
-#endif
 template <int MODE, int TC>
 int launch_w4_mw(const W4Params& p, int mw, hipStream_t s) {
-#if W4_MW3
-  if (mw == 3) return launch_w4<MODE, TC, 3>(p, s);
-#endif
+  if (mw == 1) return launch_w4<MODE, TC, 1>(p, s);
   return launch_w4<MODE, TC, 2>(p, s);
 }
 
@@ -595,6 +580,9 @@ static int w4_dispatch(const float* in, const void* wfrag, const float* scale, c
   p.MT = 0;
   p.NT = Cout / 128;
   p.Hp_out = Hp / 2; p.H_out = H / 2; p.W_out = W / 2;
+#ifndef W4_MW1_STEPS   // layers of up to this many 16-channel K steps run as half-size workgroups (tiles_per_wave = 0).
+#define W4_MW1_STEPS 4 // Measured at B = 64 (profiles/r05_w4_kloop_experiments.txt): conv1 of block 2 (4 steps) 374 -> 324-340 us;
+#endif                 // 8 steps (b2c2, b3c1) +5 %, 16 (b3c2, b4c1) +13 %, longer +20 %: twice the weight bytes per product through the L1
 #ifndef W4_DEFAULT_MAP
 #define W4_DEFAULT_MAP 4
 #endif
@@ -605,15 +593,12 @@ static int w4_dispatch(const float* in, const void* wfrag, const float* scale, c
   p.map_mode = map_mode;
   p.clip_frames = clip_frames; p.need_mul = need_mul; p.need_add = need_add;
   p.drop = drop;
-  if (mw != 2 && mw != 3) {
-    // three tiles per wave (9 MFMAs per weight fragment pair) unless two leave fewer idle CUs in the last round of workgroups
-    auto waste = [&](int m) {
-      const long g = w4_grid(p.rows_total, W, Cout, m);
-      const long rounds = (g + 255) / 256;
-      return (double)(rounds * 256 - g) / (double)(rounds * 256);
-    };
-    mw = (waste(3) > waste(2) + 0.12) ? 2 : 3;
+  if (mw != 1 && mw != 2) {
+    // half-size workgroups (two per CU) where a workgroup's prologue + epilogue is a large part of its life: short K loops
+    static const int mw1_max_steps = getenv("AUDIOCAPTION_W4_MW1_STEPS") ? atoi(getenv("AUDIOCAPTION_W4_MW1_STEPS")) : W4_MW1_STEPS;
+    mw = (W != 2 && Cin / KS <= mw1_max_steps) ? 1 : 2;
   }
+  if (W == 2) mw = 2;   // column tiles
   hipStream_t s = (hipStream_t)stream;
 #define W4_CASE(TCV)                                                                     \
   if (W == TCV) return mode == MODE_FULL ? launch_w4_mw<MODE_FULL, TCV>(p, mw, s) : launch_w4_mw<MODE_POOL, TCV>(p, mw, s);

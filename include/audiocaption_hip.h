@@ -137,8 +137,9 @@ int ac_conv3x3_bn_relu_skinny(const float* in, const void* wfrag, const float* s
  * (conv blocks 2-5; modes 0, 1) and W = 2 (block 6: column tiles that skip the taps on the zero padding; modes 0 and
  * 2 = mean over the two mel columns, out (B, H, Cout), cnn_encoder.py:443) with Cout % 128 == 0, Cin % 32 == 0,
  * Hp % 4 == 0; wfrag
- * [Cin/16][3 kx x 6 positions][Cout/32][hi, lo][64 lanes][8] bf16 (U = G g in f64, then split).  tiles_per_wave: 3 (288
- * accumulators, 9 MFMAs per weight fragment pair), 2, or 0 = chosen by the launch's last-round occupancy.  The input is
+ * [Cin/16][3 kx x 6 positions][Cout/32][hi, lo][64 lanes][8] bf16 (U = G g in f64, then split).  tiles_per_wave: 2 (192
+ * accumulators, one workgroup per CU), 1 (96 accumulators, <= 256 registers: two workgroups per CU, one's prologue and
+ * epilogue under the other's K loop - the short-K layers), or 0 = chosen by the layer's K steps.  The input is
  * addressed through a buffer descriptor rebased per workgroup, so any B * Hp * W * Cin is accepted (B * Hp < 2^23 rows: the
  * epilogue's row -> clip arithmetic; callers chunk clips beyond it).  Ragged batches: see the contract note above - valid
  * frames within 5e-5 of the dense run with the F(2,3) windows, bit-identical with the quad-wide ones.

@@ -56,9 +56,9 @@ def _case(B, H, W, Cin, Cout, mode, seed):
     (3, 21, 32, 64, 128, 0), (2, 20, 32, 128, 128, 1), (2, 11, 16, 128, 256, 0), (5, 30, 16, 32, 128, 1),
     (2, 9, 8, 256, 512, 1), (3, 50, 8, 256, 512, 0), (3, 7, 4, 512, 1024, 0), (3, 6, 4, 1024, 1024, 1), (1, 95, 4, 512, 1024, 1)])
 @pytest.mark.parametrize("map_mode", [-1, 0])
-@pytest.mark.parametrize("tiles", [2, 3])
+@pytest.mark.parametrize("tiles", [1, 2])
 def test_conv3x3_wino43_vs_conv2d(K, B, H, W, Cin, Cout, mode, map_mode, tiles):
-    """conv3x3 + BN + ReLU (+ 2x2 average pool) vs F.conv2d on the CPU, both tile counts per wave and both block maps.
+    """conv3x3 + BN + ReLU (+ 2x2 average pool) vs F.conv2d on the CPU, both tile counts per wave (half-size workgroups, two per CU, and full-size ones) and both block maps.
     Bar: the split-bf16 tiers' (2^-16 relative operand error on O(1..10) outputs): 1e-3 * sqrt(K / 576)."""
     x, w, sc, sh, Hp, want, shape = _case(B, H, W, Cin, Cout, mode, B * 1000 + H * 10 + W + Cin)
     out = torch.full(shape, 7.0).cuda()
