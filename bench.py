@@ -388,7 +388,7 @@ def bench_train(args, ranks, steps, warmup, with_rccl=False, roofline=True):
         "metric": "clips/sec trained (forward+backward+Adam), Cnn14_Rnn-Trm, AudioCaps-shape batches",
         "value": world * B * steps / elapsed, "unit": "clips/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16x3 (frozen convolutions: F(2,3) Winograd on split-bf16 operands; large GEMMs on split-bf16 operands; f32 "
+        "dtype": "bf16x3 (frozen convolutions: F(4,3) Winograd on split-bf16 operands, the same kernels as inference; large GEMMs on split-bf16 operands; f32 "
                  "accumulation, f32 elsewhere)"
                  if engine.gemm_algo in ("bf16x3", "pw") else "bf16x3 frozen convolutions, f32 everything trained",
         "data": "synthetic",
@@ -518,7 +518,7 @@ def bench_effb2(args, ranks, steps, warmup):
     enc_ms = e0.elapsed_time(e1) / 3
     alg_bytes = 100e6 * (args.seconds / 10.0) * B
     traffic, tsrc = None, None
-    for name in ("r04_traffic_effb2.json", "r03_traffic_effb2.json", "r02_traffic_effb2.json", "r01_traffic_effb2.json"):
+    for name in ("r05_traffic_effb2.json", "r04_traffic_effb2.json", "r03_traffic_effb2.json", "r02_traffic_effb2.json", "r01_traffic_effb2.json"):
         tpath = os.path.join(REPO, "profiles", name)
         if os.path.exists(tpath) and args.seconds == 10.0:
             with open(tpath) as f:   # PMC-measured HBM bytes per clip (collected in separate --pmc passes), scaled to B
@@ -699,7 +699,7 @@ def conv_roofline(tier, events):
     n = len(events)
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     traffic, tsrc = None, None
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         tpath = os.path.join(REPO, "profiles", f"{rnd}_traffic_{t['conv_algo']}.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
@@ -1169,9 +1169,9 @@ def main():
                        "precision": {
                            "wino43": "f32 activations in HBM; 3x3 convolutions as Winograd along time on split-bf16 operands "
                                      "(x = hi + lo, hi*hi + hi*lo + lo*hi, f32 accumulate: 2^-16 operand error) - F(4,3) on conv "
-                                     "blocks 2-5 (input transform in f32, filter transform in f64, both BEFORE the split), "
-                                     "F(2,3) on conv2 of block 1 and block 6 - GRU input projections on split-bf16 operands, "
-                                     "everything else f32",
+                                     "blocks 1-6 (block 1 fused: conv1 computed inside conv2's staging; block 6 as column "
+                                     "tiles; input transform in f32, filter transform in f64, both BEFORE the split) - GRU "
+                                     "input projections on split-bf16 operands, everything else f32",
                            "wino1d": "f32 activations in HBM; 3x3 convolutions as F(2,3) Winograd along time on split-bf16 "
                                      "operands (x = hi + lo, hi*hi + hi*lo + lo*hi, f32 accumulate: 2^-16 operand error), "
                                      "GRU input projections on split-bf16 operands, everything else f32",

@@ -1,7 +1,7 @@
 # Development tool: the profile set committed under profiles/ each round (run on the GPU box from the repo root).
 set -x
 export TMPDIR=/tmp PYTHONPATH=$PWD
-R=${ROUND:-r04}
+R=${ROUND:-r05}
 T=${TIER:-wino43}
 python bench.py > gpurun_out/${R}_bench_final.json 2> gpurun_out/${R}_bench_final.err
 cp gpurun_out/bench_details.json gpurun_out/${R}_bench_details.json
