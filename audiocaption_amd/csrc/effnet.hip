@@ -168,13 +168,13 @@ __global__ __launch_bounds__(256) void depthwise_kernel(DwP p) {
   for (int c = threadIdx.x; c < p.C; c += 256) atomicAdd(p.pool + (long)b * p.C + c, spool[c] * p.pool_scale);
 }
 
-// The same layer for stride 1 and a NARROW mel axis (F = 2 ... 16: 21 of EfficientNet-B2's 23 depthwise layers): lane = channel group of 4, wave = a chunk of consecutive output rows (time); a thread keeps the K input
+// The same layer for stride 1 and a NARROW mel axis (F = 2 ... 16: 19 of EfficientNet-B2's 23 depthwise layers): lane = channel group of 4, wave = a chunk of consecutive output rows (time); a thread keeps the K input
 // rows x F columns of its window in registers and SLIDES ALONG TIME - one new input row (F 16-byte loads, requested a row
 // ahead) per F output positions, instead of re-reading K rows per output row.  A wave instruction reads / writes 64 channel
 // groups = 1 KiB contiguous.  The squeeze sums of a workgroup's four chunks meet in LDS: one atomic per channel and workgroup.
 template <int K, int F, int HALVES>
 __global__ __launch_bounds__(256) void depthwise_rows_kernel(DwP p, int lc) {
-  // HALVES = 2 (F = 8 at K = 5, F = 16): a thread owns HALF of the output columns and keeps the F / 2 + (K - 1) / 2 input
+  // HALVES = 2 (F = 16): a thread owns HALF of the output columns and keeps the F / 2 + (K - 1) / 2 input
   // columns they read - the window fits the registers at 1.25-1.5x the loads
   constexpr int PAD = (K - 1) / 2, NO = F / HALVES, NW = HALVES == 1 ? F : NO + PAD;
   __shared__ __attribute__((aligned(16))) float spart[4][64 * 4];
@@ -481,14 +481,15 @@ int ac_effnet_depthwise(const float* x, const float* w, const float* scale, cons
   // stride 1, "same" padding, a narrow mel axis: the rows-in-registers form (AUDIOCAPTION_DW_ROWS_KERNEL=0: the form below)
   static const bool rows_kernel = !(getenv("AUDIOCAPTION_DW_ROWS_KERNEL") && !strcmp(getenv("AUDIOCAPTION_DW_ROWS_KERNEL"), "0"));
   if (rows_kernel && stride == 1 && pad_before == (k - 1) / 2 && p.Fo == F && p.To == T &&
-      (F == 2 || F == 4 || F == 8 || (F == 16 && k == 3))) {
+      (F == 2 || F == 4 || ((F == 8 || F == 16) && k == 3))) {
+    // (k = 5 at F = 8, 288 channels = 72 channel groups: a 6-column window + 25 weights do not fit 256 registers, and with the
+    // weights in LDS the form takes 160 us against 141 for the one below - 44 % of its lanes have no channel group)
     const int lc = T >= 48 ? 16 : 8;                        // output rows per wave: 4 (2) halo rows per 16 / 8
-    const int halves = (F == 16 || (F == 8 && k == 5)) ? 2 : 1;
+    const int halves = F == 16 ? 2 : 1;
     dim3 g((C4 + 63) / 64, B, (((p.To + lc - 1) / lc + 3) / 4) * halves);
     hipStream_t st = (hipStream_t)stream;
     if (k == 5 && F == 2) hipLaunchKernelGGL((depthwise_rows_kernel<5, 2, 1>), g, dim3(256), 0, st, p, lc);
-    else if (k == 5 && F == 4) hipLaunchKernelGGL((depthwise_rows_kernel<5, 4, 1>), g, dim3(256), 0, st, p, lc);
-    else if (k == 5) hipLaunchKernelGGL((depthwise_rows_kernel<5, 8, 2>), g, dim3(256), 0, st, p, lc);
+    else if (k == 5) hipLaunchKernelGGL((depthwise_rows_kernel<5, 4, 1>), g, dim3(256), 0, st, p, lc);
     else if (F == 2) hipLaunchKernelGGL((depthwise_rows_kernel<3, 2, 1>), g, dim3(256), 0, st, p, lc);
     else if (F == 4) hipLaunchKernelGGL((depthwise_rows_kernel<3, 4, 1>), g, dim3(256), 0, st, p, lc);
     else if (F == 8) hipLaunchKernelGGL((depthwise_rows_kernel<3, 8, 1>), g, dim3(256), 0, st, p, lc);
