@@ -51,6 +51,7 @@ SIGNATURES = {
     "ac_conv3x3_bn_relu_wino43_drop": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _U64, _P, _P]),
     "ac_conv3x3_wino43_workgroups": (_L, [_I, _I, _I, _I]),
     "ac_conv3x3_block1_wino43": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _I, _F, _U64, _P, _P]),
+    "ac_conv3x3_block1_wino43_mfma": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _I, _F, _U64, _P, _P]),
     "ac_conv3x3_block1_conv2_wino43": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ac_conv3x3_bn_relu_f16x2_gw": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "ac_conv3x3_block1_f16x2": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),

@@ -125,6 +125,9 @@ def _conv_wino43(x, w, scale, shift, out, B, Hp, H, W, Cin, Cout, mode, map_mode
                         dropout=dropout)
 
 
+# conv1 of block 1 inside the one-kernel block: "mfma" (split-bf16 product on the matrix cores) | "valu" (the f32 chain of
+# ac_conv3x3_first, bit-identical to the two-kernel form)
+BLOCK1_CONV1 = os.environ.get("AUDIOCAPTION_BLOCK1_CONV1", "mfma")
 SKINNY = os.environ.get("AUDIOCAPTION_SKINNY", "1") != "0"
 SKINNY_MAX_PX = int(os.environ.get("AUDIOCAPTION_SKINNY_MAX_PX", "1024"))   # pixels (B * Hp * W) up to which it is the faster form
 
@@ -432,7 +435,7 @@ class Cnn14Encoder(nn.Module):
             if b == 0 and fuse1_w4:
                 K.conv3x3_block1_wino43(x0, w1, s1, t1, pk["b1c2_f43"], s2, t2, pooled, B, Hp[0], H[0],
                                         dropout=(dropout[0], dropout[1], dropout[2]) if dropout is not None else None,
-                                        **need(1, 2))
+                                        conv1=BLOCK1_CONV1, **need(1, 2))
             elif b == 0 and fuse1:   # conv1 is computed inside conv2's kernel: its 64-channel output never reaches HBM
                 K.conv3x3_block1_f16x2(x0, w1, s1, t1, w2, s2, t2, pooled, B, Hp[0], H[0], W, overflow=overflow)
             elif b == 0:

@@ -15,6 +15,17 @@
 // csrc/conv3x3.hip: bit-identical to the two-kernel form), transforms the two quads (F(4,3): 6 positions each), splits
 // into bf16 hi + lo and stores the planes - one row or two pieces per MFMA group.  !FUSED: the rows come from a
 // 64-channel activation tensor in HBM instead (the unfused reference form of the same kernel; tests).
+//
+// Staging (FORM 2: conv1 on the matrix cores, the default).  The 9-term chain above is 1760 of the 4700 vector
+// instructions of a tile - the kernel was bound by them, not by its 432 MFMAs.  conv1 is a GEMM too: [32 channels] x
+// [K = 16: tap (ky, kx) in slot 4 ky + kx, BN shift in slot 12 against a constant 1] x [32 columns of one row], on the same
+// split-bf16 operands (hi x lo + lo x hi + hi x hi) as conv2, BN scale folded into the taps before the split.  Wave w
+// computes, once per channel tile ct (32 channels = two K steps of conv2), the six rows of quad w >> 1 for columns
+// 32 (w & 1) ..: 18 MFMAs, +8 % on the matrix pipe.  A lane then HOLDS what the staging needs - four groups of four
+// consecutive channels of one column over the six rows of its quad: ReLU, F(4,3) transform, split, plane stores as before;
+// groups 0-1 (the next K step) at once, groups 2-3 (the step after) one step later.  The B operand of row r is two packed
+// log-mel rows (columns c - 1 .. c + 1, four 16-byte loads ahead of time); lanes 32-63 supply ky = 2 and the constant.
+// Not bit-identical to conv_first_kernel any more: conv1 now has the split-bf16 grade of every other layer of the tier.
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
@@ -29,12 +40,24 @@ namespace {
 #define B1_RING 3     // conv2 weight fragment ring (18 % B1_RING == 0): a group's pair is requested B1_RING - 1 groups ahead
 #endif
 
-#ifndef B1_KO    // development: 1 no staging (conv1 / transform / split / plane stores), 2 no MFMAs, 4 no epilogue stores
+#ifndef B1_RING_MFC
+#define B1_RING_MFC 6   // FORM 2 without dropout has the registers for five groups of distance (477 vs 485 us)
+#endif
+#ifndef B1_SGB_MEM
+#define B1_SGB_MEM 0x0b0   // one LDS or memory instruction per gap
+#endif
+#ifndef B1_SGB    // development: > 0 = ask the scheduler for (1 MFMA, B1_SGB vector instructions, 1 LDS, 1 load) x 9 per MFMA group
+#define B1_SGB 0
+#endif
+#ifndef B1_KO    // development: 1 no staging (conv1 / transform / split / plane stores), 2 no MFMAs, 4 no epilogue stores,
+                 // FORM 2: 8 no plane stores, 16 no transform / split / plane stores
 #define B1_KO 0
 #endif
 #ifdef B1_CLK
 __device__ unsigned long long b1_clk[8];
 #endif
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct B1Params {
   const float* in;       // FUSED: [B*Hp][64] log-mel after bn0; else [B*Hp][64][64] conv1 output
@@ -57,11 +80,13 @@ constexpr int B1_HALF = (((B1_W + 2) * B1_COLP * 16 + 127) / 128) * 128 + 64;   
 constexpr int B1_PLANE = 2 * B1_HALF;
 constexpr int B1_VBUF = 12 * B1_PLANE;                                         // 78336
 constexpr int B1_WT = 2 * B1_VBUF;                                             // conv1 table [64][12] floats behind the planes
-constexpr int B1_LDS = B1_WT + 64 * 12 * 4;
+constexpr int B1_LDS = B1_WT + 4096;                                                // FORM 1: 3072 bytes; FORM 2: A operands of conv1
 static_assert(B1_LDS <= 160 * 1024, "LDS");
 
-template <bool FUSED>
+// FORM 0: conv2 on a 64-channel input in HBM; 1: conv1 on the vector ALUs inside the staging; 2: conv1 on the matrix cores
+template <int FORM, bool DROP>
 __global__ __launch_bounds__(256, 1) void block1_w4_kernel(B1Params p) {
+  constexpr bool FUSED = FORM == 1, MFC = FORM == 2;
   constexpr int HALF = B1_HALF, PLANE = B1_PLANE, VBUF = B1_VBUF, COLP = B1_COLP;
   extern __shared__ __attribute__((aligned(128))) unsigned char dsm_raw[];
   unsigned char* sV = dsm_raw;
@@ -106,6 +131,28 @@ __global__ __launch_bounds__(256, 1) void block1_w4_kernel(B1Params p) {
         wt[i] = k < 9 ? p.w1[ch * 9 + k] : (k == 9 ? p.sc1[ch] : (k == 10 ? p.sh1[ch] : 0.f));
       }
     }
+    if (MFC && tid < 128) {
+      // A operand of conv1 for channel tile ct = tid >> 6, lane (i, h): channel 32 ct + i, slots 8 h .. 8 h + 7 =
+      // (ky = 2 h, kx = 0..3), (ky = 2 h + 1, kx = 0..3); kx = 3 and ky = 3 are zeros but slot 12 (ky = 3, kx = 0): the BN
+      // shift.  Taps times the BN scale, split into bf16 hi + lo: [ct][hi, lo][lane] 16 bytes
+      const int ct = tid >> 6, l = tid & 63, ch = 32 * ct + (l & 31), h = l >> 5;
+      const float sc = p.sc1[ch];
+      f32x4 v[2];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int ky = 2 * h + q / 4, kx = q % 4;
+        float w = 0.f;
+        if (ky < 3 && kx < 3) w = p.w1[ch * 9 + ky * 3 + kx] * sc;
+        if (ky == 3 && kx == 0) w = p.sh1[ch];
+        v[q / 4][q % 4] = w;
+      }
+      u32x2 hi0, lo0, hi1, lo1;
+      split_bf16x4(v[0], hi0, lo0);
+      split_bf16x4(v[1], hi1, lo1);
+      unsigned* dst = (unsigned*)(dsm_raw + B1_WT) + (ct * 2 * 64 + l) * 4;
+      dst[0] = hi0.x; dst[1] = hi0.y; dst[2] = hi1.x; dst[3] = hi1.y;
+      dst[256] = lo0.x; dst[257] = lo0.y; dst[258] = lo1.x; dst[259] = lo1.y;
+    }
   }
 
   // A fragment of MFMA tile m (columns 32 m ..), tap kx, plane (pos, hl): lane (i, half) reads item (column 32 m + i + kx,
@@ -131,7 +178,7 @@ __global__ __launch_bounds__(256, 1) void block1_w4_kernel(B1Params p) {
   };
 
   // input descriptor: FUSED [rows][64] floats (16.8 MB at 64 ten-second clips), else [rows][64][64] rebased per tile
-  const size_t in_elems = (size_t)p.rows_total * 64 * (FUSED ? 1 : 64);
+  const size_t in_elems = (size_t)p.rows_total * 64 * (FORM ? 1 : 64);
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
       (void*)p.in, 0, (int)(in_elems * 4 < 0x7fffffffull ? in_elems * 4 : 0x7fffffffull), 0x00020000);
 
@@ -171,7 +218,8 @@ __global__ __launch_bounds__(256, 1) void block1_w4_kernel(B1Params p) {
   };
 
   f32x16 acc[6][2];
-  bf16x8 wr[B1_RING][2];
+  constexpr int RING = MFC && !DROP ? B1_RING_MFC : B1_RING, AH = RING - 1;   // weight pairs are requested AH groups ahead
+  bf16x8 wr[RING][2];
   bf16x8 af[2][2][2];
   float xc[12][3];                // FUSED: log-mel values around the thread's column (the tile being STAGED)
   unsigned mask_c = 0;
@@ -238,30 +286,153 @@ __global__ __launch_bounds__(256, 1) void block1_w4_kernel(B1Params p) {
     }
   };
 
+  // ---- FORM 2: conv1 on the matrix cores.  This wave's conv1 rows: quad j1, columns 32 m1 .. + 31; lane (i, half) ----
+  const int m1 = wave & 1, j1 = wave >> 1;
+  const int c1col = 32 * m1 + (lane & 31);
+  unsigned lofs1[2];
+#pragma unroll
+  for (int gh = 0; gh < 2; ++gh) lofs1[gh] = (unsigned)(gh * HALF + ((c1col + 1) * COLP + j1) * 16 + half * 8);
+  f32x4 xr[7];                    // log-mel rows 8 t - 2 + 4 j1 + 2 half + k, columns c1col - 1 .. + 2, as loaded
+  u32x2 rph[7], rpl[7];           // the same rows as bf16 (columns c - 1, c | c + 1, zero), hi and lo
+  f32x4 d1[4][6];                 // conv1 + BN + ReLU: channels 32 ct + 8 g + 4 half .. + 3 of rows 4 j1 - 1 + r of the tile
+  f32x16 c1a[2];                  // the rows in flight (row r in c1a[r & 1]: read a whole MFMA group after its last product)
+  bf16x8 a1h, a1l;
+  auto x_request = [&](int t) {
+    const int row0 = 8 * t - 2 + 4 * j1 + 2 * half;
+    const int cadj = c1col == 0 ? 0 : c1col - 1;   // column 0: no load from in front of the buffer; shifted below
+#pragma unroll
+    for (int k = 0; k < 7; ++k)   // rows above / below the batch: out of range -> zeros
+      xr[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (unsigned)(((row0 + k) * 64 + cadj) * 4), 0, 0));
+  };
+  auto x_convert = [&](int k) {   // row k of the seven
+    const bool first = c1col == 0, last = c1col == 63;
+    if (B1_KO & 64) {   // development: no split of the log-mel rows
+      rph[k].x = __builtin_bit_cast(unsigned, xr[k][0]); rph[k].y = __builtin_bit_cast(unsigned, xr[k][1]);
+      rpl[k].x = __builtin_bit_cast(unsigned, xr[k][2]); rpl[k].y = __builtin_bit_cast(unsigned, xr[k][3]);
+      return;
+    }
+    const float e0 = first ? 0.f : xr[k][0], e1 = first ? xr[k][0] : xr[k][1];
+    const float e2 = last ? 0.f : (first ? xr[k][1] : xr[k][2]);
+    const unsigned h0 = cvt_pk_bf16(e0, e1), h1 = cvt_pk_bf16(e2, 0.f);
+    const float f0 = __builtin_bit_cast(float, h0 << 16), f1 = __builtin_bit_cast(float, h0 & 0xffff0000u);
+    const float f2 = __builtin_bit_cast(float, h1 << 16);
+    rph[k].x = h0; rph[k].y = h1;
+    rpl[k].x = cvt_pk_bf16(e0 - f0, e1 - f1);
+    rpl[k].y = cvt_pk_bf16(e2 - f2, 0.f);
+  };
+  auto a1_load = [&](int ct) {
+    const unsigned char* t = dsm_raw + B1_WT + (ct * 2 * 64 + lane) * 16;
+    a1h = *(const bf16x8*)t;
+    a1l = *(const bf16x8*)(t + 1024);
+  };
+  // product `which` (hi x lo, lo x hi, hi x hi) of conv1 row r: lanes 0-31 supply taps ky = 0, 1 (rows r, r + 1 of the
+  // lane's seven), lanes 32-63 ky = 2 (row r of THEIR seven, two rows further down) and the constant 1 of the BN shift
+  auto c1_mfma = [&](int which, int r) {
+    f32x16& a = c1a[r & 1];
+    if (B1_KO & 32) {   // development: no conv1 products (one cheap dependent instruction per call instead)
+      if (which == 0) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a[k] = __builtin_bit_cast(float, rph[r].x);
+      } else {
+        a[which] += __builtin_bit_cast(float, rpl[r + 1].y);
+      }
+      return;
+    }
+    if (which == 0) {
+      const u32x4 bl = {rpl[r].x, rpl[r].y, half ? 0u : rpl[r + 1].x, half ? 0u : rpl[r + 1].y};
+      f32x16 z;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) z[k] = 0.f;
+      a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, __builtin_bit_cast(bf16x8, bl), z, 0, 0, 0);
+    } else {
+      const u32x4 bh = {rph[r].x, rph[r].y, half ? 0x3f80u : rph[r + 1].x, half ? 0u : rph[r + 1].y};
+      a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(which == 1 ? a1l : a1h, __builtin_bit_cast(bf16x8, bh), a, 0, 0, 0);
+    }
+  };
+  auto c1_post = [&](int r, unsigned mask) {   // ReLU; rows outside the clip are the zero rows of conv1's output
+    const float cap = (mask >> (4 * j1 + r)) & 1u ? __builtin_inff() : 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d1[g][r][e] = __builtin_amdgcn_fmed3f(c1a[r & 1][4 * g + e], 0.f, cap);
+  };
+  auto piece1 = [&](unsigned char* buf, int g, int pos) {
+    const f32x4 v = w4_transform(pos, d1[g][0], d1[g][1], d1[g][2], d1[g][3], d1[g][4], d1[g][5]);
+    u32x2 hi, lo;
+    split_bf16x4(v, hi, lo);
+    unsigned char* dst = buf + lofs1[g & 1] + (2 * pos) * PLANE;
+    if (B1_KO & 8) {
+      asm volatile("" :: "v"(hi), "v"(lo), "v"(dst));
+      return;
+    }
+    *(u32x2*)dst = hi;
+    *(u32x2*)(dst + PLANE) = lo;
+  };
+  // vector work of MFMA group gi in a step that runs conv1 (channel tile ct; groups 0-1 = the next K step into `buf`) ...
+  auto stage_a = [&](unsigned char* buf, int gi, int ct, unsigned mask) {
+    if (B1_KO & 1) return;
+    if (gi == 0) {
+      a1_load(ct);
+#pragma unroll
+      for (int k = 0; k < 7; ++k) x_convert(k);   // (a row per group instead: 16 registers spilled, slower)
+    }
+    if (gi >= 2 && gi <= 7) c1_post(gi - 2, mask);       // its products were issued in group gi - 1
+    if (gi >= 8 && gi <= 13 && !(B1_KO & 16)) {
+      piece1(buf, 0, gi - 8);
+      piece1(buf, 1, gi - 8);
+    }
+  };
+  // ... and in the step after it (groups 2-3 = the K step after the next)
+  auto stage_b = [&](unsigned char* buf, int gi) {
+    if (B1_KO & 1) return;
+    if (gi >= 1 && gi <= 11 && (gi & 1) && !(B1_KO & 16)) {
+      piece1(buf, 2, gi >> 1);
+      piece1(buf, 3, gi >> 1);
+    }
+  };
+
   // ---- prologue of the first tile: its inputs, step 0 staged into buffer 0 ----
   lds_barrier();   // conv1 table, zero columns
-  constexpr int RING = B1_RING, AH = RING - 1;
   static_assert(18 % RING == 0, "ring positions are static");
 #pragma unroll
   for (int g0 = 0; g0 < AH; ++g0) w_load(0, g0, wr[g0]);
   if (FUSED) {
     load_x(tile, xc);
     mask_c = row_mask(tile);
+  } else if (MFC) {
+    x_request(tile);
+    mask_c = row_mask(tile);
   } else {
     rows_request(tile, 0, c1);
     rows_request(tile, 1, c1b);
   }
+  if (MFC) {
+    a1_load(0);
 #pragma unroll
-  for (int gi = 0; gi < 16; ++gi) stage_unit(sV, gi, 0, xc, mask_c, c1);
+    for (int k = 0; k < 7; ++k) x_convert(k);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) c1_mfma(k, r);
+      c1_post(r, mask_c);
+    }
+#pragma unroll
+    for (int gi = 8; gi < 14; ++gi) stage_a(sV, gi, 0, mask_c);
+  } else {
+#pragma unroll
+    for (int gi = 0; gi < 16; ++gi) stage_unit(sV, gi, 0, xc, mask_c, c1);
+  }
   lds_barrier();
   a_load(sV, 0, af[0]);
 
+  const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc((void*)p.scale, 0, 256, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsh = __builtin_amdgcn_make_buffer_rsrc((void*)p.shift, 0, 256, 0x00020000);
   const FastDiv4 by_hp_out(p.Hp / 2);
   const int chw = cg * 32 + 4 * half;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
 #ifdef B1_CLK
-  unsigned long long clk_loop = 0, clk_epi = 0, clk_n = 0;
+  unsigned long long clk_loop = 0, clk_epi = 0, clk_n = 0, clk_even = 0, clk_s1 = 0;
   const unsigned long long clk_t0 = __builtin_readcyclecounter(), clk_rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
 #pragma unroll 1
@@ -296,12 +467,17 @@ __global__ __launch_bounds__(256, 1) void block1_w4_kernel(B1Params p) {
             acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[gi % RING][0], af[gi & 1][m][1], acc[q][m], 0, 0, 0);
           }
         }
+        // conv1 row gi - 1 rides along, one product behind each pair
+        const bool C1ROW = MFC && (s & 1) && gi >= 1 && gi <= 6 && !(B1_KO & 1);
+        if (C1ROW) c1_mfma(0, gi - 1);
 #pragma unroll
         for (int m = 0; m < 2; ++m)
           acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[gi % RING][1], af[gi & 1][m][0], acc[q][m], 0, 0, 0);
+        if (C1ROW) c1_mfma(1, gi - 1);
 #pragma unroll
         for (int m = 0; m < 2; ++m)
           acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[gi % RING][0], af[gi & 1][m][0], acc[q][m], 0, 0, 0);
+        if (C1ROW) c1_mfma(2, gi - 1);
         } else {
 #pragma unroll
           for (int m = 0; m < 2; ++m)
@@ -314,7 +490,15 @@ __global__ __launch_bounds__(256, 1) void block1_w4_kernel(B1Params p) {
           }
         }
         // staging of the next step: steps 0-2 from this tile's inputs, step 3 from the next tile's
-        if (FUSED) {
+        if (MFC) {
+          // steps 1 / 3 run conv1 for channel tile 1 of this tile / 0 of the next one and stage its first K step; steps
+          // 2 / 0 stage the second; the log-mel rows are requested three groups before the end of the step in front
+          if (s & 1) stage_a(nxt, gi, s == 1 ? 1 : 0, mask_c);
+          else stage_b(nxt, gi);
+          if (!(s & 1) && gi == 13) x_request(s == 0 ? tile : next);
+          if (s == 0 && gi == 16) touch_x(next);
+          if (s == 2 && gi == 16) mask_c = row_mask(next);
+        } else if (FUSED) {
           // steps 0-2 stage this tile's next step, step 3 the first step of the next tile: its log-mel values replace this
           // tile's once step 2 has staged the last of them (the lines were touched two steps earlier: L2 hits)
           stage_unit(nxt, gi, s + 1, xc, mask_c, c1);
@@ -335,11 +519,26 @@ __global__ __launch_bounds__(256, 1) void block1_w4_kernel(B1Params p) {
           }
         }
         if (gi == 16) lds_barrier();
+        if (B1_SGB > 0 && MFC) {
+#pragma unroll
+          for (int i = 0; i < 9; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, B1_SGB, 0);
+            __builtin_amdgcn_sched_group_barrier(B1_SGB_MEM, 1, 0);
+          }
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     };
     step(std::integral_constant<int, 0>{});
+#ifdef B1_CLK
+    const unsigned long long clk_s0 = __builtin_readcyclecounter();
+    clk_even += clk_s0 - clk_a;
+#endif
     step(std::integral_constant<int, 1>{});
+#ifdef B1_CLK
+    clk_s1 += __builtin_readcyclecounter() - clk_s0;
+#endif
     step(std::integral_constant<int, 2>{});
     step(std::integral_constant<int, 3>{});
 
@@ -347,22 +546,26 @@ __global__ __launch_bounds__(256, 1) void block1_w4_kernel(B1Params p) {
     const unsigned long long clk_b = __builtin_readcyclecounter();
 #endif
     // ---- epilogue: output transform, BN, ReLU, 2x2 pool.  Lane l owns PIXEL column 32 m + l % 32 of quad wq and, in
-    // register quad g, channels chw + 8 g .. + 3; the two columns of a pooling window sit in lanes l, l ^ 1 ----
+    // register quad g, channels chw + 8 g .. + 3; the two columns of a pooling window sit in lanes l, l ^ 1.  Stores go
+    // through a descriptor rebased to the tile's 32 KB of output and cut at the end of the tensor (no 64-bit addresses,
+    // no bounds test per store) ----
     {
       f32x4 sc4[4], sh4[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        sc4[g] = *(const f32x4*)(p.scale + chw + 8 * g);
-        sh4[g] = *(const f32x4*)(p.shift + chw + 8 * g);
+        sc4[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsc, (unsigned)(chw * 4 + 32 * g), 0, 0));
+        sh4[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsh, (unsigned)(chw * 4 + 32 * g), 0, 0));
       }
       const int qg = 2 * tile + wq;
-      const bool inside = 4 * qg < p.rows_total;
       const int hp0 = by_hp_out.mod(2 * qg);
+      const long left = ((long)(p.rows_total / 2) - 4L * tile) * (32 * 64 * 4);
+      const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(p.out + (size_t)tile * (4 * 32 * 64)), 0, (int)(left < 32768 ? (left < 0 ? 0 : left) : 32768), 0x00020000);
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         const int col = 32 * m + (lane & 31);
-        const int pr = 2 * qg + (col & 1);
         const bool valid = hp0 + (col & 1) < p.H / 2;
+        const unsigned ob = (unsigned)((((2 * wq + (col & 1)) * 32 + (col >> 1)) * 64 + chw) * 4);   // byte offset in the tile
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           f32x4 t0, t1, o;
@@ -380,13 +583,14 @@ __global__ __launch_bounds__(256, 1) void block1_w4_kernel(B1Params p) {
             const float a = t0[e] + dpp_mov<DPP_QUAD_XOR1>(t0[e]), b = t1[e] + dpp_mov<DPP_QUAD_XOR1>(t1[e]);
             o[e] = 0.25f * ((col & 1) ? b : a);
           }
-          const size_t oi = ((size_t)pr * 32 + (col >> 1)) * 64 + chw + 8 * g;
           if (!valid) o = zero4;
-          if (p.drop.thresh != 0) {
+          if (DROP) {
+            const size_t oi = (size_t)tile * (4 * 32 * 64) + ob / 4 + 8 * g;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] *= p.drop.mask(oi + e);
           }
-          if (inside && !(B1_KO & 4)) *(f32x4*)(p.out + oi) = o;
+          if (!(B1_KO & 4))
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ro, ob + 32u * g, 0, 0);
         }
       }
     }
@@ -405,14 +609,16 @@ __global__ __launch_bounds__(256, 1) void block1_w4_kernel(B1Params p) {
     atomicAdd(&b1_clk[2], __builtin_readcyclecounter() - clk_t0);
     atomicAdd(&b1_clk[3], __builtin_amdgcn_s_memrealtime() - clk_rt0);
     atomicAdd(&b1_clk[4], clk_n);
+    atomicAdd(&b1_clk[5], clk_even);
+    atomicAdd(&b1_clk[6], clk_s1);
   }
 #endif
 }
 
-template <bool FUSED>
+template <int FORM, bool DROP>
 int launch_b1(const B1Params& p, hipStream_t s) {
   static AcLdsAttr lds_attr;   // per device
-  if (ac_allow_lds((const void*)block1_w4_kernel<FUSED>, 160 * 1024, &lds_attr) != AC_OK) return AC_ERR_LAUNCH;
+  if (ac_allow_lds((const void*)block1_w4_kernel<FORM, DROP>, 160 * 1024, &lds_attr) != AC_OK) return AC_ERR_LAUNCH;
   static int cus_of[64];   // compute units per device (one persistent workgroup each), 0 = not asked yet
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess) return AC_ERR_LAUNCH;
@@ -423,31 +629,33 @@ int launch_b1(const B1Params& p, hipStream_t s) {
     if (dev >= 0 && dev < 64) __atomic_store_n(&cus_of[dev], cus, __ATOMIC_RELAXED);
   }
   const unsigned grid = (unsigned)(p.tiles < cus ? p.tiles : cus);
-  hipLaunchKernelGGL(block1_w4_kernel<FUSED>, dim3(grid), dim3(256), (size_t)B1_LDS, s, p);
+  hipLaunchKernelGGL((block1_w4_kernel<FORM, DROP>), dim3(grid), dim3(256), (size_t)B1_LDS, s, p);
   return ac_check_launch();
 }
 
 }  // namespace
 
-static int b1_dispatch(bool fused, const float* in, const float* w1, const float* sc1, const float* sh1, const void* wfrag2,
+static int b1_dispatch(int form, const float* in, const float* w1, const float* sc1, const float* sh1, const void* wfrag2,
                        const float* scale2, const float* shift2, float* out, int B, int Hp, int H, const int* clip_frames,
                        int need_mul, int need_add, void* stream, Drop drop) {
-  if (!in || !wfrag2 || !scale2 || !shift2 || !out || (fused && (!w1 || !sc1 || !sh1))) return AC_ERR_ARG;
+  if (!in || !wfrag2 || !scale2 || !shift2 || !out || (form && (!w1 || !sc1 || !sh1))) return AC_ERR_ARG;
   if (B <= 0 || Hp <= H || (Hp & 7) || H < 2) return AC_ERR_ARG;   // 8-row tiles inside a clip
   if (((unsigned long long)B * Hp + 4096) * 256 >= (1ull << 31)) return AC_ERR_ARG;   // 32-bit byte offsets into [rows][64] floats
-  if (!fused && (unsigned long long)B * Hp * 64 * 64 * 4 >= (1ull << 31)) return AC_ERR_ARG;   // unfused form: one descriptor
+  if (!form && (unsigned long long)B * Hp * 64 * 64 * 4 >= (1ull << 31)) return AC_ERR_ARG;   // unfused form: one descriptor
   B1Params p;
   p.in = in; p.w1 = w1; p.sc1 = sc1; p.sh1 = sh1; p.wpk = wfrag2; p.scale = scale2; p.shift = shift2; p.out = out;
   p.rows_total = B * Hp; p.Hp = Hp; p.H = H;
   p.tiles = p.rows_total / 8;
   p.clip_frames = clip_frames; p.need_mul = need_mul; p.need_add = need_add;
   p.drop = drop;
-  return fused ? launch_b1<true>(p, (hipStream_t)stream) : launch_b1<false>(p, (hipStream_t)stream);
+  const hipStream_t st = (hipStream_t)stream;
+  if (drop.thresh != 0) return form == 2 ? launch_b1<2, true>(p, st) : form == 1 ? launch_b1<1, true>(p, st) : AC_ERR_ARG;
+  return form == 2 ? launch_b1<2, false>(p, st) : form == 1 ? launch_b1<1, false>(p, st) : launch_b1<0, false>(p, st);
 }
 
 #ifdef B1_CLK
 extern "C" int ac_b1_clk_read(unsigned long long* out5, int reset) {
-  if (hipMemcpyFromSymbol(out5, HIP_SYMBOL(b1_clk), 40) != hipSuccess) return -2;
+  if (hipMemcpyFromSymbol(out5, HIP_SYMBOL(b1_clk), 56) != hipSuccess) return -2;   // out5: seven words
   if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(b1_clk), z, 64) != hipSuccess) return -2; }
   return 0;
 }
@@ -459,12 +667,21 @@ extern "C" int ac_conv3x3_block1_wino43(const float* in1, const float* w1, const
                                         int Hp, int H, const int* clip_frames, int need_mul, int need_add, float drop_p,
                                         unsigned long long drop_seed, const unsigned long long* seed_dev, void* stream) {
   if (!(drop_p >= 0.f) || drop_p >= 1.f) return AC_ERR_ARG;
-  return b1_dispatch(true, in1, w1, scale1, shift1, wfrag2, scale2, shift2, out, B, Hp, H, clip_frames, need_mul, need_add,
+  return b1_dispatch(1, in1, w1, scale1, shift1, wfrag2, scale2, shift2, out, B, Hp, H, clip_frames, need_mul, need_add,
+                     stream, make_drop(drop_p, drop_seed, seed_dev));
+}
+
+extern "C" int ac_conv3x3_block1_wino43_mfma(const float* in1, const float* w1, const float* scale1, const float* shift1,
+                                             const void* wfrag2, const float* scale2, const float* shift2, float* out, int B,
+                                             int Hp, int H, const int* clip_frames, int need_mul, int need_add, float drop_p,
+                                             unsigned long long drop_seed, const unsigned long long* seed_dev, void* stream) {
+  if (!(drop_p >= 0.f) || drop_p >= 1.f) return AC_ERR_ARG;
+  return b1_dispatch(2, in1, w1, scale1, shift1, wfrag2, scale2, shift2, out, B, Hp, H, clip_frames, need_mul, need_add,
                      stream, make_drop(drop_p, drop_seed, seed_dev));
 }
 
 extern "C" int ac_conv3x3_block1_conv2_wino43(const float* in64, const void* wfrag2, const float* scale2, const float* shift2,
                                               float* out, int B, int Hp, int H, void* stream) {
-  return b1_dispatch(false, in64, nullptr, nullptr, nullptr, wfrag2, scale2, shift2, out, B, Hp, H, nullptr, 0, 0, stream,
+  return b1_dispatch(0, in64, nullptr, nullptr, nullptr, wfrag2, scale2, shift2, out, B, Hp, H, nullptr, 0, 0, stream,
                      make_drop(0.f, 0, nullptr));
 }

@@ -189,27 +189,33 @@ def conv3x3_bn_relu_wino1d(x, wfrag, scale, shift, out, B, Hp, H, W, Cin, Cout, 
     return out
 
 
-def conv3x3_block1_wino43(x0, w1, scale1, shift1, wfrag2, scale2, shift2, out, B, Hp, H, need=None, dropout=None):
+def conv3x3_block1_wino43(x0, w1, scale1, shift1, wfrag2, scale2, shift2, out, B, Hp, H, need=None, dropout=None,
+                          conv1="mfma"):
     """Conv block 1 in one kernel at f32 grade: conv1 computed into conv2's staging, conv2 + pool as F(4,3) on split-bf16
     operands (csrc/conv3x3_block1_w4.hip).  x0 [B*Hp][64] f32, out [B*Hp/2][32][64] f32; ``wfrag2`` from
-    ``pack_conv_weight_wino43_frag``; ``need`` / ``dropout`` as for ``conv3x3_bn_relu_wino1d``."""
+    ``pack_conv_weight_wino43_frag``; ``need`` / ``dropout`` as for ``conv3x3_bn_relu_wino1d``.  ``conv1``: "mfma" (a
+    split-bf16 product on the matrix cores) or "valu" (the f32 chain of ``conv3x3_first``, bit-identical to it)."""
+    if conv1 not in ("mfma", "valu"):
+        raise ValueError(f"conv1 = {conv1!r}")
     cf, mul, add = need if need is not None else (None, 0, 0)
     dp, dseed, ddev = dropout if dropout is not None else (0.0, 0, None)
     hook = CONV_LAUNCH_HOOK
     if hook is not None:
-        info = {"B": B, "H": H, "Hp": Hp, "W": 64, "Cin": 1, "Cout": 64, "mode": 1, "algo": "block1_w4"}
+        info = {"B": B, "H": H, "Hp": Hp, "W": 64, "Cin": 1, "Cout": 64, "mode": 1, "algo": "block1_w4", "conv1": conv1}
         hook("pre", info)
         try:
-            return _block1_wino43(x0, w1, scale1, shift1, wfrag2, scale2, shift2, out, B, Hp, H, cf, mul, add, dp, dseed, ddev)
+            return _block1_wino43(x0, w1, scale1, shift1, wfrag2, scale2, shift2, out, B, Hp, H, cf, mul, add, dp, dseed, ddev,
+                                  conv1)
         finally:
             hook("post", info)
-    return _block1_wino43(x0, w1, scale1, shift1, wfrag2, scale2, shift2, out, B, Hp, H, cf, mul, add, dp, dseed, ddev)
+    return _block1_wino43(x0, w1, scale1, shift1, wfrag2, scale2, shift2, out, B, Hp, H, cf, mul, add, dp, dseed, ddev, conv1)
 
 
-def _block1_wino43(x0, w1, scale1, shift1, wfrag2, scale2, shift2, out, B, Hp, H, cf, mul, add, dp, dseed, ddev):
-    check(_lib.load().ac_conv3x3_block1_wino43(ptr(x0), ptr(w1), ptr(scale1), ptr(shift1), ptr(wfrag2), ptr(scale2),
-                                               ptr(shift2), ptr(out), B, Hp, H, ptr(cf), int(mul), int(add), float(dp),
-                                               int(dseed), ddev, stream()), "ac_conv3x3_block1_wino43")
+def _block1_wino43(x0, w1, scale1, shift1, wfrag2, scale2, shift2, out, B, Hp, H, cf, mul, add, dp, dseed, ddev, conv1):
+    name = "ac_conv3x3_block1_wino43_mfma" if conv1 == "mfma" else "ac_conv3x3_block1_wino43"
+    check(getattr(_lib.load(), name)(ptr(x0), ptr(w1), ptr(scale1), ptr(shift1), ptr(wfrag2), ptr(scale2), ptr(shift2),
+                                     ptr(out), B, Hp, H, ptr(cf), int(mul), int(add), float(dp), int(dseed), ddev,
+                                     stream()), name)
     return out
 
 

@@ -167,6 +167,15 @@ int ac_conv3x3_block1_wino43(const float* in1, const float* w1, const float* sca
                              const void* wfrag2, const float* scale2, const float* shift2, float* out, int B, int Hp,
                              int H, const int* clip_frames, int need_mul, int need_add, float drop_p,
                              unsigned long long drop_seed, const unsigned long long* seed_dev, void* stream);
+/* The same kernel with conv1 on the matrix cores as well (the default of the host class): a [32 channels] x [K = 16: nine
+ * taps times the BN scale + the BN shift against a constant 1] x [32 columns] split-bf16 product per row, whose result a lane
+ * holds in the layout conv2's staging stores - 1760 of the 4700 vector instructions per tile gone for 8 % more MFMAs.  Same
+ * arguments; conv1 has the split-bf16 grade of the tier's other layers (not bit-identical to ac_conv3x3_first).
+ * cnn_encoder.py:59-75 / :431-432. */
+int ac_conv3x3_block1_wino43_mfma(const float* in1, const float* w1, const float* scale1, const float* shift1,
+                                  const void* wfrag2, const float* scale2, const float* shift2, float* out, int B, int Hp,
+                                  int H, const int* clip_frames, int need_mul, int need_add, float drop_p,
+                                  unsigned long long drop_seed, const unsigned long long* seed_dev, void* stream);
 /* The conv2 half of the same kernel on a 64-channel input in HBM ([B*Hp][64][64] f32, B*Hp*64*64*4 < 2^31): the unfused
  * form the fused kernel is tested against. */
 int ac_conv3x3_block1_conv2_wino43(const float* in64, const void* wfrag2, const float* scale2, const float* shift2,

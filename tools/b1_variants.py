@@ -3,7 +3,8 @@
     python tools/b1_variants.py --build [name=flags ...]   # here (no GPU): tools/bin/libb1_<name>.so
     python tools/b1_variants.py [--batch 64]                # on the GPU box: microseconds per launch, variants interleaved
 
-B1_KO bits: 1 no staging, 2 no MFMAs, 4 no epilogue stores (results are then wrong).  B1_CLK: per-tile cycle counters."""
+B1_KO bits: 1 no staging, 2 no MFMAs, 4 no epilogue stores (results are then wrong).  B1_CLK: per-tile cycle counters.
+A variant whose name starts with "valu" runs conv1 as the f32 chain on the vector ALUs, every other one on the matrix cores."""
 import argparse
 import ctypes
 import glob
@@ -58,8 +59,9 @@ def main():
     libs = {}
     for v in names:
         lib = ctypes.CDLL(os.path.join(BIN, f"libb1_{v}.so"))
-        lib.ac_conv3x3_block1_wino43.restype = I
-        lib.ac_conv3x3_block1_wino43.argtypes = [P] * 8 + [I, I, I, P, I, I, F, U, P, P]
+        for sym in ("ac_conv3x3_block1_wino43", "ac_conv3x3_block1_wino43_mfma"):
+            getattr(lib, sym).restype = I
+            getattr(lib, sym).argtypes = [P] * 8 + [I, I, I, P, I, I, F, U, P, P]
         if v.startswith("clk"):
             lib.ac_b1_clk_read.restype = I
             lib.ac_b1_clk_read.argtypes = [P, I]
@@ -76,7 +78,8 @@ def main():
     for _ in range(args.rounds):
         for v in names:
             def fn():
-                rc = libs[v].ac_conv3x3_block1_wino43(x0.data_ptr(), w1.data_ptr(), s1.data_ptr(), t1.data_ptr(), wp.data_ptr(),
+                sym = "ac_conv3x3_block1_wino43" if v.startswith("valu") else "ac_conv3x3_block1_wino43_mfma"
+                rc = getattr(libs[v], sym)(x0.data_ptr(), w1.data_ptr(), s1.data_ptr(), t1.data_ptr(), wp.data_ptr(),
                                                       s2.data_ptr(), t2.data_ptr(), out.data_ptr(), B, Hp, H, None, 0, 0, 0.0, 0,
                                                       None, torch.cuda.current_stream().cuda_stream)
                 assert rc == 0, rc
@@ -91,11 +94,11 @@ def main():
     for v in names:
         line = f"{v:8s} {best[v]:9.1f} us"
         if v.startswith("clk"):
-            buf = (ctypes.c_ulonglong * 5)()
+            buf = (ctypes.c_ulonglong * 7)()
             libs[v].ac_b1_clk_read(ctypes.cast(buf, P), 1)
             n = max(buf[4], 1)
             line += (f"   per tile: K loop {buf[0] / n:.0f} cycles, epilogue {buf[1] / n:.0f}; {n} tiles, "
-                     f"{buf[2] / max(buf[3], 1) / 10.0:.2f} GHz")
+                     f"{buf[2] / max(buf[3], 1) / 10.0:.2f} GHz; step 0 {buf[5] / n:.0f}, step 1 {buf[6] / n:.0f}")
         print(line, flush=True)
 
 
