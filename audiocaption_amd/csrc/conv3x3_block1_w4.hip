@@ -371,24 +371,24 @@ __global__ __launch_bounds__(256, 1) void block1_w4_kernel(B1Params p) {
   // vector work of MFMA group gi in a step that runs conv1 (channel tile ct; groups 0-1 = the next K step into `buf`) ...
   auto stage_a = [&](unsigned char* buf, int gi, int ct, unsigned mask) {
     if (B1_KO & 1) return;
-    if (gi == 0) {
-      a1_load(ct);
+    if (gi == 0) a1_load(ct);
+    if (gi == 0) {   // (spread over groups 0-2, or moved to the end of the step in front: spills / no faster)
 #pragma unroll
-      for (int k = 0; k < 7; ++k) x_convert(k);   // (a row per group instead: 16 registers spilled, slower)
+      for (int k = 0; k < 7; ++k) x_convert(k);
     }
     if (gi >= 2 && gi <= 7) c1_post(gi - 2, mask);       // its products were issued in group gi - 1
-    if (gi >= 8 && gi <= 13 && !(B1_KO & 16)) {
-      piece1(buf, 0, gi - 8);
-      piece1(buf, 1, gi - 8);
+    if (gi >= 8 && gi <= 15 && !(B1_KO & 16)) {   // twelve pieces over eight groups: 2, 1, 2, 1, ...
+      const int p0 = 3 * ((gi - 8) >> 1) + 2 * (gi & 1), np = gi & 1 ? 1 : 2;
+#pragma unroll
+      for (int q = p0; q < p0 + np; ++q) piece1(buf, q & 1, q >> 1);
     }
   };
   // ... and in the step after it (groups 2-3 = the K step after the next)
   auto stage_b = [&](unsigned char* buf, int gi) {
     if (B1_KO & 1) return;
-    if (gi >= 1 && gi <= 11 && (gi & 1) && !(B1_KO & 16)) {
-      piece1(buf, 2, gi >> 1);
-      piece1(buf, 3, gi >> 1);
-    }
+    // one piece per group: a group's five or six vector instructions per MFMA are what one wave per SIMD hides (two pieces
+    // in every other group: +390 cycles per step)
+    if (gi < 12 && !(B1_KO & 16)) piece1(buf, 2 + (gi & 1), gi >> 1);
   };
 
   // ---- prologue of the first tile: its inputs, step 0 staged into buffer 0 ----
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256, 1) void block1_w4_kernel(B1Params p) {
       c1_post(r, mask_c);
     }
 #pragma unroll
-    for (int gi = 8; gi < 14; ++gi) stage_a(sV, gi, 0, mask_c);
+    for (int gi = 8; gi < 16; ++gi) stage_a(sV, gi, 0, mask_c);
   } else {
 #pragma unroll
     for (int gi = 0; gi < 16; ++gi) stage_unit(sV, gi, 0, xc, mask_c, c1);
