@@ -75,6 +75,10 @@ def main():
     out = torch.empty(B * Hp // 2, 32, 64, device=dev)
     wp = K.pack_conv_weight_wino43_frag(w2)
     best = {v: 1e9 for v in names}
+    # every variant's RESULT against the library's f32-chain form before anything is timed (knock-outs are wrong by design)
+    ref = torch.empty_like(out)
+    K.conv3x3_block1_wino43(x0, w1, s1, t1, wp, s2, t2, ref, B, Hp, H, conv1="valu")
+    verdict = {}
     for _ in range(args.rounds):
         for v in names:
             def fn():
@@ -84,6 +88,9 @@ def main():
                                                       None, torch.cuda.current_stream().cuda_stream)
                 assert rc == 0, rc
             fn()
+            if v not in verdict:
+                d = float((out - ref).abs().max()) / float(ref.abs().max())
+                verdict[v] = f"result {'ok' if d < 2e-5 else 'WRONG'} ({d:.1e} of the largest output)"
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             for _ in range(args.iters):
@@ -92,7 +99,7 @@ def main():
             torch.cuda.synchronize()
             best[v] = min(best[v], s.elapsed_time(e) / args.iters * 1000)
     for v in names:
-        line = f"{v:8s} {best[v]:9.1f} us"
+        line = f"{v:8s} {best[v]:9.1f} us   {verdict[v]}"
         if v.startswith("clk"):
             buf = (ctypes.c_ulonglong * 7)()
             libs[v].ac_b1_clk_read(ctypes.cast(buf, P), 1)
