@@ -9,11 +9,11 @@
 // x 64 columns (full width: the halo columns are LDS columns that stay zero) x 64 channels; wave w owns channel tile
 // w & 1 and quad w >> 1 as two MFMA tiles of 32 columns x 6 positions = 192 accumulators.
 //
-// Staging (FUSED).  Thread t = (channel quad t & 3, column t >> 2) holds the 12 x 3 log-mel values around its column for
+// Staging (FORM 1: conv1 on the vector ALUs).  Thread t = (channel quad t & 3, column t >> 2) holds the 12 x 3 log-mel values around its column for
 // both quads of the tile in registers (loaded a tile ahead).  Per K step it evaluates conv1 + BN + ReLU for its 4
 // channels on the 10 rows 4 q0 - 1 .. 4 q0 + 8 (the same 9-term fmaf chain, BN and zero rows as conv_first_kernel,
 // csrc/conv3x3.hip: bit-identical to the two-kernel form), transforms the two quads (F(4,3): 6 positions each), splits
-// into bf16 hi + lo and stores the planes - one row or two pieces per MFMA group.  !FUSED: the rows come from a
+// into bf16 hi + lo and stores the planes - one row or two pieces per MFMA group.  FORM 0: the rows come from a
 // 64-channel activation tensor in HBM instead (the unfused reference form of the same kernel; tests).
 //
 // Staging (FORM 2: conv1 on the matrix cores, the default).  The 9-term chain above is 1760 of the 4700 vector
@@ -23,8 +23,10 @@
 // computes, once per channel tile ct (32 channels = two K steps of conv2), the six rows of quad w >> 1 for columns
 // 32 (w & 1) ..: 18 MFMAs, +8 % on the matrix pipe.  A lane then HOLDS what the staging needs - four groups of four
 // consecutive channels of one column over the six rows of its quad: ReLU, F(4,3) transform, split, plane stores as before;
-// groups 0-1 (the next K step) at once, groups 2-3 (the step after) one step later.  The B operand of row r is two packed
-// log-mel rows (columns c - 1 .. c + 1, four 16-byte loads ahead of time); lanes 32-63 supply ky = 2 and the constant.
+// groups 0-1 (the next K step) at once, groups 2-3 (the step after) one step later, ONE piece per MFMA group (a wave per
+// SIMD hides ~5 vector instructions per MFMA gap; more are paid in full).  The B operand of row r is two packed log-mel
+// rows (columns c - 1 .. c + 1; seven unaligned 16-byte loads per lane, requested three groups before the step); lanes
+// 32-63 supply ky = 2 and the constant.  A row's accumulator is read a whole MFMA group after its last product.
 // Not bit-identical to conv_first_kernel any more: conv1 now has the split-bf16 grade of every other layer of the tier.
 #include <stdlib.h>
 #include <string.h>
@@ -50,7 +52,7 @@ namespace {
 #define B1_SGB 0
 #endif
 #ifndef B1_KO    // development: 1 no staging (conv1 / transform / split / plane stores), 2 no MFMAs, 4 no epilogue stores,
-                 // FORM 2: 8 no plane stores, 16 no transform / split / plane stores
+                 // FORM 2: 8 no plane stores, 16 no transform / split / plane stores, 32 no conv1 products, 64 no row split
 #define B1_KO 0
 #endif
 #ifdef B1_CLK
@@ -60,7 +62,7 @@ __device__ unsigned long long b1_clk[8];
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct B1Params {
-  const float* in;       // FUSED: [B*Hp][64] log-mel after bn0; else [B*Hp][64][64] conv1 output
+  const float* in;       // FORM 1, 2: [B*Hp][64] log-mel after bn0; FORM 0: [B*Hp][64][64] conv1 output
   const float* w1;       // [64][9]
   const float* sc1;
   const float* sh1;
