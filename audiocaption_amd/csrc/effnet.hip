@@ -253,6 +253,78 @@ __global__ __launch_bounds__(256) void depthwise_rows_kernel(DwP p, int lc) {
   }
 }
 
+// The same sliding window for the FIRST stage's two 3 x 3 layers (F = 32 mel columns, 32 or 16 channels = 8 or 4 channel
+// groups: far fewer than a wave's lanes): a wave covers a whole row - lane = (channel group cg = lane % C4W, column segment
+// seg = lane / C4W of NO = F * C4W / 64 columns); a thread keeps its NO + 2 window columns of the 3 rows in registers and
+// slides along time.  A wave instruction reads 64 / C4W separate runs of C4W * 16 contiguous bytes (whole 128-byte lines at 8
+// channel groups).  223 -> ~110 us (32 channels) / 133 -> ~60 us (16) at 128 clips against the sliding-along-mel form.
+template <int C4W, int NO>
+__global__ __launch_bounds__(256) void depthwise_rowseg_kernel(DwP p, int lc) {
+  constexpr int K = 3, NSEG = 64 / C4W, F = NSEG * NO, NW = NO + 2;
+  __shared__ __attribute__((aligned(16))) float spart[4][64 * 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  const int cg = lane % C4W, seg = lane / C4W;
+  const int chunk = (int)blockIdx.z * 4 + wave;
+  const int o0 = seg * NO;                              // first output column of this thread; its window starts at o0 - 1
+  const int to0 = chunk * lc, to1 = min(p.To, to0 + lc);
+  const bool act = to0 < to1;
+  const int c = cg * 4;
+  const float* xb = p.x + (long)b * p.T * F * p.C + c;
+  float* yb = p.y + (long)b * p.To * F * p.C + c;
+  f32x4 psum = {0.f, 0.f, 0.f, 0.f};
+  if (act) {
+    const f32x4 sc = *(const f32x4*)(p.scale + c), sh = *(const f32x4*)(p.shift + c);
+    f32x4 w[K][K];
+#pragma unroll
+    for (int kt = 0; kt < K; ++kt)
+#pragma unroll
+      for (int kf = 0; kf < K; ++kf) w[kt][kf] = *(const f32x4*)(p.w + (long)(kt * K + kf) * p.C + c);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto load_row = [&](int t, f32x4 (&dst)[NW]) {   // input row t, columns o0 - 1 .. o0 + NO (zeros outside the image)
+      const bool ok = t >= 0 && t < p.T;
+      const float* rp = xb + ((long)(ok ? t : 0) * F + o0 - 1) * p.C;
+#pragma unroll
+      for (int j = 0; j < NW; ++j) {
+        const int col = o0 - 1 + j;
+        dst[j] = (ok && col >= 0 && col < F) ? *(const f32x4*)(rp + (long)j * p.C) : zero4;
+      }
+    };
+    f32x4 win[K][NW], nxt[NW];
+    load_row(to0 - p.pb, win[1]);
+    load_row(to0 - p.pb + 1, win[2]);
+    load_row(to0 - p.pb + 2, nxt);
+    for (int to = to0; to < to1; ++to) {
+#pragma unroll
+      for (int j = 0; j < NW; ++j) { win[0][j] = win[1][j]; win[1][j] = win[2][j]; win[2][j] = nxt[j]; }
+      if (to + 1 < to1) load_row(to + 1 - p.pb + 2, nxt);   // in flight under this row's arithmetic
+#pragma unroll
+      for (int oo = 0; oo < NO; ++oo) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < K; ++kt)
+#pragma unroll
+          for (int kf = 0; kf < K; ++kf) acc += win[kt][oo + kf] * w[kt][kf];   // the order of depthwise_rows_kernel
+        f32x4 v = acc * sc + sh;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = swishf(v[j]);
+        psum += v;
+        *(f32x4*)(yb + ((long)to * F + o0 + oo) * p.C) = v;
+      }
+    }
+  }
+  *(f32x4*)(&spart[wave][lane * 4]) = psum;
+  __syncthreads();
+  if (threadIdx.x < C4W) {   // squeeze sums: the workgroup's 4 row chunks x NSEG column segments of channel group threadIdx.x
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv)
+      for (int sg = 0; sg < NSEG; ++sg) t += *(const f32x4*)(&spart[wv][(sg * C4W + (int)threadIdx.x) * 4]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) atomicAdd(p.pool + (long)b * p.C + threadIdx.x * 4 + j, t[j] * p.pool_scale);
+  }
+}
+
 // ---- squeeze-excite gate: g[b][c] = sigmoid(W2 swish(W1 mean[b] + b1) + b2) -----------------------------------------
 // pool [B][C] sums, w1 [S][C], w2 [C][S]; one workgroup per clip.
 __global__ __launch_bounds__(256) void se_gate_kernel(const float* pool, float inv_count, const float* w1, const float* b1,
@@ -480,6 +552,14 @@ int ac_effnet_depthwise(const float* x, const float* w, const float* scale, cons
   }
   // stride 1, "same" padding, a narrow mel axis: the rows-in-registers form (AUDIOCAPTION_DW_ROWS_KERNEL=0: the form below)
   static const bool rows_kernel = !(getenv("AUDIOCAPTION_DW_ROWS_KERNEL") && !strcmp(getenv("AUDIOCAPTION_DW_ROWS_KERNEL"), "0"));
+  if (rows_kernel && stride == 1 && k == 3 && pad_before == 1 && p.Fo == F && p.To == T && F == 32 && (C == 32 || C == 16)) {
+    const int lc = 16;
+    dim3 g(1, B, ((p.To + lc - 1) / lc + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 32) hipLaunchKernelGGL((depthwise_rowseg_kernel<8, 4>), g, dim3(256), 0, st, p, lc);
+    else hipLaunchKernelGGL((depthwise_rowseg_kernel<4, 2>), g, dim3(256), 0, st, p, lc);
+    return ac_check_launch();
+  }
   if (rows_kernel && stride == 1 && pad_before == (k - 1) / 2 && p.Fo == F && p.To == T &&
       (F == 2 || F == 4 || ((F == 8 || F == 16) && k == 3))) {
     // (k = 5 at F = 8, 288 channels = 72 channel groups: a 6-column window + 25 weights do not fit 256 registers, and with the

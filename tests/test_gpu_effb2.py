@@ -99,11 +99,13 @@ def test_depthwise_kernel_and_squeeze_sums(lib, k, stride, pad, C):
 
 @pytest.mark.parametrize("k,Fm,T,C,B", [(5, 4, 63, 720, 3), (5, 2, 32, 1248, 2), (3, 4, 63, 528, 2), (3, 2, 32, 2112, 2),
                                         (3, 8, 126, 288, 2), (5, 4, 7, 48, 3), (3, 2, 1, 8, 1), (5, 2, 94, 1248, 1), (5, 4, 188, 132, 1),
-                                        (5, 8, 126, 288, 2), (3, 16, 251, 144, 2), (5, 8, 5, 16, 1), (3, 16, 17, 260, 1)])
+                                        (5, 8, 126, 288, 2), (3, 16, 251, 144, 2), (5, 8, 5, 16, 1), (3, 16, 17, 260, 1),
+                                        (3, 32, 501, 32, 2), (3, 32, 501, 16, 2), (3, 32, 1, 32, 1), (3, 32, 70, 16, 3)])
 def test_depthwise_rows_in_registers_form(lib, k, Fm, T, C, B, monkeypatch):
     """Stride 1 on a narrow mel axis (the 63 x 4 and 32 x 2 stages; 188 / 94 rows: 30 s clips): the form that keeps the K x F
     window in registers and slides along time (csrc/effnet.hip depthwise_rows_kernel) against F.conv2d, chunk borders
-    (partial last chunk, a single row), channel counts that leave lanes idle, and the squeeze sums."""
+    (partial last chunk, a single row), channel counts that leave lanes idle, and the squeeze sums.  F = 32 with 32 / 16
+    channels (the first stage): the row-segment form, a wave per row (depthwise_rowseg_kernel)."""
     g = torch.Generator().manual_seed(k * 100 + Fm * 10 + T)
     x = torch.randn(B, T, Fm, C, generator=g)
     w = torch.randn(C, 1, k, k, generator=g) * 0.3

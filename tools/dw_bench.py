@@ -10,7 +10,7 @@ P = lambda t: ctypes.c_void_p(t.data_ptr())
 S = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 B = 128
 print("rows kernel:", os.environ.get("AUDIOCAPTION_DW_ROWS_KERNEL", "1"))
-for (k, F, T, C) in [(3, 32, 501, 32), (3, 16, 251, 144), (5, 8, 126, 288), (3, 4, 63, 528), (5, 4, 63, 528), (5, 4, 63, 720), (5, 2, 32, 1248),
+for (k, F, T, C) in [(3, 32, 501, 32), (3, 32, 501, 16), (3, 16, 251, 144), (3, 16, 251, 96), (5, 8, 126, 288), (3, 4, 63, 528), (5, 4, 63, 528), (5, 4, 63, 720), (5, 2, 32, 1248),
                      (3, 2, 32, 1248), (3, 2, 32, 2112)]:
     x = torch.randn(B, T, F, C, device="cuda")
     w = torch.randn(k, k, C, device="cuda") * 0.3
