@@ -257,19 +257,22 @@ __global__ __launch_bounds__(256) void depthwise_rows_kernel(DwP p, int lc) {
 // groups: far fewer than a wave's lanes): a wave covers a whole row - lane = (channel group cg = lane % C4W, column segment
 // seg = lane / C4W of NO = F * C4W / 64 columns); a thread keeps its NO + 2 window columns of the 3 rows in registers and
 // slides along time.  A wave instruction reads 64 / C4W separate runs of C4W * 16 contiguous bytes (whole 128-byte lines at 8
-// channel groups).  223 -> ~110 us (32 channels) / 133 -> ~60 us (16) at 128 clips against the sliding-along-mel form.
-template <int C4W, int NO>
+// channel groups).  223 -> 97 us (32 channels) / 133 -> 54 us (16) at 128 clips against the sliding-along-mel form.  (For the
+// 5 x 5 layers at 8 mel columns x 288 channels - blocks of 8 channel groups over blockIdx.x, one output column per thread, 254
+// registers - the form takes 165 us against 146 for the sliding-along-mel kernel: not routed.)
+template <int K, int C4W, int NO>
 __global__ __launch_bounds__(256) void depthwise_rowseg_kernel(DwP p, int lc) {
-  constexpr int K = 3, NSEG = 64 / C4W, F = NSEG * NO, NW = NO + 2;
+  constexpr int PAD = (K - 1) / 2, NSEG = 64 / C4W, F = NSEG * NO, NW = NO + K - 1;
   __shared__ __attribute__((aligned(16))) float spart[4][64 * 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b = blockIdx.y;
-  const int cg = lane % C4W, seg = lane / C4W;
+  const int b = blockIdx.y, C4 = p.C >> 2;
+  const int cgl = lane % C4W, seg = lane / C4W;
+  const int cg = blockIdx.x * C4W + cgl;                // blockIdx.x: blocks of C4W channel groups
   const int chunk = (int)blockIdx.z * 4 + wave;
-  const int o0 = seg * NO;                              // first output column of this thread; its window starts at o0 - 1
+  const int o0 = seg * NO;                              // first output column of this thread; its window starts at o0 - PAD
   const int to0 = chunk * lc, to1 = min(p.To, to0 + lc);
-  const bool act = to0 < to1;
-  const int c = cg * 4;
+  const bool act = to0 < to1 && cg < C4;
+  const int c = (cg < C4 ? cg : 0) * 4;
   const float* xb = p.x + (long)b * p.T * F * p.C + c;
   float* yb = p.y + (long)b * p.To * F * p.C + c;
   f32x4 psum = {0.f, 0.f, 0.f, 0.f};
@@ -281,23 +284,27 @@ __global__ __launch_bounds__(256) void depthwise_rowseg_kernel(DwP p, int lc) {
 #pragma unroll
       for (int kf = 0; kf < K; ++kf) w[kt][kf] = *(const f32x4*)(p.w + (long)(kt * K + kf) * p.C + c);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    auto load_row = [&](int t, f32x4 (&dst)[NW]) {   // input row t, columns o0 - 1 .. o0 + NO (zeros outside the image)
+    auto load_row = [&](int t, f32x4 (&dst)[NW]) {   // input row t, columns o0 - PAD .. o0 + NO - 1 + PAD (zeros outside the image)
       const bool ok = t >= 0 && t < p.T;
-      const float* rp = xb + ((long)(ok ? t : 0) * F + o0 - 1) * p.C;
+      const float* rp = xb + ((long)(ok ? t : 0) * F + o0 - PAD) * p.C;
 #pragma unroll
       for (int j = 0; j < NW; ++j) {
-        const int col = o0 - 1 + j;
+        const int col = o0 - PAD + j;
         dst[j] = (ok && col >= 0 && col < F) ? *(const f32x4*)(rp + (long)j * p.C) : zero4;
       }
     };
     f32x4 win[K][NW], nxt[NW];
-    load_row(to0 - p.pb, win[1]);
-    load_row(to0 - p.pb + 1, win[2]);
-    load_row(to0 - p.pb + 2, nxt);
+#pragma unroll
+    for (int kt = 0; kt + 1 < K; ++kt) load_row(to0 - p.pb + kt, win[kt + 1]);   // rows of the first window but its last, shifted below
+    load_row(to0 - p.pb + K - 1, nxt);
     for (int to = to0; to < to1; ++to) {
 #pragma unroll
-      for (int j = 0; j < NW; ++j) { win[0][j] = win[1][j]; win[1][j] = win[2][j]; win[2][j] = nxt[j]; }
-      if (to + 1 < to1) load_row(to + 1 - p.pb + 2, nxt);   // in flight under this row's arithmetic
+      for (int kt = 0; kt + 1 < K; ++kt)
+#pragma unroll
+        for (int j = 0; j < NW; ++j) win[kt][j] = win[kt + 1][j];
+#pragma unroll
+      for (int j = 0; j < NW; ++j) win[K - 1][j] = nxt[j];
+      if (to + 1 < to1) load_row(to + 1 - p.pb + K - 1, nxt);   // in flight under this row's arithmetic
 #pragma unroll
       for (int oo = 0; oo < NO; ++oo) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -315,13 +322,15 @@ __global__ __launch_bounds__(256) void depthwise_rowseg_kernel(DwP p, int lc) {
   }
   *(f32x4*)(&spart[wave][lane * 4]) = psum;
   __syncthreads();
-  if (threadIdx.x < C4W) {   // squeeze sums: the workgroup's 4 row chunks x NSEG column segments of channel group threadIdx.x
+  if (threadIdx.x < C4W && blockIdx.x * C4W + threadIdx.x < C4) {
+    // squeeze sums: the workgroup's 4 row chunks x NSEG column segments of channel group threadIdx.x of this block
     f32x4 t = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int wv = 0; wv < 4; ++wv)
       for (int sg = 0; sg < NSEG; ++sg) t += *(const f32x4*)(&spart[wv][(sg * C4W + (int)threadIdx.x) * 4]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) atomicAdd(p.pool + (long)b * p.C + threadIdx.x * 4 + j, t[j] * p.pool_scale);
+    for (int j = 0; j < 4; ++j)
+      atomicAdd(p.pool + (long)b * p.C + (blockIdx.x * C4W + threadIdx.x) * 4 + j, t[j] * p.pool_scale);
   }
 }
 
@@ -556,14 +565,14 @@ int ac_effnet_depthwise(const float* x, const float* w, const float* scale, cons
     const int lc = 16;
     dim3 g(1, B, ((p.To + lc - 1) / lc + 3) / 4);
     hipStream_t st = (hipStream_t)stream;
-    if (C == 32) hipLaunchKernelGGL((depthwise_rowseg_kernel<8, 4>), g, dim3(256), 0, st, p, lc);
-    else hipLaunchKernelGGL((depthwise_rowseg_kernel<4, 2>), g, dim3(256), 0, st, p, lc);
+    if (C == 32) hipLaunchKernelGGL((depthwise_rowseg_kernel<3, 8, 4>), g, dim3(256), 0, st, p, lc);
+    else hipLaunchKernelGGL((depthwise_rowseg_kernel<3, 4, 2>), g, dim3(256), 0, st, p, lc);
     return ac_check_launch();
   }
   if (rows_kernel && stride == 1 && pad_before == (k - 1) / 2 && p.Fo == F && p.To == T &&
       (F == 2 || F == 4 || ((F == 8 || F == 16) && k == 3))) {
-    // (k = 5 at F = 8, 288 channels = 72 channel groups: a 6-column window + 25 weights do not fit 256 registers, and with the
-    // weights in LDS the form takes 160 us against 141 for the one below - 44 % of its lanes have no channel group)
+    // (k = 5 at F = 8, 288 channels = 72 channel groups: a 6-column window + 25 weights do not fit 256 registers; with the
+    // weights in LDS the form takes 160 us, as depthwise_rowseg_kernel<5, 8, 1> 165 us, against 141-146 for the one below)
     const int lc = T >= 48 ? 16 : 8;                        // output rows per wave: 4 (2) halo rows per 16 / 8
     const int halves = F == 16 ? 2 : 1;
     dim3 g((C4 + 63) / 64, B, (((p.To + lc - 1) / lc + 3) / 4) * halves);

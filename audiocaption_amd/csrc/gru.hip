@@ -240,30 +240,30 @@ __global__ __launch_bounds__(256) void gru_layer_split_kernel(GruSplitParams p) 
     for (int t = len; t < p.T; ++t) p.out[((size_t)b * p.T + t) * 2 * H + dir * H + unit] = 0.f;
 }
 
-// fc_emb[b][c] = sum_{t < len[b]} x[b][t][c] / len[b]   (model_util.py:41-63 mean_with_lens)
+// fc_emb[b][c] = sum_{t < len[b]} x[b][t][c] / len[b]   (model_util.py:41-63 mean_with_lens).  One thread per (clip, channel),
+// channels of a clip over blockIdx.y (one workgroup per clip walked 1408 channels in 6 passes of 32 dependent loads: 63 us for
+// 128 EfficientNet clips); t ascending as before: the same bits.
 __global__ void mean_lens_kernel(const float* x, const int* lens, float* out, int T, int C) {
-  const int b = blockIdx.x;
+  const int b = blockIdx.x, c = blockIdx.y * blockDim.x + threadIdx.x;
+  if (c >= C) return;
   const int len = lens[b];
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float s = 0.f;
-    for (int t = 0; t < len && t < T; ++t) s += x[((size_t)b * T + t) * C + c];
-    out[(size_t)b * C + c] = s / (float)len;
-  }
+  float s = 0.f;
+  for (int t = 0; t < len && t < T; ++t) s += x[((size_t)b * T + t) * C + c];
+  out[(size_t)b * C + c] = s / (float)len;
 }
 
 // max over valid steps (model_util.py:65-81 max_with_lens) + mean, Cnn14's own fc_emb input
 __global__ void maxmean_lens_kernel(const float* x, const int* lens, float* out, int T, int C) {
-  const int b = blockIdx.x;
+  const int b = blockIdx.x, c = blockIdx.y * blockDim.x + threadIdx.x;
+  if (c >= C) return;
   const int len = lens[b];
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float s = 0.f, m = -INFINITY;
-    for (int t = 0; t < len && t < T; ++t) {
-      const float v = x[((size_t)b * T + t) * C + c];
-      s += v;
-      m = fmaxf(m, v);
-    }
-    out[(size_t)b * C + c] = m + s / (float)len;
+  float s = 0.f, m = -INFINITY;
+  for (int t = 0; t < len && t < T; ++t) {
+    const float v = x[((size_t)b * T + t) * C + c];
+    s += v;
+    m = fmaxf(m, v);
   }
+  out[(size_t)b * C + c] = m + s / (float)len;
 }
 
 // packed[d][k/4][n][k%4] = whh[d][n][k]
@@ -330,8 +330,8 @@ extern "C" int ac_mean_with_lens(const float* x, const int* lens, float* out, in
                                  void* stream) {
   if (!x || !lens || !out || B <= 0 || T <= 0 || C <= 0) return AC_ERR_ARG;
   if (add_max)
-    hipLaunchKernelGGL(maxmean_lens_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, lens, out, T, C);
+    hipLaunchKernelGGL(maxmean_lens_kernel, dim3(B, (C + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, lens, out, T, C);
   else
-    hipLaunchKernelGGL(mean_lens_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, lens, out, T, C);
+    hipLaunchKernelGGL(mean_lens_kernel, dim3(B, (C + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, lens, out, T, C);
   return ac_check_launch();
 }
