@@ -1294,7 +1294,19 @@ int decoder_step(const ac_trm_weights* w, const float* memkv, const int* mem_len
 
 // logits[R, V] = LayerNorm(fin.x + fin.y) W_cls^T, the normalised rows also stored to xout (= `embed`)
 int classifier_step(const ac_trm_weights* w, const StepOut& fin, int R, float* xout, long ldxo, float* logit,
-                    long ldl, hipStream_t s) {
+                    long ldl, hipStream_t s, float* scratch = nullptr) {
+  // From 512 rows on (beam search over grouped batches: 768 rows x 4368 words) the 16 x 16-tile projection re-reads the
+  // classifier once per 16 rows: 47 us per step; the residual join as its own launch + the tiled exact-f32 GEMM (ac_gemm)
+  // take 4 + 30.  Another summation order than the projection's (last bits of the logits; not a precision change).
+  // AUDIOCAPTION_DEC_CLS_GEMM=0: the projection at every row count.
+  static const bool cls_gemm = !(getenv("AUDIOCAPTION_DEC_CLS_GEMM") && !strcmp(getenv("AUDIOCAPTION_DEC_CLS_GEMM"), "0"));
+  if (cls_gemm && R >= 512 && (xout || scratch) && w->cls_w) {
+    float* nx = xout ? xout : scratch;
+    const long ldn = xout ? ldxo : (long)w->d_model;
+    AC_TRY(launch_ln(fin.x, fin.y, fin.ln_w, fin.ln_b, nx, R, w->d_model, w->d_model, w->d_model, ldn, s));
+    return ac_gemm(nx, ldn, 1, w->cls_w, 1, w->d_model, logit, ldl, R, w->vocab, w->d_model, nullptr, 0, 0.f, 1, 0.f, 0,
+                   nullptr, 0, nullptr, 0, (void*)s);
+  }
   DecGemmParams g;
   g.tok = nullptr; g.tok_stride = 0; g.t = 0; g.emb = nullptr; g.pe = nullptr; g.emb_scale = 0.f;
   g.M = R; g.N = w->vocab; g.K = w->d_model; g.relu = 0;
@@ -1441,7 +1453,7 @@ extern "C" int ac_trm_beam_step(const ac_trm_weights* w, const float* memkv, con
   StepOut fin;
   AC_TRY(decoder_step(w, memkv, mem_len, R, beam, Tm, max_len, t, tokens, key_mask, max_len + 1,
                       ws.cache[t & 1], ws, &fin, s));
-  AC_TRY(classifier_step(w, fin, R, nullptr, 0, ws.lg, V, s));
+  AC_TRY(classifier_step(w, fin, R, nullptr, 0, ws.lg, V, s, ws.att));   // ws.att: dead once the last layer has consumed it
   static const bool two_kernels = getenv("AUDIOCAPTION_BEAM_TOPK") && !strcmp(getenv("AUDIOCAPTION_BEAM_TOPK"), "scan");
   if (beam <= 8 && V <= 8192 && !two_kernels) {
     // scores + per-row candidates in one pass over registers, then a one-wave merge per clip; the candidates (2 x R x

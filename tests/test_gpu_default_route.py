@@ -196,3 +196,22 @@ def test_beam_at_the_clotho_vocabulary_vs_oracle(clotho_models, golden_dir, kind
     wantn = O.beam_search(st, attn, alen, beam_size=beam, max_length=20, n_best=True, n_best_size=beam)["seq"]
     outn = model.forward_decoder(dict(req, n_best=True, n_best_size=beam), enc)
     np.testing.assert_array_equal(outn["seq"].numpy(), wantn.numpy())
+
+
+@pytest.mark.parametrize("kind", ["plain", "beam"])
+def test_beam_over_512_rows_takes_the_tiled_classifier_and_matches_the_oracle(clotho_models, golden_dir, kind):
+    """From 512 decode rows on (beam search over grouped batches) the classifier runs as LayerNorm + the tiled exact-f32 GEMM
+    instead of the 16 x 16-tile projection (csrc/decoder.hip classifier_step): 176 clips x beam 3 = 528 rows - the g4 clips
+    repeated - must give every copy the oracle's caption of its clip (base.py:254-361), like the 12-row search does."""
+    import os
+    from oracle import cpu_path as O
+    model, st = clotho_models[kind]
+    g4 = dict(np.load(os.path.join(golden_dir, "g4_greedy.npz")))
+    attn, alen = torch.from_numpy(g4["attn_emb"]), torch.from_numpy(g4["attn_emb_len"])
+    want = O.beam_search(st, attn, alen, beam_size=3, max_length=20)["seq"]
+    reps = (176 + attn.shape[0] - 1) // attn.shape[0]
+    enc = {"attn_emb": attn.repeat(reps, 1, 1).cuda(), "attn_emb_len": alen.repeat(reps),
+           "fc_emb": torch.from_numpy(g4["fc_emb"]).repeat(reps, 1).cuda()}
+    assert enc["attn_emb"].shape[0] * 3 >= 512
+    out = model.forward_decoder({"mode": "inference", "sample_method": "beam", "beam_size": 3, "max_length": 20}, enc)
+    np.testing.assert_array_equal(out["seq"].numpy(), want.repeat(reps, 1).numpy())
