@@ -990,7 +990,7 @@ def main():
         # secondary: the training step (BASELINE configs[3]) on this GPU
         del out
         try:   # a secondary measurement must never cost the headline line
-            tr = bench_train(args, ranks, max(3, args.steps // 2), 3, with_rccl=True)
+            tr = bench_train(args, ranks, args.steps, 3, with_rccl=True)   # the step count of `--mode train` (the look-ahead's first step is not overlapped)
             extra["train_step"] = {k: tr[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config",
                                                        "roofline", "rccl") if k in tr}
         except Exception as e:  # noqa: BLE001
@@ -999,7 +999,7 @@ def main():
             import copy
             a4 = copy.copy(args)
             a4.train_batch = 4
-            t4 = bench_train(a4, ranks, max(5, args.steps // 2), 3, with_rccl=False, roofline=False)
+            t4 = bench_train(a4, ranks, args.steps, 3, with_rccl=False, roofline=False)
             extra["train_step_b4"] = {k: t4[k] for k in ("value", "unit", "ms_per_step", "steps") if k in t4}
         except Exception as e:  # noqa: BLE001
             extra["train_step_b4"] = {"error": f"{type(e).__name__}: {e}"}
