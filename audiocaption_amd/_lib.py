@@ -68,6 +68,9 @@ SIGNATURES = {
     "ac_trm_memory": (_I, [_WP, _P, _I, _I, _P, _P, _P]),
     "ac_trm_step_pack_floats": (_L, [_WP]),
     "ac_trm_pack_step_weights": (_I, [_WP, _P, _P]),
+    "ac_dec_wide_packed_floats": (_L, [_I, _I]),
+    "ac_dec_wide_pack": (_I, [_P, _L, _I, _I, _P, _P]),
+    "ac_dec_wide_gemm": (_I, [_I, _P, _L, _P, _L, _P, _P, _P, _L, _I, _P, _P, _F, _P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P]),
     "ac_trm_workspace_floats": (_L, [_WP, _I, _I]),
     "ac_trm_greedy": (_I, [_WP, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "ac_conv3x3_skinny_workspace_floats": (_L, [_I, _I, _I, _I, _I]),

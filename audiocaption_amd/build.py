@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libaudiocaption_hip.so")
 STAMP = LIB + ".stamp"
-SOURCES = ["logmel.hip", "conv3x3.hip", "conv3x3_winograd.hip", "conv3x3_wino1d.hip", "conv3x3_wino43.hip", "conv3x3_block1_w4.hip", "conv3x3_skinny.hip", "gemm.hip", "gru.hip", "decoder.hip", "decoder_cluster.hip", "train.hip", "effnet.hip", "effnet_fused.hip", "pw_gemm.hip", "ingest.hip", "probe.hip"]
+SOURCES = ["logmel.hip", "conv3x3.hip", "conv3x3_winograd.hip", "conv3x3_wino1d.hip", "conv3x3_wino43.hip", "conv3x3_block1_w4.hip", "conv3x3_skinny.hip", "gemm.hip", "gru.hip", "decoder.hip", "decoder_wide.hip", "decoder_cluster.hip", "train.hip", "effnet.hip", "effnet_fused.hip", "pw_gemm.hip", "ingest.hip", "probe.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
          "-Wno-unused-function", "-Wno-unused-result"]
 # Every source is built WITHOUT the packed-f32 VALU instructions (v_pk_fma_f32, v_pk_add_f32 ...).  With them the per-row

@@ -22,6 +22,13 @@
 
 extern "C" int ac_linear(const float* X, const float* W, const float* bias, float* Y, int M, int N, int K,
                          long ldx, long ldw, long ldy, int relu, void* stream);
+// csrc/decoder_wide.hip: the projections of a step over >= AUDIOCAPTION_DEC_WIDE_MIN rows
+extern "C" long ac_dec_wide_packed_floats(int N, int K);
+extern "C" int ac_dec_wide_pack(const float* W, long ldw, int N, int K, float* out, void* stream);
+extern "C" int ac_dec_wide_gemm(int producer, const float* X, long ldx, const float* Y2, long ldy2, const float* ln_w,
+                                const float* ln_b, const int* tok, long tok_stride, int t, const float* emb, const float* pe,
+                                float emb_scale, float* xout, long ldxo, const float* Wp, const float* bias, float* Y, long ldy,
+                                int M, int N, int K, int relu, int ntb, int split_out, void* stream);
 
 namespace {
 
@@ -85,6 +92,9 @@ struct AttnParams {
   float* Kw; float* Vw;                   // writable cache base (same geometry as K/V) for the append
   float* out; long ldo;
   int hd; float scale;
+  // wide route (csrc/decoder_wide.hip): the context rows leave as three bf16 planes in MFMA fragment order instead, the A
+  // operand of the out-projection launch: pack[row / 32][k step of 16][plane][lane = row % 32 + 32 * (k % 16 / 8)][k % 8]
+  unsigned char* out_pk = nullptr; int pk_kst = 0;
 };
 
 __global__ __launch_bounds__(64) void attn_step_kernel(AttnParams p) {
@@ -161,7 +171,24 @@ __global__ __launch_bounds__(64) void attn_step_kernel(AttnParams p) {
       o3 = fmaf(sc[j + 3], vpre[j + 3], o3);
     }
     for (int j = VPRE; j < p.nkeys; ++j) o0 = fmaf(sc[j], Vb[(size_t)j * p.key_stride + lane], o0);
-    p.out[(size_t)r * p.ldo + hoff + lane] = ((o0 + o1) + (o2 + o3)) / den;
+    const float val = ((o0 + o1) + (o2 + o3)) / den;
+    if (p.out_pk) {
+      const int c = (int)hoff + lane;
+      unsigned short* d = (unsigned short*)(p.out_pk + ((size_t)(r >> 5) * p.pk_kst + (c >> 4)) * 3072 +
+                                            (size_t)((r & 31) + 32 * ((c >> 3) & 1)) * 16 + (c & 7) * 2);
+      // RNE to bf16, three times over the exact remainders (the split of csrc/decoder_wide.hip, one value at a time)
+      auto rne = [](float x) { const unsigned u = __builtin_bit_cast(unsigned, x); return (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u; };
+      const unsigned h0 = rne(val);
+      const float r1 = val - __builtin_bit_cast(float, h0);
+      const unsigned h1 = rne(r1);
+      const float r2 = r1 - __builtin_bit_cast(float, h1);
+      const unsigned h2 = rne(r2);
+      d[0] = (unsigned short)(h0 >> 16);
+      d[512] = (unsigned short)(h1 >> 16);
+      d[1024] = (unsigned short)(h2 >> 16);
+    } else {
+      p.out[(size_t)r * p.ldo + hoff + lane] = val;
+    }
   }
 }
 
@@ -706,10 +733,12 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void dec_gemm_kernel(DecGemmParams 
 }
 
 template <int PRO>
-int launch_dec_gemm(const DecGemmParams& p, hipStream_t s) {
+int launch_dec_gemm(const DecGemmParams& p_in, hipStream_t s) {
+  DecGemmParams p = p_in;
   if (p.K % 64 || (PRO != PRO_PLAIN && p.K > DEC_MAX_D) || (p.K > DEC_KC && p.K % DEC_KC)) return AC_ERR_ARG;
   const int KC = p.K < DEC_KC ? p.K : DEC_KC;
-  if (p.ntb < 1 || (p.ntb > 1 && p.K > DEC_KC)) return AC_ERR_ARG;
+  if (p.ntb < 1) return AC_ERR_ARG;
+  if (p.K > DEC_KC) p.ntb = 1;   // several column tiles per block re-use ONE staged A tile: single-chunk K only
   // the A tile is [16][KC + 4]: sized by the launch's K chunk, so that the K = 256 projections fit 7 workgroups to a CU
   const size_t lds = ((size_t)DEC_T * (KC + 4) + (size_t)DEC_WAVES * DEC_T * 17) * sizeof(float);
   const int ntiles = (p.N + DEC_T - 1) / DEC_T;
@@ -1072,8 +1101,15 @@ __global__ void cache_gather_kernel(const float* src, float* dst, const int* src
 // ---------------------------------------------------------------------------------------------
 // workspace carving
 // ---------------------------------------------------------------------------------------------
+// The wide route (steps over many rows, csrc/decoder_wide.hip) covers the reference's decoder width: d_model 256 (its fused
+// producers stage a 256-wide row; heads of <= 64) and a feed-forward width of 256, 512 or 1024.
+inline bool wide_shape_ok(const ac_trm_weights* w) {
+  return w->d_model == 256 && (w->dim_ff == 256 || w->dim_ff == 512 || w->dim_ff == 1024);
+}
+
 struct Ws {
   float *x, *x2, *qkv, *att, *tmp, *ff, *q2, *lg;
+  float *attp, *ffp;        // wide route: fragment packs of the attention context rows / the feed-forward hidden rows
   float* cache[2];  // [2 (K,V)][nlayers][R][max_len][d] each
   int *tok, *unfinished;
   unsigned char* mask;
@@ -1096,6 +1132,9 @@ Ws carve(const ac_trm_weights* w, int R, int max_len, float* base) {
   s.ff = take((size_t)R * w->dim_ff);
   s.q2 = take(R * d);
   s.lg = take((size_t)R * w->vocab);
+  const size_t r32 = (size_t)(R + 31) / 32 * 32;
+  s.attp = take(wide_shape_ok(w) ? r32 * d * 3 / 2 : 0);
+  s.ffp = take(wide_shape_ok(w) ? r32 * (size_t)w->dim_ff * 3 / 2 : 0);
   s.cache_set_stride = (size_t)R * max_len * d;
   for (int i = 0; i < 2; ++i) s.cache[i] = take(2 * (size_t)w->nlayers * s.cache_set_stride);
   s.tok = (int*)take((size_t)R * (max_len + 1));
@@ -1134,10 +1173,14 @@ int launch_ln(const float* x, const float* y, const float* w, const float* b, fl
 struct PackLayout {
   size_t sa_in, sa_out, ca_q, ca_out, l1, l2;
   size_t sa_outT, ca_qT, ca_outT;   // transposed [k][n] copies for the fused per-row sub-layer kernel
+  size_t w_sa_in, w_sa_out, w_ca_q, w_ca_out, w_l1, w_l2;   // three-plane bf16 packs of the wide route (csrc/decoder_wide.hip)
 };
 inline size_t packed_floats(int N, int K) { return (size_t)((N + DEC_T - 1) / DEC_T) * DEC_T * K; }
-inline size_t pack_layout(const ac_trm_weights* w, PackLayout* L /* [nlayers] or null */, size_t* cls_off) {
+inline size_t pack_layout(const ac_trm_weights* w, PackLayout* L /* [nlayers] or null */, size_t* cls_off,
+                          size_t* wcls_off = nullptr) {
   const int d = w->d_model, ff = w->dim_ff;
+  const bool wide = wide_shape_ok(w);
+  auto wf = [&](int N, int K) { return wide ? (size_t)ac_dec_wide_packed_floats(N, K) : (size_t)0; };
   size_t off = 0;
   for (int l = 0; l < w->nlayers; ++l) {
     PackLayout t;
@@ -1150,10 +1193,18 @@ inline size_t pack_layout(const ac_trm_weights* w, PackLayout* L /* [nlayers] or
     t.sa_outT = off; off += (size_t)d * d;
     t.ca_qT = off; off += (size_t)d * d;
     t.ca_outT = off; off += (size_t)d * d;
+    t.w_sa_in = off; off += wf(3 * d, d);
+    t.w_sa_out = off; off += wf(d, d);
+    t.w_ca_q = off; off += wf(d, d);
+    t.w_ca_out = off; off += wf(d, d);
+    t.w_l1 = off; off += wf(ff, d);
+    t.w_l2 = off; off += wf(d, ff);
     if (L) L[l] = t;
   }
   if (cls_off) *cls_off = off;
   off += packed_floats(w->vocab, d);
+  if (wcls_off) *wcls_off = off;
+  off += wf(w->vocab, d);
   return off;
 }
 
@@ -1163,6 +1214,18 @@ struct StepOut {
   const float* ln_w;
   const float* ln_b;
 };
+
+// AUDIOCAPTION_DEC_WIDE_MIN=n (default 0 = never): a step over n rows or more takes the wide route.  Opt-in, because it does
+// not pay on this part: stand-alone it is 145 / 217 us per step at 256 / 768 rows against 115 / 193 for the narrow route
+// (22 launches per step instead of 10, each ~3 us of launch overhead + a 3-5 us critical path, although a projection
+// occupies 32-128 workgroups for 3-5 us instead of every CU for 7-18), and beside the next batches' encoders the step
+// costs what its DURATION is, not its CU time: headline 13.85 k vs 14.10 k clips/s, EffB2-Trm 20.65 k vs 20.55 k
+// (EXPERIMENTS.md, round 6).
+inline bool wide_route(const ac_trm_weights* w, int R) {
+  const char* e = getenv("AUDIOCAPTION_DEC_WIDE_MIN");   // read per call (tests switch it); a captured graph keeps its route
+  const int wide_min = e ? atoi(e) : 0;
+  return wide_min > 0 && R >= wide_min && wide_shape_ok(w) && w->d_model / w->nhead <= 64 && w->d_model % w->nhead == 0;
+}
 
 int decoder_step(const ac_trm_weights* w, const float* memkv, const int* mem_len, int R, int row_div, int Tm,
                  int max_len, int t, const int* tok, const unsigned char* mask, long tok_stride, float* cache,
@@ -1191,8 +1254,57 @@ int decoder_step(const ac_trm_weights* w, const float* memkv, const int* mem_len
   // kernels.  (The row kernels once gave co-runner-dependent results: built with packed-f32 VALU instructions their
   // matrix-vector products broke beside MFMA-heavy kernels of another stream - see audiocaption_amd/build.py; every mode is
   // now held to tests/test_gpu_model.py::test_decode_is_bit_stable_beside_matrix_heavy_kernels.)
-  static const bool no_rows = getenv("AUDIOCAPTION_DEC_ROW") && !strcmp(getenv("AUDIOCAPTION_DEC_ROW"), "gemm");
+  const char* dec_row = getenv("AUDIOCAPTION_DEC_ROW");   // read per call (tests compare the sequences; a captured graph keeps its own)
+  const bool no_rows = dec_row && !strcmp(dec_row, "gemm");
   const bool fused = d == ROW_D && w->nhead == ROW_H && t + 1 <= MAX_KEYS && Tm <= MAX_KEYS && !no_rows;
+  if (wide_route(w, R)) {
+    // ---- the wide route: 8 launches per layer, every projection a few dozen 32-row workgroups on the bf16 matrix cores
+    // (csrc/decoder_wide.hip), the attention sub-layers one wave per (row, head).  Rows that feed a projection without a
+    // residual join in front (attention contexts, feed-forward hidden rows) travel as bf16-plane fragment packs ----
+    const float emb_scale = sqrtf((float)d);
+    auto fused = [&](int pro, const float* X, const float* Y2, const float* lw, const float* lb, float* xout, size_t wp,
+                     const float* bias, float* Y, long ldy, int N, int relu, int split_out) {
+      return ac_dec_wide_gemm(pro, X, d, Y2, d, lw, lb, tok, tok_stride, t, w->emb, w->pe, emb_scale, xout, d, pk + wp, bias, Y,
+                              ldy, R, N, d, relu, 1, split_out, (void*)s);
+    };
+    auto packed = [&](const float* Xs, size_t wp, const float* bias, float* Y, int N, int K) {
+      return ac_dec_wide_gemm(0, Xs, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0.f, nullptr, 0, pk + wp,
+                              bias, Y, N, R, N, K, 0, 1, 0, (void*)s);
+    };
+    for (int l = 0; l < w->nlayers; ++l) {
+      const ac_trm_layer& L = w->layer[l];
+      AC_TRY(fused(l == 0 ? 1 : 2, jx, jy, jw, jb, xa, PL[l].w_sa_in, L.sa_in_b, ws.qkv, 3 * d, 3 * d, 0, 0));
+      AttnParams a;
+      float* Kc = cache + (size_t)(2 * l) * ws.cache_set_stride;
+      float* Vc = cache + (size_t)(2 * l + 1) * ws.cache_set_stride;
+      a.q = ws.qkv; a.ldq = 3 * d;
+      a.K = Kc; a.V = Vc; a.Kw = Kc; a.Vw = Vc;
+      a.row_stride = (long)max_len * d; a.key_stride = d; a.row_div = 1; a.nkeys = t + 1;
+      a.key_len = nullptr; a.key_mask = mask; a.mask_stride = tok_stride;
+      a.new_k = ws.qkv + d; a.new_v = ws.qkv + 2 * d; a.ld_new = 3 * d;
+      a.out = nullptr; a.ldo = 0; a.hd = hd; a.scale = scale;
+      a.out_pk = (unsigned char*)ws.attp; a.pk_kst = d / 16;
+      hipLaunchKernelGGL(attn_step_kernel, dim3(R, w->nhead), dim3(64), 0, s, a);
+      AC_TRY(ac_check_launch());
+      AC_TRY(packed(ws.attp, PL[l].w_sa_out, L.sa_out_b, ws.tmp, d, d));
+      AC_TRY(fused(2, xa, ws.tmp, L.n1_w, L.n1_b, xb, PL[l].w_ca_q, L.ca_in_b, ws.q2, d, d, 0, 0));
+      const float* mk = memkv + (size_t)l * Rm * 2 * d;
+      a.q = ws.q2; a.ldq = d;
+      a.K = mk; a.V = mk + d; a.Kw = nullptr; a.Vw = nullptr;
+      a.row_stride = (long)Tm * 2 * d; a.key_stride = 2 * d; a.row_div = row_div; a.nkeys = Tm;
+      a.key_len = mem_len; a.key_mask = nullptr; a.mask_stride = 0;
+      a.new_k = nullptr; a.new_v = nullptr; a.ld_new = 0;
+      hipLaunchKernelGGL(attn_step_kernel, dim3(R, w->nhead), dim3(64), 0, s, a);
+      AC_TRY(ac_check_launch());
+      AC_TRY(packed(ws.attp, PL[l].w_ca_out, L.ca_out_b, ws.tmp, d, d));
+      AC_TRY(fused(2, xb, ws.tmp, L.n2_w, L.n2_b, xa, PL[l].w_l1, L.l1_b, ws.ffp, 0, w->dim_ff, 1, 1));
+      AC_TRY(packed(ws.ffp, PL[l].w_l2, L.l2_b, ws.tmp, d, w->dim_ff));
+      jx = xa; jy = ws.tmp; jw = L.n3_w; jb = L.n3_b;
+      float* tsw = xa; xa = xb; xb = tsw;
+    }
+    fin->x = jx; fin->y = jy; fin->ln_w = jw; fin->ln_b = jb;
+    return AC_OK;
+  }
   for (int l = 0; l < w->nlayers; ++l) {
     const ac_trm_layer& L = w->layer[l];
     // ---- self attention: QKV projection with the layer input produced in its prologue ----
@@ -1247,10 +1359,7 @@ int decoder_step(const ac_trm_weights* w, const float* memkv, const int* mem_len
       AC_TRY(launch_dec_gemm<PRO_PLAIN>(g, s));
       g.X = ws.ff; g.ldx = w->dim_ff; g.Wp = pk + PL[l].l2; g.bias = L.l2_b; g.Y = ws.tmp; g.ldy = d;
       g.N = d; g.K = w->dim_ff; g.relu = 0; g.xout = nullptr;
-      const int ntb_keep = g.ntb;
-      if (g.K > DEC_KC) g.ntb = 1;
-      AC_TRY(launch_dec_gemm<PRO_PLAIN>(g, s));
-      g.ntb = ntb_keep;
+      AC_TRY(launch_dec_gemm<PRO_PLAIN>(g, s));   // K = dim_ff may exceed one chunk: the launcher then takes one tile per block
       jx = xa; jy = ws.tmp; jw = L.n3_w; jb = L.n3_b;
       float* tsw = xa; xa = xb; xb = tsw;
       continue;
@@ -1299,6 +1408,15 @@ int classifier_step(const ac_trm_weights* w, const StepOut& fin, int R, float* x
   // classifier once per 16 rows: 47 us per step; the residual join as its own launch + the tiled exact-f32 GEMM (ac_gemm)
   // take 4 + 30.  Another summation order than the projection's (last bits of the logits; not a precision change).
   // AUDIOCAPTION_DEC_CLS_GEMM=0: the projection at every row count.
+  if (wide_route(w, R) && (!xout || (ldxo % 4 == 0 && !((uintptr_t)xout & 15)))) {
+    size_t wcls;
+    pack_layout(w, nullptr, nullptr, &wcls);
+    const char* e = getenv("AUDIOCAPTION_DEC_WIDE_CLS_NTB");
+    const int cls_ntb = e ? atoi(e) : 2;
+    return ac_dec_wide_gemm(2, fin.x, w->d_model, fin.y, w->d_model, fin.ln_w, fin.ln_b, nullptr, 0, 0, nullptr, nullptr, 0.f,
+                            xout, ldxo, w->step_pk + wcls, nullptr, logit, ldl, R, w->vocab, w->d_model, 0,
+                            cls_ntb > 0 ? cls_ntb : 1, 0, (void*)s);
+  }
   static const bool cls_gemm = !(getenv("AUDIOCAPTION_DEC_CLS_GEMM") && !strcmp(getenv("AUDIOCAPTION_DEC_CLS_GEMM"), "0"));
   if (cls_gemm && R >= 512 && (xout || scratch) && w->cls_w) {
     float* nx = xout ? xout : scratch;
@@ -1359,8 +1477,12 @@ extern "C" int ac_trm_pack_step_weights(const ac_trm_weights* w, float* out, voi
   hipStream_t s = (hipStream_t)stream;
   const int d = w->d_model, ff = w->dim_ff;
   PackLayout PL[AC_MAX_LAYERS];
-  size_t cls_off;
-  pack_layout(w, PL, &cls_off);
+  size_t cls_off, wcls_off;
+  pack_layout(w, PL, &cls_off, &wcls_off);
+  const bool wide = wide_shape_ok(w);
+  auto wpack = [&](const float* W, int N, int K, float* dst) {
+    return wide ? ac_dec_wide_pack(W, (long)K, N, K, dst, stream) : AC_OK;
+  };
   auto pack = [&](const float* W, int N, int K, float* dst) {
     const size_t n4 = packed_floats(N, K) / 4;
     hipLaunchKernelGGL(pack_frag_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, W, (long)K, N, K, dst);
@@ -1374,6 +1496,12 @@ extern "C" int ac_trm_pack_step_weights(const ac_trm_weights* w, float* out, voi
     AC_TRY(pack(L.ca_out_w, d, d, out + PL[l].ca_out));
     AC_TRY(pack(L.l1_w, ff, d, out + PL[l].l1));
     AC_TRY(pack(L.l2_w, d, ff, out + PL[l].l2));
+    AC_TRY(wpack(L.sa_in_w, 3 * d, d, out + PL[l].w_sa_in));
+    AC_TRY(wpack(L.sa_out_w, d, d, out + PL[l].w_sa_out));
+    AC_TRY(wpack(L.ca_in_w, d, d, out + PL[l].w_ca_q));
+    AC_TRY(wpack(L.ca_out_w, d, d, out + PL[l].w_ca_out));
+    AC_TRY(wpack(L.l1_w, ff, d, out + PL[l].w_l1));
+    AC_TRY(wpack(L.l2_w, d, ff, out + PL[l].w_l2));
     if (d % 32 == 0) {
       const float* src[3] = {L.sa_out_w, L.ca_in_w, L.ca_out_w};
       const size_t dst[3] = {PL[l].sa_outT, PL[l].ca_qT, PL[l].ca_outT};
@@ -1383,7 +1511,8 @@ extern "C" int ac_trm_pack_step_weights(const ac_trm_weights* w, float* out, voi
       }
     }
   }
-  return pack(w->cls_w, w->vocab, d, out + cls_off);
+  AC_TRY(pack(w->cls_w, w->vocab, d, out + cls_off));
+  return wpack(w->cls_w, w->vocab, d, out + wcls_off);
 }
 
 extern "C" long ac_trm_workspace_floats(const ac_trm_weights* w, int rows, int max_len) {

@@ -35,13 +35,14 @@
 // d_model 256, 4 heads of 64, dim_ff 1024, <= 8 layers, max_len <= 32, the LDS must hold the row's memory slices
 // (nlayers x (Tm + max_len) x 512 bytes + 12 KB <= 160 KB); other shapes are the launch chain's (AC_ERR_ARG here).
 #include "ac_common.h"
+#include <stdlib.h>
 #include "../../include/audiocaption_hip.h"
 
 namespace {
 
 constexpr int CD = 256, CHD = 64, CFF = 1024, CFQ = 256, CPARTS = 4;
 constexpr int CMAXL = 32;                         // max_len bound (scores of the self attention: one 8-lane group per key)
-constexpr long long C_SPIN_TICKS = 200000000;     // 2 s of the 100 MHz wall clock
+constexpr long long C_SPIN_TICKS = 200000000;     // 2 s of the 100 MHz wall clock (AUDIOCAPTION_CLUSTER_TIMEOUT_US overrides)
 constexpr size_t C_LAYER_FLOATS = (size_t)CD * 192 + 64 * CD + (size_t)CD * 64 + 64 * CD + (size_t)CD * CFQ + (size_t)CFQ * CD;
 constexpr size_t C_OFF_QKV = 0, C_OFF_O = (size_t)CD * 192, C_OFF_CQ = C_OFF_O + 64 * CD, C_OFF_CO = C_OFF_CQ + (size_t)CD * 64,
                  C_OFF_W1 = C_OFF_CO + 64 * CD, C_OFF_W2 = C_OFF_W1 + (size_t)CD * CFQ;
@@ -64,6 +65,8 @@ struct ClusterParams {
                             //   so that a reader who sees every cluster arrived also sees every row's contribution
   unsigned long long* xch;  // [B][2 slots][4 parts][256] granules
   unsigned* ticket; unsigned* error;
+  long long spin_ticks;     // how long a part polls for a partner's granule before it raises the error word (100 MHz ticks)
+  int fault;                // development / tests: the workgroup that draws ticket fault - 1 returns at once (a lost partner); 0: off
 };
 
 __device__ __forceinline__ long long c_wall_clock() { return (long long)__builtin_amdgcn_s_memrealtime(); }
@@ -166,6 +169,7 @@ struct ClusterCtx {
   unsigned* error;
   int part;
   unsigned seqno;
+  long long spin_ticks;
 };
 
 // Publish `val` (threads with `active`) and collect the four parts' values of this exchange: x4[q * 256 + tid] = part q's value
@@ -199,7 +203,7 @@ __device__ __forceinline__ bool cluster_exchange(ClusterCtx& c, float val, bool 
         do {
           __builtin_amdgcn_s_sleep(1);
           x[i] = __hip_atomic_load(c.base + (size_t)(slot * 4 + other) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (c_wall_clock() - t0 > C_SPIN_TICKS) { ok = false; break; }
+          if (c_wall_clock() - t0 > c.spin_ticks) { ok = false; break; }
         } while ((unsigned)(x[i] >> 32) != tag);
       }
       x4[other * 256 + tid] = __uint_as_float((unsigned)x[i]);
@@ -296,7 +300,7 @@ __global__ __launch_bounds__(256) void cluster_init_kernel(ClusterParams p, unsi
   if (i < (unsigned)(p.B * p.max_len)) { p.seq[i] = p.end_idx; p.logprob[i] = 0.f; }
   if (i < (unsigned)p.max_len) p.cnt[i] = 0;
   if (i < (unsigned)CMAXL) p.prog[i] = 0ull;
-  if (i == 0) *p.ticket = 0u;
+  if (i == 0) { *p.ticket = 0u; *p.error = 0u; }   // the error word reports THIS call (a stale flag would re-decode every later batch)
   for (unsigned w = i; w < xch_words; w += gridDim.x * 256u) p.xch[w] = 0ull;
 }
 
@@ -325,6 +329,7 @@ __global__ __launch_bounds__(256, 1) void greedy_cluster_kernel(ClusterParams p)
   __syncthreads();
   const int row = (int)(s_ticket >> 2), part = (int)(s_ticket & 3u);
   if (row >= p.B) return;
+  if (p.fault && s_ticket == (unsigned)(p.fault - 1)) return;   // injected fault: this part never answers its partners
   const int nl = p.nlayers, Tm = p.Tm, L = p.max_len;
   // ---- LDS carving (floats) ----
   float* xs = lds;                    // [256] the row entering a sub-layer
@@ -358,6 +363,7 @@ __global__ __launch_bounds__(256, 1) void greedy_cluster_kernel(ClusterParams p)
   cx.error = p.error;
   cx.part = part;
   cx.seqno = 0u;
+  cx.spin_ticks = p.spin_ticks;
   const CRsrc wrs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.pk + (size_t)part * p.part_floats), 0, (int)(p.part_floats * 4), 0x00020000);
   const unsigned cls_off = (unsigned)((size_t)nl * C_LAYER_FLOATS * 4);
   int tok = p.start_idx, unfinished = 1;
@@ -592,7 +598,8 @@ inline size_t cluster_part_floats(const ac_trm_weights* w) { return (size_t)w->n
 
 inline int cluster_shape_ok(const ac_trm_weights* w) {
   return w && w->d_model == CD && w->nhead == 4 && w->dim_ff == CFF && w->nlayers >= 1 && w->nlayers <= AC_MAX_LAYERS &&
-         w->vocab >= 4 && cluster_nlc(w->vocab) <= 8192;
+         w->vocab >= 4 && 3 * cluster_vq(w->vocab) < w->vocab &&   // every quarter owns a column (V = 5, 6, 9: the last one would not)
+         cluster_nlc(w->vocab) <= 8192;
 }
 
 inline size_t cluster_lds_bytes(int nlayers, int Tm, int max_len, int NLC) {
@@ -673,6 +680,13 @@ extern "C" int ac_trm_greedy_cluster(const ac_trm_weights* w, const float* clust
   p.start_idx = start_idx; p.end_idx = end_idx; p.pad_idx = pad_idx;
   p.stop_rows = early_stop ? B : -1;
   p.seq = seq; p.logit = logit; p.logprob = logprob; p.embed = embed; p.cnt = unfinished_cnt;
+  {   // read per call (tests shorten the bound and inject a lost partner; a captured graph keeps what it was captured with)
+    const char* e = getenv("AUDIOCAPTION_CLUSTER_TIMEOUT_US");
+    const long long us = e ? atoll(e) : 0;
+    p.spin_ticks = us > 0 ? us * 100 : C_SPIN_TICKS;
+    const char* f = getenv("AUDIOCAPTION_CLUSTER_FAULT");
+    p.fault = f ? atoi(f) : 0;
+  }
   p.error = (unsigned*)workspace;
   p.ticket = (unsigned*)((char*)workspace + 64);
   p.prog = (unsigned long long*)((char*)workspace + 128);

@@ -273,11 +273,13 @@ def conv3x3_bn_relu_skinny(x, wfrag, scale, shift, out, B, Hp, H, W, Cin, Cout, 
         info = {"B": B, "H": H, "Hp": Hp, "W": W, "Cin": Cin, "Cout": Cout, "mode": mode, "algo": "skinny"}
         hook("pre", info)
     dp, dseed, ddev = dropout if dropout is not None else (0.0, 0, None)
-    check(_lib.load().ac_conv3x3_bn_relu_skinny(ptr(x), ptr(wfrag), ptr(scale), ptr(shift), ptr(out), B, Hp, H, W, Cin, Cout,
-                                               mode, ptr(workspace), workspace.numel(), float(dp), int(dseed), ddev, stream()),
-          "ac_conv3x3_bn_relu_skinny")
-    if hook is not None:
-        hook("post", info)
+    try:
+        check(_lib.load().ac_conv3x3_bn_relu_skinny(ptr(x), ptr(wfrag), ptr(scale), ptr(shift), ptr(out), B, Hp, H, W, Cin, Cout,
+                                                   mode, ptr(workspace), workspace.numel(), float(dp), int(dseed), ddev, stream()),
+              "ac_conv3x3_bn_relu_skinny")
+    finally:   # a rejected launch must not leave the observer's "pre" event unpaired
+        if hook is not None:
+            hook("post", info)
     return out
 
 

@@ -155,15 +155,26 @@ class TransformerDecoder(BaseDecoder):
                 self._cluster_pk = pk
         return self._cluster_pk if self._cluster_pk is not False else None
 
-    def cluster_covers(self, rows, Tm, max_length):
+    def cluster_covers(self, rows, Tm, max_length, device=None):
         """The one-launch greedy search takes this problem: shape covered, the row's keys and values fit the LDS, and the
-        clusters are resident together (one workgroup per CU, four per row: AUDIOCAPTION_CLUSTER_MAX_ROWS, default 64)."""
+        clusters are resident together - one workgroup per CU, four per row: rows <= compute units // 4 of ``device`` (64 on
+        a whole MI355X; a CU-masked or partitioned device has fewer and would run the clusters in rounds, slower than the
+        launch chain).  AUDIOCAPTION_CLUSTER_MAX_ROWS overrides the bound."""
         if self.d_model != 256 or self.nhead != 4 or self.dim_feedforward != 1024 or max_length > 32:
             return False
-        nlc = ((self.vocab_size + 3) // 4 + 63) // 64 * 64
+        vq = (self.vocab_size + 3) // 4
+        if 3 * vq >= self.vocab_size:     # a vocabulary quarter without a column (csrc/decoder_cluster.hip cluster_shape_ok)
+            return False
+        nlc = (vq + 63) // 64 * 64
         lds = 4 * (256 + 192 + 64 + 256 + 5 * 256 + ((max(Tm, 32) + 3) & ~3) + 256 + 16 + 1024 + nlc
                    + 2 * self.nlayers * (max_length + Tm) * 64) + 64
-        return lds <= 159 * 1024 and rows <= int(os.environ.get("AUDIOCAPTION_CLUSTER_MAX_ROWS", "64"))
+        env = os.environ.get("AUDIOCAPTION_CLUSTER_MAX_ROWS")
+        if env is not None:
+            max_rows = int(env)
+        else:
+            dev = device if device is not None else self.word_embedding.weight.device
+            max_rows = torch.cuda.get_device_properties(dev).multi_processor_count // 4 if dev.type == "cuda" else 0
+        return lds <= 159 * 1024 and rows <= max_rows
 
     def workspace(self, rows, max_len, device):
         lib = _lib.load()
@@ -252,10 +263,11 @@ class TransformerDecoder(BaseDecoder):
         mode = mode or os.environ.get("AUDIOCAPTION_GREEDY", "auto")
         if mode not in ("auto", "chain", "cluster"):
             raise ValueError(f"AUDIOCAPTION_GREEDY={mode!r}: 'auto', 'chain' or 'cluster'")
-        covered = self.cluster_covers(B, Tm, max_length) and self.cluster_pack() is not None
+        wanted = mode == "cluster" or (mode == "auto" and alone)   # the weights are repacked for it only when it can be chosen
+        covered = wanted and self.cluster_covers(B, Tm, max_length, dev) and self.cluster_pack() is not None
         if mode == "cluster" and not covered:
             raise _lib.HipLibraryError("the one-launch greedy search does not cover this decoder shape / row count")
-        cluster = mode == "cluster" or (mode == "auto" and alone and covered)
+        cluster = wanted and covered
         # AUDIOCAPTION_CLUSTER_EARLY_STOP=0: the one-launch form runs all max_length steps like the launch chain (benchmarks that
         # compare the two at equal work; the outputs are the same either way)
         early = os.environ.get("AUDIOCAPTION_CLUSTER_EARLY_STOP", "1") != "0"
@@ -280,7 +292,7 @@ class TransformerDecoder(BaseDecoder):
             }
             if cluster:
                 nb = _lib.load().ac_trm_cluster_workspace_bytes(B)
-                st["cluster_ws"] = torch.zeros((nb + 7) // 8, device=dev, dtype=torch.int64)   # error word zeroed once
+                st["cluster_ws"] = torch.zeros((nb + 7) // 8, device=dev, dtype=torch.int64)   # (the error word is reset by every call)
                 st["cluster_pk"] = self.cluster_pack()
                 st["early_stop"] = early
         states[key] = st                       # most recently used last; batches of changing length keep 8 shapes

@@ -288,6 +288,26 @@ int ac_trm_memory(const ac_trm_weights* w, const float* attn_emb, int R, int Tm,
 long ac_trm_step_pack_floats(const ac_trm_weights* w);
 int ac_trm_pack_step_weights(const ac_trm_weights* w, float* out, void* stream);
 
+/* Decode-step projection for WIDE row batches (a greedy chain over several submissions, a beam search over grouped batches:
+ * 200 ... 1000 rows per step), csrc/decoder_wide.hip:  Y[M][N] = act(P(X)[M][K] W[N][K]^T + bias), the F.linear calls of
+ * nn.TransformerDecoderLayer and the classifier (transformer_decoder.py:92-101) with the producer of the A rows fused in -
+ * producer 0: X is a fragment PACK of the rows (ac_dec_wide_pack of a [M][K] matrix, or the output of a split_out launch),
+ *             K = 256, 512 or 1024, ntb = 1;
+ * producer 1: A = emb[tok[r*tok_stride + t]] * emb_scale + pe[t] (transformer_decoder.py:89-91), K = 256;
+ * producer 2: A = LayerNorm(X + Y2) * ln_w + ln_b, eps 1e-5 (the post-LN residual join), K = 256.
+ * Producers 1 and 2 also store the produced rows to xout (may be NULL).  Arithmetic: both operands split into three bf16 planes
+ * (24 significant bits), the six plane products of order <= 2 on v_mfma_f32_32x32x16_bf16 with f32 accumulation - f32-grade
+ * (below the rounding of an f32 dot product) at 2.7x the f32 matrix rate.  Pack layout: [tile of 32 rows][k step of 16][plane]
+ * [lane = row % 32 + 32 * (k % 16 / 8)][k % 8] bf16, ac_dec_wide_packed_floats(rows, K) floats, 16-byte aligned; Wp = the pack
+ * of W.  split_out = 1 (producers 1 / 2, N % 16 == 0): Y receives the PACK of the [M][N] result instead of f32 rows.
+ * ntb: 64-column groups per workgroup.  16-byte aligned rows of X / Y2 / xout (Y: any; 16-byte stores when its rows are aligned). */
+long ac_dec_wide_packed_floats(int N, int K);
+int ac_dec_wide_pack(const float* W, long ldw, int N, int K, float* out, void* stream);
+int ac_dec_wide_gemm(int producer, const float* X, long ldx, const float* Y2, long ldy2, const float* ln_w,
+                     const float* ln_b, const int* tok, long tok_stride, int t, const float* emb, const float* pe,
+                     float emb_scale, float* xout, long ldxo, const float* Wp, const float* bias, float* Y, long ldy, int M,
+                     int N, int K, int relu, int ntb, int split_out, void* stream);
+
 /* Number of workspace floats ac_trm_greedy / ac_trm_forward_tokens / ac_trm_beam need. */
 long ac_trm_workspace_floats(const ac_trm_weights* w, int rows, int max_len);
 

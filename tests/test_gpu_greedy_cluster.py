@@ -103,3 +103,114 @@ def test_cluster_refuses_what_it_does_not_cover(hip_model):
         dec.greedy(*args, mode="cluster")
     out = dec.greedy(*args, alone=True)
     assert "cluster_error" not in out and out["seq"].shape == (100, 20)
+
+
+def test_lost_partner_unwinds_and_the_blocking_call_falls_back_to_the_chain(hip_model, monkeypatch):
+    """The failure path of the one-launch search, exercised: one workgroup of row 0's cluster returns at once
+    (AUDIOCAPTION_CLUSTER_FAULT: the part that draws ticket 3), its three partners poll for the configured bound
+    (AUDIOCAPTION_CLUSTER_TIMEOUT_US: 20 ms here, 2 s by default), raise the error word and unwind; the other rows finish.
+    ``model()`` must warn and return the launch chain's result - and the NEXT call must be judged on its own (the word is
+    reset by every call: a stale flag would decode every later batch twice)."""
+    import time
+    from audiocaption_amd import procedural as P
+    monkeypatch.delenv("AUDIOCAPTION_GREEDY", raising=False)
+    monkeypatch.setenv("AUDIOCAPTION_DECODE_GRAPH", "0")          # eager launches: the environment is read by every call
+    wav_len = [96000, 80000, 64000, 90000, 70000]
+    wav = P.synthetic_wav(5, 96000, seed=11, varied=True)
+    for i, n in enumerate(wav_len):
+        wav[i, n:] = 0.0
+    inp = {"mode": "inference", "wav": torch.from_numpy(wav).cuda(), "wav_len": wav_len, "specaug": False,
+           "sample_method": "greedy", "max_length": 12}
+    monkeypatch.setenv("AUDIOCAPTION_GREEDY", "chain")
+    want = hip_model(dict(inp))
+    monkeypatch.delenv("AUDIOCAPTION_GREEDY")
+    monkeypatch.setenv("AUDIOCAPTION_CLUSTER_TIMEOUT_US", "20000")
+    monkeypatch.setenv("AUDIOCAPTION_CLUSTER_FAULT", "4")
+    t0 = time.perf_counter()
+    with pytest.warns(UserWarning, match="one-launch greedy search"):
+        got = hip_model(dict(inp))
+    dt = time.perf_counter() - t0
+    assert torch.equal(got["seq"], want["seq"])
+    assert torch.equal(got["logit"], want["logit"]), "the fallback is the launch chain itself"
+    assert dt < 1.5, f"the unwind took {dt:.2f} s with a 20 ms bound"
+    # the error word of the faulty call does not leak into the next one
+    monkeypatch.delenv("AUDIOCAPTION_CLUSTER_FAULT")
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        again = hip_model(dict(inp))
+    assert torch.equal(again["seq"], want["seq"])
+    assert float((again["logit"] - want["logit"]).abs().max()) < 2e-5
+
+
+def test_cluster_64_rows_wav_to_ids_vs_oracle(hip_model, state4981, monkeypatch):
+    """Every CU holds a workgroup: 64 clips (ragged, 5 s) through the blocking call, whose decode must be the one-launch form,
+    against oracle/cpu_path.py run in chunks of 16 clips: ids identical, logits within 1e-4."""
+    from audiocaption_amd import procedural as P
+    from test_gpu_default_route import _oracle_in_chunks, _check_against_chunks
+    monkeypatch.delenv("AUDIOCAPTION_GREEDY", raising=False)
+    B, L = 64, 160000
+    wav_len = [L - 3200 * (i % 7) * (1 if i % 4 else 0) for i in range(B)]
+    wav = P.synthetic_wav(B, L, seed=21, varied=True)
+    for i, n in enumerate(wav_len):
+        wav[i, n:] = 0.0
+    wav = torch.from_numpy(wav)
+    seen = []
+    orig = hip_model.decoder._greedy_launch
+
+    def spy(st, *a):
+        seen.append(st.get("cluster_ws") is not None)
+        return orig(st, *a)
+
+    monkeypatch.setattr(hip_model.decoder, "_greedy_launch", spy)
+    out = hip_model({"mode": "inference", "wav": wav.cuda(), "wav_len": wav_len, "specaug": False,
+                     "sample_method": "greedy", "max_length": 20})
+    torch.cuda.synchronize()
+    assert seen and all(seen), "the blocking call at 64 rows should have used the cluster kernel"
+    ref = _oracle_in_chunks(state4981, wav, wav_len)
+    assert _check_against_chunks(out, ref, wav_len) < 1e-4
+
+
+def test_cluster_is_bit_stable_beside_a_matrix_heavy_corunner(hip_model):
+    """The clusters wait for compute units a co-runner holds: beside the F(2,3) conv kernel launched back to back on a second
+    stream (256-thread workgroups, two per CU, matrix cores busy) the 64-row search must still finish (clusters form by
+    ticket: any four co-resident workgroups do), raise no error and give the bits of the undisturbed run."""
+    from audiocaption_amd import kernels as K
+    dec = hip_model.decoder
+    attn, lens = _enc(64, 31, seed=9)
+    args = (attn.cuda(), lens, 20, hip_model.start_idx, hip_model.end_idx, hip_model.pad_idx)
+    for _ in range(3):
+        want = dec.greedy(*args, mode="cluster")
+    torch.cuda.synchronize()
+    assert int(want["cluster_error"].item()) == 0
+    B, H, Hp, W, Cin, Cout = 16, 250, 256, 16, 128, 256
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(B * Hp, W, Cin, device="cuda", generator=g)
+    wpk = K.pack_conv_weight_wino1d_frag(torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) * 0.03)
+    sc, sh = torch.ones(Cout, device="cuda"), torch.zeros(Cout, device="cuda")
+    out = torch.empty(B * Hp, W, Cout, device="cuda")
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    differing = 0
+    for _ in range(12):
+        with torch.cuda.stream(side):
+            for _ in range(6):
+                K.conv3x3_bn_relu_wino1d(x, wpk, sc, sh, out, B, Hp, H, W, Cin, Cout, 0)
+        got = dec.greedy(*args, mode="cluster")
+        torch.cuda.synchronize()
+        assert int(got["cluster_error"].item()) == 0
+        differing += int(not (torch.equal(got["logit"], want["logit"]) and torch.equal(got["seq"], want["seq"])))
+    assert differing == 0
+
+
+def test_cluster_refuses_a_vocabulary_quarter_without_a_column():
+    """V = 5, 6, 9: the last quarter would own no column (its arg-max would start from -inf - -inf): the shape is not covered, the
+    C ABI says so and ``cluster_covers`` routes to the chain."""
+    import ctypes
+    import audiocaption_amd as A
+    from audiocaption_amd import _lib
+    for V, ok in ((5, False), (6, False), (9, False), (8, True), (4368, True)):
+        dec = A.TransformerDecoder(emb_dim=256, vocab_size=V, fc_emb_dim=512, attn_emb_dim=512, dropout=0.2, nlayers=2).eval().cuda()
+        n = _lib.load().ac_trm_cluster_pack_floats(ctypes.byref(dec.weights()))
+        assert (n > 0) == ok, V
+        assert dec.cluster_covers(4, 31, 20) == ok, V
