@@ -30,6 +30,19 @@ extern "C" int ac_dec_wide_gemm(int producer, const float* X, long ldx, const fl
                                 float emb_scale, float* xout, long ldxo, const float* Wp, const float* bias, float* Y, long ldy,
                                 int M, int N, int K, int relu, int ntb, int split_out, void* stream);
 
+// DEC_REGCAP: registers per lane the decode chain's kernels may use (development switch: -DDEC_REGCAP=64 builds them to fit
+// beside a one-wave-per-SIMD conv workgroup, which leaves 64 of a SIMD's 512 registers - tools/tax_probe.py)
+#ifndef DEC_REGCAP
+#define DEC_REGCAP 0
+#endif
+#if DEC_REGCAP
+#define DEC_CAP __attribute__((amdgpu_waves_per_eu(512 / DEC_REGCAP, 8)))
+#define DEC_ROW_BOUNDS __launch_bounds__(256) DEC_CAP
+#else
+#define DEC_CAP
+#define DEC_ROW_BOUNDS __launch_bounds__(256, 2)
+#endif
+
 namespace {
 
 // ---------------------------------------------------------------------------------------------
@@ -97,7 +110,7 @@ struct AttnParams {
   unsigned char* out_pk = nullptr; int pk_kst = 0;
 };
 
-__global__ __launch_bounds__(64) void attn_step_kernel(AttnParams p) {
+__global__ __launch_bounds__(64) DEC_CAP void attn_step_kernel(AttnParams p) {
   __shared__ float sc[MAX_KEYS];
   const int r = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
   const int kr = r / p.row_div;
@@ -423,7 +436,7 @@ extern "C" int ac_row_stamps_read(unsigned long long* out16) {
 #define ROW_STAMP(k) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(256, 2) void dec_row_kernel(RowParams p) {
+__global__ DEC_ROW_BOUNDS void dec_row_kernel(RowParams p) {
   __shared__ float sc[ROW_H][MAX_KEYS];
   __shared__ __attribute__((aligned(16))) float sx[ROW_D];
   __shared__ __attribute__((aligned(16))) float part[4 * ROW_D];
@@ -457,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void dec_row_kernel(RowParams p) {
 // LN2 (dec_row_kernel on the audio memory).  Everything after the QKV projection is row-local, so the second launch only
 // bought a kernel boundary and a global round trip of the 256-float query.  The same functions in the same order: the
 // same bits as the two launches.
-__global__ __launch_bounds__(256, 2) void dec_row2_kernel(RowParams p1, RowParams p2) {
+__global__ DEC_ROW_BOUNDS void dec_row2_kernel(RowParams p1, RowParams p2) {
   __shared__ float sc[ROW_H][MAX_KEYS];
   __shared__ __attribute__((aligned(16))) float sx[ROW_D];
   __shared__ __attribute__((aligned(16))) float sq[ROW_D];
@@ -587,7 +600,7 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 }
 
 template <int PRO>
-__global__ __launch_bounds__(64 * DEC_WAVES) void dec_gemm_kernel(DecGemmParams p) {
+__global__ __launch_bounds__(64 * DEC_WAVES) DEC_CAP void dec_gemm_kernel(DecGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];
   float* sX = dsm;   // [16][KC + 4] A tile: the fused producer's rows, or a coalesced copy of X
   float* red = dsm + DEC_T * ((p.K < DEC_KC ? p.K : DEC_KC) + 4);  // [DEC_WAVES][16*17] split-K partials
@@ -765,7 +778,7 @@ __device__ __forceinline__ void argmax_merge(float& v, int& i, float ov, int oi)
 
 constexpr int PICK_MAXV = 16384;  // logits of a row are held in registers: <= 64 per thread
 
-__global__ __launch_bounds__(256) void greedy_pick_kernel(PickParams p) {
+__global__ __launch_bounds__(256) DEC_CAP void greedy_pick_kernel(PickParams p) {
   __shared__ float sv[4];
   __shared__ int si[4];
   __shared__ float ssum[4];
@@ -1227,6 +1240,15 @@ inline bool wide_route(const ac_trm_weights* w, int R) {
   return wide_min > 0 && R >= wide_min && wide_shape_ok(w) && w->d_model / w->nhead <= 64 && w->d_model % w->nhead == 0;
 }
 
+// From 512 rows on (a beam search over grouped batches) two launches of the narrow route are far from their arithmetic: the
+// QKV projection with the residual join in its prologue (30 us at 768 rows: 24 column blocks per 16-row tile each redo the
+// LayerNorm) and the classifier (LayerNorm launch + tiled exact-f32 GEMM: 8 + 49 us).  Both have a wide twin with the same
+// inputs and outputs (csrc/decoder_wide.hip, f32-grade on the bf16 matrix cores): 11 and ~25 us.  AUDIOCAPTION_DEC_HYBRID=0: off.
+inline bool hybrid_route(const ac_trm_weights* w, int R) {
+  const char* e = getenv("AUDIOCAPTION_DEC_HYBRID");
+  return !(e && !strcmp(e, "0")) && R >= 512 && wide_shape_ok(w);
+}
+
 int decoder_step(const ac_trm_weights* w, const float* memkv, const int* mem_len, int R, int row_div, int Tm,
                  int max_len, int t, const int* tok, const unsigned char* mask, long tok_stride, float* cache,
                  const Ws& ws, StepOut* fin, hipStream_t s) {
@@ -1312,6 +1334,9 @@ int decoder_step(const ac_trm_weights* w, const float* memkv, const int* mem_len
     g.xout = xa; g.ldxo = d;
     if (l == 0) {
       AC_TRY(launch_dec_gemm<PRO_EMBED>(g, s));
+    } else if (hybrid_route(w, R)) {
+      AC_TRY(ac_dec_wide_gemm(2, jx, d, jy, d, jw, jb, nullptr, 0, 0, nullptr, nullptr, 0.f, xa, d, pk + PL[l].w_sa_in, L.sa_in_b,
+                              ws.qkv, 3 * d, R, 3 * d, d, 0, 1, 0, (void*)s));
     } else {
       g.X = jx; g.ldx = d; g.Y2 = jy; g.ldy2 = d; g.ln_w = jw; g.ln_b = jb;
       AC_TRY(launch_dec_gemm<PRO_ADDLN>(g, s));
@@ -1408,11 +1433,11 @@ int classifier_step(const ac_trm_weights* w, const StepOut& fin, int R, float* x
   // classifier once per 16 rows: 47 us per step; the residual join as its own launch + the tiled exact-f32 GEMM (ac_gemm)
   // take 4 + 30.  Another summation order than the projection's (last bits of the logits; not a precision change).
   // AUDIOCAPTION_DEC_CLS_GEMM=0: the projection at every row count.
-  if (wide_route(w, R) && (!xout || (ldxo % 4 == 0 && !((uintptr_t)xout & 15)))) {
+  if ((wide_route(w, R) || hybrid_route(w, R)) && (!xout || (ldxo % 4 == 0 && !((uintptr_t)xout & 15)))) {
     size_t wcls;
     pack_layout(w, nullptr, nullptr, &wcls);
     const char* e = getenv("AUDIOCAPTION_DEC_WIDE_CLS_NTB");
-    const int cls_ntb = e ? atoi(e) : 2;
+    const int cls_ntb = e ? atoi(e) : (R >= 512 ? 4 : 2);   // 64-column groups per workgroup: the LayerNorm of a 32-row tile is redone once per group block
     return ac_dec_wide_gemm(2, fin.x, w->d_model, fin.y, w->d_model, fin.ln_w, fin.ln_b, nullptr, 0, 0, nullptr, nullptr, 0.f,
                             xout, ldxo, w->step_pk + wcls, nullptr, logit, ldl, R, w->vocab, w->d_model, 0,
                             cls_ntb > 0 ? cls_ntb : 1, 0, (void*)s);

@@ -517,15 +517,10 @@ def bench_effb2(args, ranks, steps, warmup):
     torch.cuda.synchronize()
     enc_ms = e0.elapsed_time(e1) / 3
     alg_bytes = 100e6 * (args.seconds / 10.0) * B
-    traffic, tsrc = None, None
-    for name in ("r05_traffic_effb2.json", "r04_traffic_effb2.json", "r03_traffic_effb2.json", "r02_traffic_effb2.json", "r01_traffic_effb2.json"):
-        tpath = os.path.join(REPO, "profiles", name)
-        if os.path.exists(tpath) and args.seconds == 10.0:
-            with open(tpath) as f:   # PMC-measured HBM bytes per clip (collected in separate --pmc passes), scaled to B
-                traffic = json.load(f).get("hbm_bytes_per_clip")
-                traffic = traffic * B if traffic else None
-            tsrc = f"profiles/{name} (rocprofv3 --pmc passes of the same command, not this run)"
-            break
+    traffic, tsrc = (None, None)
+    if args.seconds == 10.0:   # PMC-measured HBM bytes per clip (collected in separate --pmc passes), scaled to B
+        per_clip, tsrc = pmc_traffic(EFFB2_TRAFFIC_FILE, "hbm_bytes_per_clip", False)
+        traffic = per_clip * B if per_clip else None
     return {
         "encoder_roofline": {"bound": "hbm", "achieved": alg_bytes / (enc_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": alg_bytes / (enc_ms * 1e-3) / 8e12, "traffic": traffic, "traffic_source": tsrc,
@@ -689,28 +684,54 @@ def sustained_mfma_tflops(dev):
     return rate
 
 
-def conv_roofline(tier, events):
-    """Roofline object of the dominant conv kernel from the HIP events the launch hook collected.  One convention for every
-    tier: ``achieved`` = ALGORITHMIC direct-convolution f32 FLOPs / kernel time; ``frac`` = MFMA FLOPs actually issued
-    (achieved x the tier's products per direct product) / the dense peak of the pipe they run on."""
+# HBM bytes per launch of a tier's dominant conv kernel come from rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE collected in
+# their own runs, tools/round_profiles.sh + tools/collect_profiles.py): a FILE per tier, named here with the round that measured
+# it.  No fallback chain: a file that has gone missing is an error for the headline tier (the number would silently be another
+# round's), and `traffic_source` travels in the top-level line.
+TRAFFIC_FILES = {"wino43": "r06_traffic_wino43.json", "wino1d": "r03_traffic_wino1d.json", "bf16x3": "r01_traffic_bf16x3.json",
+                 "f16x2": "r02_traffic_f16x2.json", "winograd": None}
+EFFB2_TRAFFIC_FILE = "r06_traffic_effb2.json"
+
+
+def pmc_traffic(name, key, required):
+    """(value of `key`, source string) from profiles/<name>; (None, None) when the tier has no PMC file; raises when a file
+    that should exist does not."""
+    if name is None:
+        return None, None
+    tpath = os.path.join(REPO, "profiles", name)
+    if not os.path.exists(tpath):
+        if required:
+            raise FileNotFoundError(f"{tpath}: the PMC traffic summary this bench line cites is missing "
+                                    "(tools/round_profiles.sh + tools/collect_profiles.py write it)")
+        return None, None
+    with open(tpath) as f:
+        return json.load(f).get(key), f"profiles/{name} (separate rocprofv3 --pmc passes of the same command, not this run)"
+
+
+def conv_roofline(tier, events, required_traffic=False):
+    """Roofline object of the dominant conv kernel from the HIP events the launch hook collected.  ONE convention:
+    ``achieved`` = ALGORITHMIC direct-convolution f32 FLOPs / kernel time; ``frac`` = achieved / the dense peak of the pipe the
+    kernel runs on (the roofline fraction); ``mfma_issue_frac`` = MFMA FLOPs actually ISSUED (achieved x the tier's products per
+    direct product) / that peak (pipe utilisation).  The exact-f32 tier is the one exception, and says so: Winograd F(2x2,3x3)
+    issues 2.25x FEWER products than the direct form on the same f32 pipe, so algorithmic / peak exceeds 1 and means nothing as
+    a roofline fraction - its ``frac`` is the issued fraction, the algorithmic ratio is kept as ``algorithmic_over_peak``."""
     t = TIERS[tier]
     flops = sum(2.0 * 9 * i["Cin"] * i["Cout"] * i["H"] * i["W"] * i["B"] for _, _, i in events)
     ms = sum(s.elapsed_time(e) for s, e, _ in events)
     n = len(events)
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    traffic, tsrc = None, None
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
-        tpath = os.path.join(REPO, "profiles", f"{rnd}_traffic_{t['conv_algo']}.json")
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
-            tsrc = f"profiles/{rnd}_traffic_{t['conv_algo']}.json (separate rocprofv3 --pmc passes, not this run)"
-            break
-    return {"bound": "mfma", "achieved": achieved, "peak": t["peak"], "unit": "TFLOP/s",
-            "frac": achieved / t["peak"], "mfma_issue_frac": achieved * t["issue_ratio"] / t["peak"],
-            "issued_per_algorithmic": t["issue_ratio"], "traffic": traffic, "traffic_source": tsrc,
-            "kernel": t["kernel"], "launches_timed": n, "avg_launch_ms": ms / n if n else None,
-            "algorithmic_gflop_per_launch": flops / n / 1e9 if n else None}
+    traffic, tsrc = pmc_traffic(TRAFFIC_FILES.get(t["conv_algo"]), "hbm_bytes_per_launch", required_traffic)
+    issue = achieved * t["issue_ratio"] / t["peak"]
+    out = {"bound": "mfma", "achieved": achieved, "peak": t["peak"], "unit": "TFLOP/s",
+           "frac": achieved / t["peak"], "mfma_issue_frac": issue,
+           "issued_per_algorithmic": t["issue_ratio"], "traffic": traffic, "traffic_source": tsrc,
+           "kernel": t["kernel"], "launches_timed": n, "avg_launch_ms": ms / n if n else None,
+           "algorithmic_gflop_per_launch": flops / n / 1e9 if n else None}
+    if t["issue_ratio"] < 1.0:
+        out["algorithmic_over_peak"] = out["frac"]
+        out["frac"] = issue
+        out["frac_note"] = "issued / peak: this tier issues fewer products than the direct form (see conv_roofline)"
+    return out
 
 
 def main():
@@ -876,7 +897,9 @@ def main():
     elapsed, out, events = measure(default_tier, args.steps, args.warmup)
     elapsed_own = ranks.last_own
     ref_steps = min(int((out["unfinished_cnt"].cpu() > 0).sum().item()) + 1, args.max_length)
-    headline_roof = conv_roofline(default_tier, events)
+    # the headline line cites this round's PMC file: missing = error (AUDIOCAPTION_TRAFFIC_OPTIONAL=1: the collection passes
+    # themselves, tools/round_profiles.sh, which run before the file exists)
+    headline_roof = conv_roofline(default_tier, events, required_traffic=os.environ.get("AUDIOCAPTION_TRAFFIC_OPTIONAL") != "1")
     tiers = {default_tier: {"value": world * B * args.steps / elapsed, "unit": "clips/s", "ms_per_step": elapsed / args.steps * 1e3,
                             "steps": args.steps, "conv_algo": default_algo, "dtype": TIERS[default_tier]["dtype"],
                             "precision_gate": TIERS[default_tier]["gate"], "roofline": headline_roof}}
@@ -1185,7 +1208,7 @@ def main():
                        "schedule": "blocking model() per step" if args.sync_steps else
                                    "forward_async: encoder of step i+1 under the decode chain of step i (two HIP streams)"},
             "roofline": dict({k: headline_roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "mfma_issue_frac",
-                                                            "issued_per_algorithmic", "traffic", "avg_launch_ms",
+                                                            "issued_per_algorithmic", "traffic", "traffic_source", "avg_launch_ms",
                                                             "launches_timed", "kernel")}, **sustained),
             # flat scalars, all measured in this run
             "value_f32_exact": val(tiers.get("f32")),

@@ -4,10 +4,14 @@ accuracy?  CPU emulation on the oracle's conv stack: every 3x3 convolution after
     direct   : x (f32) * w, operands split hi + lo in <fmt>, products hi*hi + hi*lo + lo*hi     (today's "bf16x3" tier)
     wino2d   : F(2x2,3x3): V = B^T d B in f32 then split, U = G g G^T in f64 then split, 16 GEMMs of 3 products
     wino1d   : F(2,3) along the time axis only (4 positions x 3 mel taps), same splitting
+    wino43   : F(4,3) along the time axis only (6 positions x 3 mel taps): the default tier's arithmetic
+    nest43x23: F(4,3) along time x F(2,3) along mel (24 positions per 4 x 2 outputs: 3 products per output instead of 4.5) -
+               the 2-D nest priced in DESIGN.md section 7 (round 6: accuracy is NOT what rules it out)
+    nest43x43: F(4,3) x F(4,3) (36 positions per 16 outputs), for the trend
 
 with f32 accumulation, and the greedy logits are compared with the plain fp32 oracle.
 
-    python tests/wino_split_emulation.py [seconds=4] [max_blocks=6]
+    python tests/wino_split_emulation.py [seconds=4] [max_blocks=6] [names, comma separated]
 """
 import os
 import sys
@@ -89,6 +93,35 @@ def conv_wino1d(x, w, fmt, flush):
     return Y[:, :, :H]
 
 
+# F(4,3), points 0, +-1, +-2, inf (Lavin & Gray) - the matrices csrc/ac_wino43.h spells out row by row
+BT4 = torch.tensor([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0],
+                    [0, 4, 0, -5, 0, 1]], dtype=torch.float64)
+G4 = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6],
+                   [0, 0, 1]], dtype=torch.float64)
+AT4 = torch.tensor([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], dtype=torch.float64)
+# "F(1,3)": the direct form as a degenerate transform (three positions = the three taps)
+BT1, G1, AT1 = torch.eye(3, dtype=torch.float64), torch.eye(3, dtype=torch.float64), torch.ones(1, 3, dtype=torch.float64)
+XF = {1: (BT1, G1, AT1), 2: (BT, G, AT), 4: (BT4, G4, AT4)}
+
+
+def conv_wino_nest(x, w, fmt, flush, mh, mw):
+    """F(mh,3) along H (time) nested with F(mw,3) along W (mel); m = 1 is the direct form along that axis.  Input transform in
+    f32 BEFORE the split, filter transform in f64 before the split, one split product per position, f32 accumulation."""
+    B, C, H, W = x.shape
+    (bth, gh, ath), (btw, gw, atw) = XF[mh], XF[mw]
+    ah, aw = mh + 2, mw + 2
+    He, We = -(-H // mh) * mh, -(-W // mw) * mw
+    xp = F.pad(x, (1, 1 + We - W, 1, 1 + He - H))
+    tiles = xp.unfold(2, ah, mh).unfold(3, aw, mw)       # (B, C, th, tw, ah, aw)
+    th, tw = tiles.shape[2], tiles.shape[3]
+    V = torch.einsum("ia,bctuak,jk->bijctu", bth.float(), tiles, btw.float()).reshape(B, ah, aw, C, th * tw)
+    U = torch.einsum("ia,ocak,jk->ijoc", gh, w.double(), gw)   # (ah, aw, O, C) f64
+    M = mm3(U[None], V, fmt, flush)                      # (B, ah, aw, O, nt)
+    Y = torch.einsum("ai,bijon,cj->boacn", ath.float(), M, atw.float())   # (B, O, mh, mw, nt)
+    Y = Y.reshape(B, -1, mh, mw, th, tw).permute(0, 1, 4, 2, 5, 3).reshape(B, -1, He, We)
+    return Y[:, :, :H, :W]
+
+
 def conv_stack(state, lms, conv, blocks, prefix="encoder.cnn."):
     x = lms.transpose(1, 2).unsqueeze(1)
     x = O._bn_eval(x.transpose(1, 3), state, prefix + "bn0").transpose(1, 3)
@@ -129,8 +162,15 @@ def main():
         ref = logits(ref_attn)
         st = ref["steps"]
         print(f"{sec} s clips, {flen.tolist()} frames, Winograd / split emulation on blocks 1..{blocks} (conv1 of block 1 exact)")
-        for name, fn in (("direct", conv_direct), ("wino1d", conv_wino1d), ("wino2d", conv_wino2d)):
+        nest = lambda mh, mw: (lambda x, w, fmt, flush: conv_wino_nest(x, w, fmt, flush, mh, mw))
+        only = sys.argv[3].split(",") if len(sys.argv) > 3 else None
+        for name, fn in (("direct", conv_direct), ("wino1d", conv_wino1d), ("wino2d", conv_wino2d), ("wino43", nest(4, 1)),
+                         ("nest43x23", nest(4, 2)), ("nest43x43", nest(4, 4))):
+            if only and name not in only:
+                continue
             for fmt, flush in (("bf16", False), ("f16", False), ("f16", True)):
+                if name.startswith(("wino43", "nest")) and fmt != "bf16":
+                    continue
                 attn = conv_stack(state, lms, lambda x, w: fn(x, w, fmt, flush), blocks)
                 out = logits(attn)
                 da = float((attn - ref_attn).abs().max())

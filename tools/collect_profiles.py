@@ -11,7 +11,7 @@ import re
 import shutil
 import sys
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r05"
+R = sys.argv[1] if len(sys.argv) > 1 else "r06"
 TIER = sys.argv[2] if len(sys.argv) > 2 else "wino43"
 src, dst = "gpurun_out", "profiles"
 names = {f"{R}_bench_final.json": f"{R}_bench.json", f"{R}_bench_details.json": None, f"{R}_kernel_stats.txt": None,
