@@ -1240,13 +1240,14 @@ inline bool wide_route(const ac_trm_weights* w, int R) {
   return wide_min > 0 && R >= wide_min && wide_shape_ok(w) && w->d_model / w->nhead <= 64 && w->d_model % w->nhead == 0;
 }
 
-// From 512 rows on (a beam search over grouped batches) two launches of the narrow route are far from their arithmetic: the
-// QKV projection with the residual join in its prologue (30 us at 768 rows: 24 column blocks per 16-row tile each redo the
-// LayerNorm) and the classifier (LayerNorm launch + tiled exact-f32 GEMM: 8 + 49 us).  Both have a wide twin with the same
-// inputs and outputs (csrc/decoder_wide.hip, f32-grade on the bf16 matrix cores): 11 and ~25 us.  AUDIOCAPTION_DEC_HYBRID=0: off.
+// AUDIOCAPTION_DEC_HYBRID=1 (default off): from 512 rows on (a beam search over grouped batches) the QKV projection with the
+// residual join in its prologue and the classifier take their wide twins (csrc/decoder_wide.hip).  Stand-alone those are the
+// two launches of the narrow route furthest from their arithmetic (20 and 30 + 5 us at 768 rows against 11 and 27); inside the
+// EffB2-Trm pipeline the wide classifier's one-workgroup-per-CU blocks take 43 us beside the encoder and the step does not move
+// (20.41 vs 20.41 k clips/s, 30 s / beam 4: 7.70 vs 7.70 k): opt-in, kept for the record.
 inline bool hybrid_route(const ac_trm_weights* w, int R) {
   const char* e = getenv("AUDIOCAPTION_DEC_HYBRID");
-  return !(e && !strcmp(e, "0")) && R >= 512 && wide_shape_ok(w);
+  return e && !strcmp(e, "1") && R >= 512 && wide_shape_ok(w);
 }
 
 int decoder_step(const ac_trm_weights* w, const float* memkv, const int* mem_len, int R, int row_div, int Tm,

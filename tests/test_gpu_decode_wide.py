@@ -244,17 +244,17 @@ def test_general_launch_sequence_at_512_rows_and_more(hip_model, monkeypatch):
 
 
 def test_hybrid_route_from_512_rows_equals_the_narrow_kernels(hip_model, monkeypatch):
-    """From 512 rows on the joined QKV projection and the classifier run on their wide twins (AUDIOCAPTION_DEC_HYBRID, default
-    on): same ids and stop bookkeeping as the all-narrow chain, logits within 2e-5; below 512 rows nothing changes (bit-equal)."""
+    """AUDIOCAPTION_DEC_HYBRID=1 (opt-in): from 512 rows on the joined QKV projection and the classifier run on their wide twins -
+    same ids and stop bookkeeping as the all-narrow chain, logits within 2e-5; below 512 rows nothing changes (bit-equal)."""
     dec = hip_model.decoder
     monkeypatch.setenv("AUDIOCAPTION_DECODE_GRAPH", "0")
     monkeypatch.setenv("AUDIOCAPTION_DEC_WIDE_MIN", "0")
     for B, differs in ((530, True), (300, False)):
         attn, lens = _enc(B, 15, seed=B)
         args = (attn.cuda(), lens, 10, hip_model.start_idx, hip_model.end_idx, hip_model.pad_idx)
-        monkeypatch.setenv("AUDIOCAPTION_DEC_HYBRID", "0")
+        monkeypatch.delenv("AUDIOCAPTION_DEC_HYBRID", raising=False)
         want = dec.greedy(*args, mode="chain")
-        monkeypatch.delenv("AUDIOCAPTION_DEC_HYBRID")
+        monkeypatch.setenv("AUDIOCAPTION_DEC_HYBRID", "1")
         got = dec.greedy(*args, mode="chain")
         torch.cuda.synchronize()
         np.testing.assert_array_equal(got["seq"].cpu().numpy(), want["seq"].cpu().numpy())
