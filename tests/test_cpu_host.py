@@ -66,6 +66,20 @@ def test_argument_validation_without_gpu(lib_path):
     assert lib.ac_trm_workspace_floats(ctypes.byref(w), 4, 20) == -1  # zeroed config is invalid
 
 
+def test_wide_decode_projection_sizes_and_argument_validation(lib_path):
+    """csrc/decoder_wide.hip through the C ABI without a GPU: the pack size formula (32-row tiles x 16-k steps x three 1 KiB
+    planes), and what the projection refuses before it would launch anything."""
+    lib = _lib.load()
+    assert lib.ac_dec_wide_packed_floats(100, 64) == 4 * 4 * 768
+    assert lib.ac_dec_wide_packed_floats(4368, 256) == 137 * 16 * 768
+    assert lib.ac_dec_wide_packed_floats(64, 24) == -1                       # K in 16-element steps
+    nul = None
+    call = lambda pro, K, ntb, split: lib.ac_dec_wide_gemm(pro, nul, 0, nul, 0, nul, nul, nul, 0, 0, nul, nul, 0.0, nul, 0,
+                                                           nul, nul, nul, 64, 64, 64, K, 0, ntb, split, nul)
+    assert call(0, 256, 1, 0) == -1 and call(2, 256, 1, 0) == -1 and call(3, 256, 1, 0) == -1   # null operands, unknown producer
+    assert lib.ac_dec_wide_pack(nul, 256, 64, 256, nul, nul) == -1
+
+
 def test_workspace_size_formula(lib_path):
     lib = _lib.load()
     w = _lib.AcTrmWeights()
