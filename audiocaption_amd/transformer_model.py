@@ -644,7 +644,10 @@ class TransformerModel(CaptionModel):
                     check(lib.ac_trm_beam_reorder(w, R, max_length, t, ptr(src_row), ptr(ws), stream()),
                           "ac_trm_beam_reorder")
 
-        bounds = [b for b in (0, 8, 12, 16) if b < max_length] + [max_length]
+        # AUDIOCAPTION_BEAM_SEGMENTS="0,8,12,16" (default): the steps after which the host asks whether any clip is still searching
+        # ("0": never - one launch sequence for the whole search, no host synchronisation inside it)
+        seg = [int(v) for v in os.environ.get("AUDIOCAPTION_BEAM_SEGMENTS", "0,8,12,16").split(",") if v.strip() != ""]
+        bounds = sorted({0} | {b for b in seg if 0 < b < max_length}) + [max_length]
         return {"st": st, "segment": segment, "bounds": bounds, "next": 0, "use_graph": use_graph and st["uses"] >= 2,
                 "dev": dev, "B": B, "beam": beam, "max_length": max_length, "cap": cap, "V": V, "n_best": n_best,
                 "n_best_size": n_best_size}
