@@ -198,13 +198,19 @@ def test_beam_at_the_clotho_vocabulary_vs_oracle(clotho_models, golden_dir, kind
     np.testing.assert_array_equal(outn["seq"].numpy(), wantn.numpy())
 
 
+@pytest.mark.parametrize("route", ["default", "wide", "hybrid"])
 @pytest.mark.parametrize("kind", ["plain", "beam"])
-def test_beam_over_512_rows_takes_the_tiled_classifier_and_matches_the_oracle(clotho_models, golden_dir, kind):
+def test_beam_over_512_rows_takes_the_tiled_classifier_and_matches_the_oracle(clotho_models, golden_dir, kind, route, monkeypatch):
     """From 512 decode rows on (beam search over grouped batches) the classifier runs as LayerNorm + the tiled exact-f32 GEMM
     instead of the 16 x 16-tile projection (csrc/decoder.hip classifier_step): 176 clips x beam 3 = 528 rows - the g4 clips
-    repeated - must give every copy the oracle's caption of its clip (base.py:254-361), like the 12-row search does."""
+    repeated - must give every copy the oracle's caption of its clip (base.py:254-361), like the 12-row search does.  The two
+    opt-in routes of csrc/decoder_wide.hip (every projection / only the joined QKV projection and the classifier on the
+    three-plane bf16 kernels; three beams share a clip's audio memory: row_div = 3) are held to the same captions."""
     import os
     from oracle import cpu_path as O
+    if route != "default":
+        monkeypatch.setenv("AUDIOCAPTION_DECODE_GRAPH", "0")     # eager launches: the route switch is read by every call
+        monkeypatch.setenv("AUDIOCAPTION_DEC_WIDE_MIN" if route == "wide" else "AUDIOCAPTION_DEC_HYBRID", "128" if route == "wide" else "1")
     model, st = clotho_models[kind]
     g4 = dict(np.load(os.path.join(golden_dir, "g4_greedy.npz")))
     attn, alen = torch.from_numpy(g4["attn_emb"]), torch.from_numpy(g4["attn_emb_len"])
