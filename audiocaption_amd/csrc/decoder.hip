@@ -1229,7 +1229,7 @@ struct StepOut {
 };
 
 // AUDIOCAPTION_DEC_WIDE_MIN=n (default 0 = never): a step over n rows or more takes the wide route.  Opt-in, because it does
-// not pay on this part: stand-alone it is 145 / 217 us per step at 256 / 768 rows against 115 / 193 for the narrow route
+// not pay on this part: stand-alone it is 145 / 202 us per step at 256 / 768 rows against 115 / 193 for the narrow route
 // (22 launches per step instead of 10, each ~3 us of launch overhead + a 3-5 us critical path, although a projection
 // occupies 32-128 workgroups for 3-5 us instead of every CU for 7-18), and beside the next batches' encoders the step
 // costs what its DURATION is, not its CU time: headline 13.85 k vs 14.10 k clips/s, EffB2-Trm 20.65 k vs 20.55 k

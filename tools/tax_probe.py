@@ -81,7 +81,13 @@ print(f"conv stack alone: {base:.3f} / {base2:.3f} ms per batch of {B}")
 base = min(base, base2)
 K = 50
 MODES = {0: "asleep", 1: "FMAs", 2: "loads", 3: "stream"}
-for vgprs, blocks, threads, lds, spin, mode in ((56, 256, 256, 0, 16, 3), (128, 256, 256, 0, 16, 3), (56, 256, 256, 24576, 16, 3),
+for vgprs, blocks, threads, lds, spin, mode in ((24, 1, 64, 0, 2, 0),                                     # launches alone
+                                                # the register / LDS cliff (asleep: no contention, only residency)
+                                                (24, 256, 256, 0, 8, 0), (56, 256, 256, 0, 8, 0), (64, 256, 256, 0, 8, 0),
+                                                (72, 256, 256, 0, 8, 0), (96, 256, 256, 0, 8, 0), (128, 256, 256, 0, 8, 0),
+                                                (56, 256, 256, 32768, 8, 0), (56, 256, 256, 65536, 8, 0), (56, 256, 256, 90112, 8, 0),
+                                                # work that moves bytes: sharing a CU vs waiting for one
+                                                (56, 256, 256, 0, 16, 3), (128, 256, 256, 0, 16, 3), (56, 256, 256, 24576, 16, 3),
                                                 (128, 256, 256, 24576, 16, 3), (56, 768, 256, 0, 8, 3), (128, 768, 256, 0, 8, 3),
                                                 (56, 256, 256, 0, 16, 1), (128, 256, 256, 0, 16, 1), (56, 64, 256, 0, 16, 3),
                                                 (128, 64, 256, 0, 16, 3)):
